@@ -1,0 +1,138 @@
+/*
+ * quanto_hip.h - C ABI of libquanto_hip.so, the MI355X (gfx950 / CDNA4) backend for the
+ * optimum-quanto QLinear hot path.
+ *
+ * Every entry point replaces one piece of the reference's per-call work (paths are relative to
+ * /root/reference/optimum/quanto).  The reference binds native code through pybind11 torch
+ * extensions loaded by library/extensions/extension.py:12-55; this library is the torch-free
+ * equivalent: plain pointers, sizes and a HIP stream, so it can be bound from ctypes (what
+ * optimum-quanto_amd/library does), from a pybind11 shim, or from C++ directly.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers owned by the caller; the library never allocates,
+ *    frees or copies device memory and keeps no state between calls.
+ *  - Matrices are dense row-major.  Weights are [N, K] ("out_features, in_features"),
+ *    activations [M, K], outputs [M, N].
+ *  - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  The
+ *    device that owns the buffers must be current in the calling thread (the Python shim
+ *    wraps each call in torch.cuda.device(tensor.device)).
+ *  - Every function returns QUANTO_HIP_OK (0) or a negative quanto_hip_status; nothing is
+ *    written when an argument is rejected.  Launch failures surface as QUANTO_HIP_ELAUNCH
+ *    with hipGetLastError() consumed.  Calls are asynchronous with respect to the host.
+ */
+#ifndef QUANTO_HIP_H_
+#define QUANTO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QUANTO_HIP_ABI_VERSION 1
+
+typedef enum {
+  QUANTO_HIP_OK = 0,
+  QUANTO_HIP_EINVAL = -1,   /* bad argument (null pointer, negative size, bits not in {2,4}, ...) */
+  QUANTO_HIP_ENOTSUP = -2,  /* valid but unsupported dtype / layout combination                   */
+  QUANTO_HIP_ELAUNCH = -3,  /* the HIP runtime rejected the launch                                 */
+  QUANTO_HIP_EALIGN = -4    /* a pointer violates the documented alignment                         */
+} quanto_hip_status;
+
+typedef enum {
+  QUANTO_HIP_F32 = 0,
+  QUANTO_HIP_F16 = 1,
+  QUANTO_HIP_BF16 = 2,
+  QUANTO_HIP_I8 = 3,
+  QUANTO_HIP_U8 = 4,
+  QUANTO_HIP_F8_E4M3FN = 5,   /* OCP e4m3 - gfx950's native fp8 */
+  QUANTO_HIP_F8_E5M2 = 6,
+  QUANTO_HIP_F8_E4M3FNUZ = 7  /* MI300-era encoding; decoded in software */
+} quanto_hip_dtype;
+
+/* Kernel selection for the *_mm entry points.  AUTO is what product code uses; the others
+ * exist so tests and benchmarks can pin one implementation. */
+typedef enum {
+  QUANTO_HIP_KERNEL_AUTO = 0,
+  QUANTO_HIP_KERNEL_NAIVE = 1, /* one thread per output element, any shape                      */
+  QUANTO_HIP_KERNEL_GEMV = 2,  /* weight-streaming kernel for M <= QUANTO_HIP_GEMV_MAX_M         */
+  QUANTO_HIP_KERNEL_MFMA = 3   /* LDS-tiled MFMA kernel                                          */
+} quanto_hip_kernel;
+
+#define QUANTO_HIP_GEMV_MAX_M 8
+
+int quanto_hip_abi_version(void);
+const char* quanto_hip_status_string(int status);
+
+/* Name of the kernel the last successful *_mm call on this thread dispatched to
+ * ("naive", "gemv", "mfma", ...).  Used by tests to assert that the intended path ran. */
+const char* quanto_hip_last_kernel(void);
+
+/*
+ * quanto::unpack(Tensor self, int bits) -> Tensor
+ *   replaces library/extensions/hip/unpack.cu:33-97 (bound at library/extensions/hip/__init__.py:34-36),
+ *   semantics of library/unpack.py:21-54.
+ * packed: uint8[packed_numel]; unpacked: uint8[packed_numel * 8 / bits].
+ * Plane i (i < 8/bits) of the output, i.e. unpacked[i*packed_numel + j], is
+ * (packed[j] >> (bits*i)) & ((1<<bits)-1): the planes are concatenated along dim 0.
+ */
+int quanto_hip_unpack(const uint8_t* packed, uint8_t* unpacked, int64_t packed_numel, int bits, void* stream);
+
+/*
+ * Fused PackedTensor.unpack + QBitsDequantizer.forward + ungroup for axis-0 weights
+ *   replaces tensor/packed.py:101-104 + tensor/qbits.py:27-49 + tensor/grouped.py:39-51
+ *   (three elementwise passes and a 2x intermediate in the reference).
+ * packed:  uint8[ceil(R / (8/bits)), C] generic PackedTensor layout of the grouped weight, where
+ *          C = group_size (or K when group_size == 0, i.e. per-channel) and R = N*K/C grouped rows.
+ * scale:   dtype[R]; shift: shift_dtype[R] with shift_dtype == dtype (float shift) or U8/I8
+ *          (integer zero-point).
+ * out:     dtype[N, K].  The rounding sequence is the reference's: float shift ->
+ *          round(round(scale*q) - shift), zero-point -> round(scale*(q - zp)); the result is
+ *          bit-identical to the reference CPU dequantize() in every dtype.
+ */
+int quanto_hip_dequantize_qbits(const uint8_t* packed, const void* scale, const void* shift, void* out,
+                                int64_t N, int64_t K, int bits, int group_size, int dtype, int shift_dtype,
+                                void* stream);
+
+/*
+ * quanto::qbits_mm - the fused product behind QLinear.forward for qint4/qint2 weights
+ *   replaces QuantizedLinearFunction.forward (tensor/function.py:41-47) applied to
+ *   QBitsDequantizer's output (tensor/qbits.py:27-49): y = x @ dequant(W).T (+ bias).
+ *   The reference has no such op; its CUDA analogs are gemm_f16i4_awq / gemm_f16i4_marlin
+ *   (library/extensions/cuda/__init__.py:82-121,170-202).
+ * x: dtype[M, K]; packed/scale/shift as in quanto_hip_dequantize_qbits; bias: dtype[N] or NULL;
+ * y: dtype[M, N].  dtype in {F32, F16, BF16}.  Accumulation is fp32; the dequantized weight is
+ * never materialised in HBM.
+ */
+int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale, const void* shift,
+                        const void* bias, void* y, int64_t M, int64_t N, int64_t K, int bits, int group_size,
+                        int dtype, int shift_dtype, int kernel, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+/*
+ * Scratch bytes quanto_hip_qbits_mm needs for this problem (0 when the selected kernel needs none).
+ * The caller allocates it (16-byte aligned), passes it as `workspace` and may reuse it for any later
+ * call on the same stream.  The MFMA kernel stores the per-group row sums of x there
+ * (fp32 [K/group_size][roundup(M,128)]).  Returns a negative status on invalid arguments.
+ */
+int64_t quanto_hip_qbits_mm_workspace_size(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype,
+                                           int kernel);
+
+/*
+ * quanto::qbytes_mm(Tensor A, Tensor B, Tensor scales) -> Tensor
+ *   replaces library/qbytes_mm.py:25-50,73-88: y = (A @ B.T) * scales.T, fp32 (or int32) accumulate.
+ * a: a_dtype[M, K] with a_dtype in {F32,F16,BF16} (float activations) or I8 / F8_* (quantized
+ *    activations, tensor/weights/qbytes.py:72-73);
+ * b: b_dtype[N, K] with b_dtype in {I8, F8_E4M3FN, F8_E5M2, F8_E4M3FNUZ};
+ * scales: out_dtype[N] (the reference passes (N,1) or a (1,N)-broadcastable product);
+ * bias: out_dtype[N] or NULL; y: out_dtype[M, N].
+ */
+int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const void* bias, void* y,
+                         int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype, int kernel,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUANTO_HIP_H_ */

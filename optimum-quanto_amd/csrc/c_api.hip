@@ -1,0 +1,167 @@
+// extern "C" surface of libquanto_hip.so: argument validation + kernel selection.  No torch, no allocation.
+#include "qh_common.h"
+
+namespace qh {
+
+static thread_local const char* g_last_kernel = "";
+void set_last_kernel(const char* name) { g_last_kernel = name; }
+
+int launch_status() { return hipGetLastError() == hipSuccess ? QUANTO_HIP_OK : QUANTO_HIP_ELAUNCH; }
+
+// implemented in the kernel translation units
+int unpack_dispatch(const uint8_t*, uint8_t*, int64_t, int, hipStream_t);
+int dequantize_qbits_dispatch(const uint8_t*, const void*, const void*, void*, const PackedGeom&, int, bool, hipStream_t);
+int qbytes_mm_naive(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
+int qbits_mm_naive(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool,
+                   hipStream_t);
+bool qbits_gemv_supported(int64_t, const PackedGeom&, int);
+int qbits_mm_gemv(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool,
+                  hipStream_t);
+bool qbytes_gemv_supported(int64_t, int64_t, int64_t, int, int, int);
+int qbytes_mm_gemv(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
+bool qbytes_mfma_supported(int64_t, int64_t, int64_t, int, int, int);
+int qbytes_mm_mfma(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
+bool qbits_mfma_supported(int64_t, const PackedGeom&, int);
+size_t qbits_mfma_workspace(int64_t, const PackedGeom&);
+int qbits_mm_mfma(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, void*,
+                  size_t, hipStream_t);
+
+static bool is_float_dtype(int dt) { return dt == QUANTO_HIP_F32 || dt == QUANTO_HIP_F16 || dt == QUANTO_HIP_BF16; }
+
+static int check_qbits(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype, int shift_dtype, bool* int_shift) {
+  if (M < 0 || N <= 0 || K <= 0) return QUANTO_HIP_EINVAL;
+  if (bits != 2 && bits != 4) return QUANTO_HIP_EINVAL;
+  if (group_size < 0) return QUANTO_HIP_EINVAL;
+  if (group_size > 0 && (K % group_size) != 0) return QUANTO_HIP_EINVAL;
+  if (!is_float_dtype(dtype)) return QUANTO_HIP_ENOTSUP;
+  if (shift_dtype == dtype)
+    *int_shift = false;
+  else if (shift_dtype == QUANTO_HIP_U8 || shift_dtype == QUANTO_HIP_I8)
+    *int_shift = true;
+  else
+    return QUANTO_HIP_ENOTSUP;
+  return QUANTO_HIP_OK;
+}
+
+// M above which the weight-streaming GEMV stops being the better choice (it re-reads W once per 4 (int4) / 2 (int8) rows of x)
+static bool prefer_gemv(int64_t M) { return M <= QUANTO_HIP_GEMV_MAX_M; }
+
+}  // namespace qh
+
+using namespace qh;
+
+extern "C" {
+
+int quanto_hip_abi_version(void) { return QUANTO_HIP_ABI_VERSION; }
+
+const char* quanto_hip_status_string(int status) {
+  switch (status) {
+    case QUANTO_HIP_OK: return "ok";
+    case QUANTO_HIP_EINVAL: return "invalid argument";
+    case QUANTO_HIP_ENOTSUP: return "unsupported dtype/layout combination";
+    case QUANTO_HIP_ELAUNCH: return "HIP kernel launch failed";
+    case QUANTO_HIP_EALIGN: return "pointer is not 16-byte aligned";
+  }
+  return "unknown status";
+}
+
+const char* quanto_hip_last_kernel(void) { return g_last_kernel; }
+
+int quanto_hip_unpack(const uint8_t* packed, uint8_t* unpacked, int64_t packed_numel, int bits, void* stream) {
+  if (bits != 2 && bits != 4) return QUANTO_HIP_EINVAL;
+  if (packed_numel < 0) return QUANTO_HIP_EINVAL;
+  if (packed_numel > 0 && (packed == nullptr || unpacked == nullptr)) return QUANTO_HIP_EINVAL;
+  return unpack_dispatch(packed, unpacked, packed_numel, bits, reinterpret_cast<hipStream_t>(stream));
+}
+
+int quanto_hip_dequantize_qbits(const uint8_t* packed, const void* scale, const void* shift, void* out, int64_t N, int64_t K, int bits,
+                                int group_size, int dtype, int shift_dtype, void* stream) {
+  bool int_shift = false;
+  const int st = check_qbits(0, N, K, bits, group_size, dtype, shift_dtype, &int_shift);
+  if (st != QUANTO_HIP_OK) return st;
+  if (!packed || !scale || !shift || !out) return QUANTO_HIP_EINVAL;
+  const PackedGeom g = make_geom(N, K, bits, group_size);
+  return dequantize_qbits_dispatch(packed, scale, shift, out, g, dtype, int_shift, reinterpret_cast<hipStream_t>(stream));
+}
+
+int64_t quanto_hip_qbits_mm_workspace_size(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype, int kernel) {
+  bool int_shift = false;
+  const int st = check_qbits(M, N, K, bits, group_size, dtype, dtype, &int_shift);
+  if (st != QUANTO_HIP_OK) return st;
+  const PackedGeom g = make_geom(N, K, bits, group_size);
+  if (kernel == QUANTO_HIP_KERNEL_NAIVE || kernel == QUANTO_HIP_KERNEL_GEMV) return 0;
+  if (kernel == QUANTO_HIP_KERNEL_AUTO && prefer_gemv(M) && qbits_gemv_supported(M, g, dtype)) return 0;
+  if (!qbits_mfma_supported(M, g, dtype)) return 0;
+  return (int64_t)qbits_mfma_workspace(M, g);
+}
+
+int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t M,
+                        int64_t N, int64_t K, int bits, int group_size, int dtype, int shift_dtype, int kernel, void* workspace,
+                        size_t workspace_bytes, void* stream_) {
+  bool int_shift = false;
+  const int st = check_qbits(M, N, K, bits, group_size, dtype, shift_dtype, &int_shift);
+  if (st != QUANTO_HIP_OK) return st;
+  if (M == 0) return QUANTO_HIP_OK;
+  if (!x || !packed || !scale || !shift || !y) return QUANTO_HIP_EINVAL;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const PackedGeom g = make_geom(N, K, bits, group_size);
+  if (kernel == QUANTO_HIP_KERNEL_AUTO) {
+    if (prefer_gemv(M) && qbits_gemv_supported(M, g, dtype))
+      kernel = QUANTO_HIP_KERNEL_GEMV;
+    else if (qbits_mfma_supported(M, g, dtype) && workspace != nullptr && workspace_bytes >= qbits_mfma_workspace(M, g))
+      kernel = QUANTO_HIP_KERNEL_MFMA;
+    else
+      kernel = QUANTO_HIP_KERNEL_NAIVE;
+  }
+  int r;
+  switch (kernel) {
+    case QUANTO_HIP_KERNEL_NAIVE:
+      r = qbits_mm_naive(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("naive");
+      return r;
+    case QUANTO_HIP_KERNEL_GEMV:
+      r = qbits_mm_gemv(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("gemv");
+      return r;
+    case QUANTO_HIP_KERNEL_MFMA:
+      r = qbits_mm_mfma(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, workspace, workspace_bytes, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("mfma");
+      return r;
+  }
+  return QUANTO_HIP_EINVAL;
+}
+
+int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const void* bias, void* y, int64_t M, int64_t N, int64_t K,
+                         int a_dtype, int b_dtype, int out_dtype, int kernel, void* stream_) {
+  if (M < 0 || N <= 0 || K <= 0) return QUANTO_HIP_EINVAL;
+  if (!is_float_dtype(out_dtype)) return QUANTO_HIP_ENOTSUP;
+  if (M == 0) return QUANTO_HIP_OK;
+  if (!a || !b || !scales || !y) return QUANTO_HIP_EINVAL;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (kernel == QUANTO_HIP_KERNEL_AUTO) {
+    if (prefer_gemv(M) && qbytes_gemv_supported(M, N, K, a_dtype, b_dtype, out_dtype))
+      kernel = QUANTO_HIP_KERNEL_GEMV;
+    else if (qbytes_mfma_supported(M, N, K, a_dtype, b_dtype, out_dtype))
+      kernel = QUANTO_HIP_KERNEL_MFMA;
+    else
+      kernel = QUANTO_HIP_KERNEL_NAIVE;
+  }
+  int r;
+  switch (kernel) {
+    case QUANTO_HIP_KERNEL_NAIVE:
+      r = qbytes_mm_naive(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("naive");
+      return r;
+    case QUANTO_HIP_KERNEL_GEMV:
+      r = qbytes_mm_gemv(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("gemv");
+      return r;
+    case QUANTO_HIP_KERNEL_MFMA:
+      r = qbytes_mm_mfma(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("mfma");
+      return r;
+  }
+  return QUANTO_HIP_EINVAL;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// Shared device helpers for libquanto_hip (gfx950 only: wave64, OCP fp8, v_dot2 bf16, MFMA 16x16x32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/quanto_hip.h"
+
+namespace qh {
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+constexpr int kWave = 64;
+
+// ---- element traits for the three float dtypes of the ABI ------------------------------------
+template <int DT>
+struct Elem;
+template <>
+struct Elem<QUANTO_HIP_F32> {
+  using T = float;
+  static __device__ __forceinline__ float to_f32(T v) { return v; }
+  static __device__ __forceinline__ T from_f32(float f) { return f; }
+};
+template <>
+struct Elem<QUANTO_HIP_F16> {
+  using T = _Float16;
+  static __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+  static __device__ __forceinline__ T from_f32(float f) { return (_Float16)f; }  // RNE
+};
+template <>
+struct Elem<QUANTO_HIP_BF16> {
+  using T = __bf16;
+  static __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+  static __device__ __forceinline__ T from_f32(float f) { return (__bf16)f; }  // v_cvt_pk_bf16_f32, RNE
+};
+
+// ---- 8-bit weight/activation decoders ---------------------------------------------------------
+// e4m3fnuz has no hardware path on gfx950 (the native fp8 is OCP e4m3fn): decode in software.
+__device__ __forceinline__ float decode_e4m3fnuz(uint32_t b) {
+  b &= 0xFFu;
+  if (b == 0x80u) return __builtin_nanf("");
+  const uint32_t e = (b >> 3) & 0xFu, m = b & 7u;
+  float v = e == 0 ? (float)m * 0x1p-10f : __builtin_bit_cast(float, ((e + 119u) << 23) | (m << 20));
+  return (b & 0x80u) ? -v : v;
+}
+
+template <int DT>
+__device__ __forceinline__ float decode8(uint8_t b);
+template <>
+__device__ __forceinline__ float decode8<QUANTO_HIP_I8>(uint8_t b) {
+  return (float)(int8_t)b;
+}
+template <>
+__device__ __forceinline__ float decode8<QUANTO_HIP_U8>(uint8_t b) {
+  return (float)b;
+}
+template <>
+__device__ __forceinline__ float decode8<QUANTO_HIP_F8_E4M3FN>(uint8_t b) {
+  return __builtin_amdgcn_cvt_f32_fp8((int)b, 0);
+}
+template <>
+__device__ __forceinline__ float decode8<QUANTO_HIP_F8_E5M2>(uint8_t b) {
+  return __builtin_amdgcn_cvt_f32_bf8((int)b, 0);
+}
+template <>
+__device__ __forceinline__ float decode8<QUANTO_HIP_F8_E4M3FNUZ>(uint8_t b) {
+  return decode_e4m3fnuz(b);
+}
+
+// ---- wave-level sum (64 lanes) ------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Generic PackedTensor geometry for an axis-0 weight [N, K] with group size C (C == K when
+// per-channel): grouped rows R = N*K/C, packed rows row_dim = ceil(R / vpi).
+struct PackedGeom {
+  int64_t N, K, C, G, R, row_dim;
+  int bits, vpi;
+};
+inline PackedGeom make_geom(int64_t N, int64_t K, int bits, int group_size) {
+  PackedGeom g;
+  g.N = N;
+  g.K = K;
+  g.bits = bits;
+  g.vpi = 8 / bits;
+  g.C = group_size > 0 ? group_size : K;
+  g.G = K / g.C;
+  g.R = N * g.G;
+  g.row_dim = (g.R + g.vpi - 1) / g.vpi;
+  return g;
+}
+
+int launch_status();  // hipGetLastError() -> quanto_hip_status (defined in c_api.hip)
+void set_last_kernel(const char* name);
+
+}  // namespace qh

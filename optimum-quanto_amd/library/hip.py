@@ -1,0 +1,201 @@
+"""``quanto_hip``: ctypes binding of ``libquanto_hip.so`` (the MI355X backend, ``include/quanto_hip.h``).
+
+This is the counterpart of the reference's ``library/extensions/hip/__init__.py:18-36`` (which binds a
+single ``unpack`` kernel through pybind11): it exposes ``ext.lib.unpack(t, bits)`` with the same call
+shape plus the fused products the reference lacks on ROCm.  The wrappers take torch tensors, allocate the
+output with the input's options and return it by value - the reference's C++ convention
+(library/extensions/cuda/unpack.cu:26-56) - and launch on torch's *current* stream under a device guard.
+"""
+import ctypes
+import os
+
+import torch
+
+from .extension import NativeLibrary, register_extension
+
+__all__ = ["quanto_hip", "QuantoHipError"]
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# quanto_hip_dtype (include/quanto_hip.h)
+F32, F16, BF16, I8, U8, F8_E4M3FN, F8_E5M2, F8_E4M3FNUZ = range(8)
+KERNEL_AUTO, KERNEL_NAIVE, KERNEL_GEMV, KERNEL_MFMA = range(4)
+KERNELS = {"auto": KERNEL_AUTO, "naive": KERNEL_NAIVE, "gemv": KERNEL_GEMV, "mfma": KERNEL_MFMA}
+
+_DTYPES = {
+    torch.float32: F32,
+    torch.float16: F16,
+    torch.bfloat16: BF16,
+    torch.int8: I8,
+    torch.uint8: U8,
+    torch.float8_e4m3fn: F8_E4M3FN,
+    torch.float8_e5m2: F8_E5M2,
+    torch.float8_e4m3fnuz: F8_E4M3FNUZ,
+}
+
+
+class QuantoHipError(RuntimeError):
+    pass
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise QuantoHipError(f"quanto_hip: unsupported dtype {t.dtype}") from None
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+class _Bindings:
+    """Typed entry points; one instance per loaded library."""
+
+    def __init__(self, cdll: ctypes.CDLL):
+        c = cdll
+        vp, i64, ci, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+        c.quanto_hip_abi_version.restype = ci
+        c.quanto_hip_status_string.restype = ctypes.c_char_p
+        c.quanto_hip_status_string.argtypes = [ci]
+        c.quanto_hip_last_kernel.restype = ctypes.c_char_p
+        c.quanto_hip_unpack.restype = ci
+        c.quanto_hip_unpack.argtypes = [vp, vp, i64, ci, vp]
+        c.quanto_hip_dequantize_qbits.restype = ci
+        c.quanto_hip_dequantize_qbits.argtypes = [vp, vp, vp, vp, i64, i64, ci, ci, ci, ci, vp]
+        c.quanto_hip_qbits_mm.restype = ci
+        c.quanto_hip_qbits_mm.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, ci, ci, ci, vp, sz, vp]
+        c.quanto_hip_qbits_mm_workspace_size.restype = i64
+        c.quanto_hip_qbits_mm_workspace_size.argtypes = [i64, i64, i64, ci, ci, ci, ci]
+        c.quanto_hip_qbytes_mm.restype = ci
+        c.quanto_hip_qbytes_mm.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, ci, ci, vp]
+        self._c = c
+        if c.quanto_hip_abi_version() != 1:
+            raise QuantoHipError("libquanto_hip.so ABI version mismatch: rebuild with __graft_entry__.build()")
+
+    # -- helpers ----------------------------------------------------------------------------------
+    def _check(self, status: int, what: str):
+        if status != 0:
+            msg = self._c.quanto_hip_status_string(status).decode()
+            raise QuantoHipError(f"quanto_hip.{what} failed: {msg} (status {status})")
+
+    @staticmethod
+    def _stream(t: torch.Tensor):
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    @staticmethod
+    def _require_cuda(*tensors):
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise QuantoHipError("quanto_hip kernels only accept tensors on a ROCm device")
+
+    def last_kernel(self) -> str:
+        return self._c.quanto_hip_last_kernel().decode()
+
+    # -- quanto::unpack ---------------------------------------------------------------------------
+    def unpack(self, t: torch.Tensor, bits: int) -> torch.Tensor:
+        self._require_cuda(t)
+        if t.dtype != torch.uint8:
+            raise QuantoHipError("unpack expects a torch.uint8 tensor")
+        if bits not in (2, 4):
+            raise ValueError(f"Can only unpack 2-bit or 4-bit tensors, got bits={bits}")
+        t = t.contiguous()
+        vpi = 8 // bits
+        out_shape = (t.shape[0] * vpi,) + tuple(t.shape[1:]) if t.ndim > 0 else (vpi,)
+        out = torch.empty(out_shape, dtype=torch.uint8, device=t.device)
+        with torch.cuda.device(t.device):
+            self._check(self._c.quanto_hip_unpack(_ptr(t), _ptr(out), t.numel(), bits, self._stream(t)), "unpack")
+        return out
+
+    # -- fused unpack + dequantize ------------------------------------------------------------------
+    def dequantize_qbits(self, packed, scale, shift, bits: int, group_size, out_features: int, in_features: int):
+        self._require_cuda(packed, scale, shift)
+        packed, scale, shift = packed.contiguous(), scale.contiguous(), shift.contiguous()
+        out = torch.empty((out_features, in_features), dtype=scale.dtype, device=packed.device)
+        with torch.cuda.device(packed.device):
+            st = self._c.quanto_hip_dequantize_qbits(
+                _ptr(packed), _ptr(scale), _ptr(shift), _ptr(out), out_features, in_features, bits, group_size or 0,
+                _dt(scale), _dt(shift), self._stream(packed))
+        self._check(st, "dequantize_qbits")
+        return out
+
+    # -- quanto::qbits_mm ---------------------------------------------------------------------------
+    def qbits_mm(self, x, packed, scale, shift, bias, bits: int, group_size, out_features: int, in_features: int,
+                 kernel: str = "auto"):
+        self._require_cuda(x, packed, scale, shift, bias)
+        if x.dtype != scale.dtype:
+            x = x.to(scale.dtype)
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, in_features).contiguous()
+        packed, scale, shift = packed.contiguous(), scale.contiguous(), shift.contiguous()
+        if bias is not None:
+            bias = bias.to(scale.dtype).contiguous()
+        M = x2.shape[0]
+        y = torch.empty((M, out_features), dtype=scale.dtype, device=x.device)
+        k = KERNELS[kernel]
+        with torch.cuda.device(x.device):
+            ws_bytes = self._c.quanto_hip_qbits_mm_workspace_size(M, out_features, in_features, bits, group_size or 0,
+                                                                  _dt(scale), k)
+            if ws_bytes < 0:
+                self._check(int(ws_bytes), "qbits_mm_workspace_size")
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
+            st = self._c.quanto_hip_qbits_mm(
+                _ptr(x2), _ptr(packed), _ptr(scale), _ptr(shift), _ptr(bias), _ptr(y), M, out_features, in_features,
+                bits, group_size or 0, _dt(scale), _dt(shift), k, _ptr(ws), ws_bytes, self._stream(x))
+        self._check(st, "qbits_mm")
+        return y.reshape(*lead, out_features)
+
+    # -- quanto::qbytes_mm --------------------------------------------------------------------------
+    def qbytes_mm(self, a, b, scales, bias=None, kernel: str = "auto"):
+        self._require_cuda(a, b, scales, bias)
+        N, K = b.shape
+        if scales.numel() != N:
+            raise QuantoHipError(f"qbytes_mm expects one scale per output feature ({N}), got {tuple(scales.shape)}")
+        lead = a.shape[:-1]
+        if a.dtype.is_floating_point and a.dtype.itemsize > 1 and a.dtype != scales.dtype:
+            a = a.to(scales.dtype)  # library/qbytes_mm.py:26
+        a2 = a.reshape(-1, K).contiguous()
+        b, s = b.contiguous(), scales.reshape(-1).contiguous()
+        if bias is not None:
+            bias = bias.to(scales.dtype).contiguous()
+        M = a2.shape[0]
+        y = torch.empty((M, N), dtype=scales.dtype, device=a.device)
+        with torch.cuda.device(a.device):
+            st = self._c.quanto_hip_qbytes_mm(_ptr(a2), _ptr(b), _ptr(s), _ptr(bias), _ptr(y), M, N, K, _dt(a2), _dt(b),
+                                              _dt(s), KERNELS[kernel], self._stream(a))
+        self._check(st, "qbytes_mm")
+        return y.reshape(*lead, N)
+
+
+class QuantoHipExtension(NativeLibrary):
+    """The ``quanto_hip`` extension (name expected by the reference's tests/library/test_extensions.py:23-24)."""
+
+    def __init__(self):
+        csrc = os.path.join(_PKG_DIR, "csrc")
+        super().__init__(
+            "quanto_hip",
+            root_dir=csrc,
+            lib_path=os.path.join(_PKG_DIR, "lib", "libquanto_hip.so"),
+            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip",
+                     "qh_common.h", os.path.join("..", "..", "include", "quanto_hip.h")],
+        )
+        self._bindings = None
+
+    @property
+    def lib(self) -> _Bindings:
+        if self._bindings is None:
+            try:
+                self._bindings = _Bindings(self.cdll)
+            except OSError as e:
+                raise QuantoHipError(
+                    f"quanto_hip: cannot load {self.lib_path} ({e}). Build it with `python -c 'import __graft_entry__ as g; "
+                    "g.build()'` (hipcc --offload-arch=gfx950). There is no fallback for ROCm tensors.") from e
+        return self._bindings
+
+
+quanto_hip = QuantoHipExtension()
+# The reference registers its HIP extension only when a ROCm device is visible
+# (library/extensions/__init__.py:24-28); same gate here, plus "the binary exists" so that a GPU box without
+# the library fails loudly at first use instead of silently running something else.
+if torch.version.hip is not None:
+    register_extension(quanto_hip)

@@ -1,0 +1,223 @@
+"""The ``quanto::`` operator library for this backend.
+
+Schemas kept verbatim from the reference so existing call sites work unchanged:
+
+* ``quanto::unpack(Tensor self, int bits) -> Tensor``                          library/unpack.py:18
+* ``quanto::qbytes_mm(Tensor A, Tensor B, Tensor scales) -> Tensor``            library/qbytes_mm.py:22
+* ``quanto::quantize_symmetric(Tensor base, ScalarType dtype, int? axis, Tensor scale) -> Tensor``   library/quantize.py:22-24
+* ``quanto::quantize_affine(Tensor base, int bits, int axis, int? group_size, Tensor scale, Tensor shift) -> Tensor``  :58-61
+
+New ops (the reference has no fused int4 product outside its CUDA-only AWQ/Marlin ops; the schema follows its own
+template, library/extensions/README.md:24-48 and cuda/__init__.py:82-94):
+
+* ``quanto::qbits_mm(Tensor input, Tensor packed, Tensor scale, Tensor shift, Tensor? bias, int bits, int? group_size,
+  int out_features, int in_features) -> Tensor``
+* ``quanto::dequantize_qbits(Tensor packed, Tensor scale, Tensor shift, int bits, int? group_size, int out_features,
+  int in_features) -> Tensor``
+
+Dispatch: the ``default`` implementations are plain torch and serve CPU tensors (quantize-time work and the CPU
+plumbing config).  The ``CUDA`` key - which is what a ROCm device uses - always goes to ``libquanto_hip.so``;
+if the library cannot be loaded the call raises: there is no silent fallback for device tensors.
+
+When ``optimum.quanto`` itself is already imported in the process the ops exist; we then only (re)register the
+``CUDA`` implementations, which is how this backend plugs into an unmodified reference install.
+"""
+from typing import Optional, Union
+
+import torch
+
+from ..tensor.dtypes import dtype_info
+from ..tensor.grouping import group, ungroup
+from .hip import quanto_hip
+
+__all__ = []
+
+_lib_def = torch.library.Library("quanto", "FRAGMENT")
+_lib_impl = torch.library.Library("quanto", "IMPL")
+
+
+def _op_exists(name: str) -> bool:
+    try:
+        return hasattr(torch.ops.quanto, name) and getattr(torch.ops.quanto, name) is not None
+    except (AttributeError, RuntimeError):
+        return False
+
+
+def _define(name: str, schema: str) -> bool:
+    """Define ``quanto::name`` unless another definer (the reference package) already did. Returns True if we own it."""
+    if _op_exists(name):
+        return False
+    _lib_def.define(name + schema)
+    return True
+
+
+def _impl(name: str, key: str, fn, owned: bool):
+    if owned:
+        _lib_impl.impl(name, fn, key)
+    else:  # plug-in mode: replace the reference's registration for this key
+        try:
+            _lib_impl.impl(name, fn, key, allow_override=True)
+        except TypeError:  # older torch without allow_override
+            _lib_impl.impl(name, fn, key)
+
+
+# ------------------------------------------------------------------------------------------------
+# quanto::unpack
+# ------------------------------------------------------------------------------------------------
+def unpack_default(packed: torch.Tensor, bits: int) -> torch.Tensor:
+    """Planes of ``bits`` bits, concatenated along dim 0 (library/unpack.py:21-54)."""
+    planes = [(packed >> (bits * i)) & ((1 << bits) - 1) for i in range(8 // bits)]
+    return torch.cat(planes).to(torch.uint8)
+
+
+def unpack_hip(packed: torch.Tensor, bits: int) -> torch.Tensor:
+    return quanto_hip.lib.unpack(packed, bits)
+
+
+_owned = _define("unpack", "(Tensor self, int bits) -> Tensor")
+if _owned:
+    _impl("unpack", "CompositeExplicitAutograd", unpack_default, True)
+_impl("unpack", "CUDA", unpack_hip, _owned)
+
+
+# ------------------------------------------------------------------------------------------------
+# quanto::qbytes_mm
+# ------------------------------------------------------------------------------------------------
+def _qbytes_mm_dense(activations, weights, output_scales):
+    """Generic path (library/qbytes_mm.py:25-33): scale the weights, then a dense matmul."""
+    activations = activations.to(output_scales.dtype)
+    if weights.dtype.is_floating_point:
+        weights = weights.to(output_scales.dtype)
+    return torch.matmul(activations, (output_scales * weights).t())
+
+
+def _qbytes_mm_int(activations, weights, output_scales):
+    """int8 x int8 (library/qbytes_mm.py:36-50): exact int32 product, fp32 rescale."""
+    k, n = activations.shape[-1], weights.shape[0]
+    acc = torch._int_mm(activations.reshape(-1, k), weights.t()).reshape(activations.shape[:-1] + (n,))
+    return (acc.to(torch.float32) * output_scales.t()).to(output_scales.dtype)
+
+
+def qbytes_mm_default(activations, weights, output_scales):
+    return _qbytes_mm_dense(activations, weights, output_scales)
+
+
+def qbytes_mm_cpu(activations, weights, output_scales):
+    """CPU selection logic of library/qbytes_mm.py:91-105."""
+    if activations.dtype == torch.int8 and weights.dtype == torch.int8:
+        return _qbytes_mm_int(activations, weights, output_scales)
+    k = activations.shape[-1]
+    if activations.dtype == torch.bfloat16 and weights.dtype == torch.int8 and k % 4 == 0:
+        n = weights.shape[0]
+        out = torch._weight_int8pack_mm(activations.reshape(-1, k), weights, output_scales.flatten())
+        return out.reshape(activations.shape[:-1] + (n,))
+    return _qbytes_mm_dense(activations, weights, output_scales)
+
+
+def qbytes_mm_hip(activations, weights, output_scales):
+    """ROCm: one fused kernel, scales applied to the fp32 accumulator (csrc/qbytes_gemv.hip, csrc/qmm_mfma.hip)."""
+    assert activations.ndim >= 1 and weights.ndim == 2
+    n = weights.shape[0]
+    if output_scales.numel() != n:
+        # per-tensor weight scale or an exotic broadcast: expand to one scale per output feature
+        output_scales = (output_scales * torch.ones((1, n), dtype=output_scales.dtype, device=output_scales.device))
+        if output_scales.numel() != n:
+            raise ValueError(f"qbytes_mm: cannot broadcast scales of shape {tuple(output_scales.shape)} to {n} features")
+    return quanto_hip.lib.qbytes_mm(activations, weights, output_scales)
+
+
+_owned = _define("qbytes_mm", "(Tensor A, Tensor B, Tensor scales) -> Tensor")
+if _owned:
+    _impl("qbytes_mm", "CompositeExplicitAutograd", qbytes_mm_default, True)
+    _impl("qbytes_mm", "CPU", qbytes_mm_cpu, True)
+_impl("qbytes_mm", "CUDA", qbytes_mm_hip, _owned)
+
+
+# ------------------------------------------------------------------------------------------------
+# quanto::quantize_symmetric / quantize_affine (quantize-time, plain torch on every device)
+# ------------------------------------------------------------------------------------------------
+def quantize_symmetric(base: torch.Tensor, dtype: torch.dtype, axis: Union[int, None], scale: torch.Tensor) -> torch.Tensor:
+    """clamp(round(base / scale)) to ``dtype`` (library/quantize.py:26-55; float8 targets are not rounded first)."""
+    if axis is None:
+        if scale.ndim > 0:
+            raise ValueError("Scale must be a scalar when quantizing per-tensor")
+    else:
+        if base.ndim == 1:
+            raise ValueError("1D Tensors cannot be quantized per-axis")
+        if axis == base.ndim - 1:
+            axis = -1
+        if axis not in (0, -1):
+            raise ValueError("Quantization is only supported along the first or last axis.")
+        if base.shape[axis] == 1:
+            raise ValueError(f"Cannot quantize Tensor of shape {base.shape} along axis {axis} of size 1")
+        if torch.squeeze(scale).ndim > 1:
+            raise ValueError("Quantizing along multiple axis is not supported")
+        if scale.ndim != base.ndim:
+            raise ValueError(
+                "When quantizing per-axis, the scale must be broadcastable to the base (Tip: try to add missing dims of length zero).")
+    data = base / scale
+    if not dtype.is_floating_point:
+        data = torch.round(data)
+    info = dtype_info(dtype)
+    return torch.clamp(data, min=info.min, max=info.max).to(dtype)
+
+
+def quantize_affine(base: torch.Tensor, bits: int, axis: int, group_size: Union[int, None], scale: torch.Tensor,
+                    shift: torch.Tensor) -> torch.Tensor:
+    """uint8 in [0, 2^bits): round((base + shift) / scale), or round(base / scale) + zero-point (library/quantize.py:66-78)."""
+    if axis not in (0, -1):
+        raise ValueError("axis parameter must be 0 (first axis) or -1 (last axis)")
+    if group_size is not None:
+        base = group(base, axis=axis, group_size=group_size)
+    if shift.dtype.is_floating_point:
+        data = torch.round((base + shift) / scale)
+    else:
+        data = torch.round(base / scale) + shift
+    return torch.clamp(data, min=0, max=2**bits - 1).to(torch.uint8)
+
+
+if _define("quantize_symmetric", "(Tensor base, ScalarType dtype, int? axis, Tensor scale) -> Tensor"):
+    _impl("quantize_symmetric", "CompositeExplicitAutograd", quantize_symmetric, True)
+if _define("quantize_affine", "(Tensor base, int bits, int axis, int? group_size, Tensor scale, Tensor shift) -> Tensor"):
+    _impl("quantize_affine", "CompositeExplicitAutograd", quantize_affine, True)
+
+
+# ------------------------------------------------------------------------------------------------
+# quanto::dequantize_qbits and quanto::qbits_mm (new ops)
+# ------------------------------------------------------------------------------------------------
+def dequantize_qbits_default(packed, scale, shift, bits: int, group_size: Optional[int], out_features: int, in_features: int):
+    """Reference sequence: unpack, trim, remove shift, scale, ungroup (tensor/packed.py:101-104, tensor/qbits.py:27-49)."""
+    rows = (out_features * in_features) // group_size if group_size is not None else out_features
+    data = torch.ops.quanto.unpack(packed, bits)[:rows]
+    if not shift.dtype.is_floating_point:
+        data = data.to(torch.int8) - shift.to(torch.int8)
+    out = scale * data
+    if shift.dtype.is_floating_point:
+        out -= shift
+    return ungroup(out, axis=0, orig_shape=torch.Size([out_features, in_features]))
+
+
+def dequantize_qbits_hip(packed, scale, shift, bits: int, group_size: Optional[int], out_features: int, in_features: int):
+    return quanto_hip.lib.dequantize_qbits(packed, scale, shift, bits, group_size, out_features, in_features)
+
+
+def qbits_mm_default(input, packed, scale, shift, bias, bits: int, group_size: Optional[int], out_features: int, in_features: int):
+    """x @ dequantize(W).T (+ bias): what tensor/function.py:41-47 computes through qfallback."""
+    w = torch.ops.quanto.dequantize_qbits(packed, scale, shift, bits, group_size, out_features, in_features)
+    out = torch.matmul(input, w.t())
+    return out if bias is None else out + bias
+
+
+def qbits_mm_hip(input, packed, scale, shift, bias, bits: int, group_size: Optional[int], out_features: int, in_features: int):
+    return quanto_hip.lib.qbits_mm(input, packed, scale, shift, bias, bits, group_size, out_features, in_features)
+
+
+if _define("dequantize_qbits",
+           "(Tensor packed, Tensor scale, Tensor shift, int bits, int? group_size, int out_features, int in_features) -> Tensor"):
+    _impl("dequantize_qbits", "CompositeExplicitAutograd", dequantize_qbits_default, True)
+    _impl("dequantize_qbits", "CUDA", dequantize_qbits_hip, True)
+if _define("qbits_mm",
+           "(Tensor input, Tensor packed, Tensor scale, Tensor shift, Tensor? bias, int bits, int? group_size, "
+           "int out_features, int in_features) -> Tensor"):
+    _impl("qbits_mm", "CompositeExplicitAutograd", qbits_mm_default, True)
+    _impl("qbits_mm", "CUDA", qbits_mm_hip, True)

@@ -1,0 +1,97 @@
+"""Model-level API: ``quantize``, ``freeze``, ``requantize``, ``quantization_map`` (optimum/quanto/quantize.py:24-149)."""
+from fnmatch import fnmatch
+from typing import Any, Dict, List, Optional, Union
+
+import torch
+
+from .nn import QModuleMixin, quantize_module
+from .tensor import Optimizer, qtype
+
+__all__ = ["quantize", "freeze", "requantize", "quantization_map"]
+
+
+def _set_module_by_name(parent: torch.nn.Module, name: str, child: torch.nn.Module) -> None:
+    *path, leaf = name.split(".")
+    for part in path:
+        parent = getattr(parent, part)
+    setattr(parent, leaf, child)
+
+
+def _quantize_submodule(model, name, module, weights=None, activations=None, optimizer=None):
+    qmodule = quantize_module(module, weights=weights, activations=activations, optimizer=optimizer)
+    if qmodule is None:
+        return
+    _set_module_by_name(model, name, qmodule)
+    qmodule.name = name
+    for pname, param in module.named_parameters():
+        # the quantized module aliases the parameters: release the originals
+        setattr(module, pname, None)
+        del param
+
+
+def _as_patterns(p: Optional[Union[str, List[str]]]):
+    return [p] if isinstance(p, str) else p
+
+
+def quantize(model: torch.nn.Module, weights: Optional[Union[str, qtype]] = None,
+             activations: Optional[Union[str, qtype]] = None, optimizer: Optional[Optimizer] = None,
+             include: Optional[Union[str, List[str]]] = None, exclude: Optional[Union[str, List[str]]] = None):
+    """Replace every eligible submodule in place by its quantized counterpart.
+
+    ``include`` / ``exclude`` are Unix shell-style patterns on module names (quantize.py:55-98).  Weights stay
+    float (dynamically quantized in forward) until ``freeze``.
+    """
+    include, exclude = _as_patterns(include), _as_patterns(exclude)
+    for name, module in list(model.named_modules()):
+        if include is not None and not any(fnmatch(name, pattern) for pattern in include):
+            continue
+        if exclude is not None and any(fnmatch(name, pattern) for pattern in exclude):
+            continue
+        _quantize_submodule(model, name, module, weights=weights, activations=activations, optimizer=optimizer)
+
+
+def requantize(model: torch.nn.Module, state_dict: Dict[str, Any], quantization_map: Dict[str, Dict[str, str]],
+               device: torch.device = None):
+    """Rebuild a frozen model from a flattened state dict + ``quantization_map`` (quantize.py:101-140)."""
+    if device is None:
+        device = next(model.parameters()).device
+        if device.type == "meta":
+            device = torch.device("cpu")
+    for name, module in list(model.named_modules()):
+        qconfig = quantization_map.get(name)
+        if qconfig is None:
+            continue
+        weights = None if qconfig["weights"] == "none" else qconfig["weights"]
+        activations = None if qconfig["activations"] == "none" else qconfig["activations"]
+        _quantize_submodule(model, name, module, weights=weights, activations=activations)
+    # materialise parameters/buffers still on the meta device, then load
+    for name, m in model.named_modules():
+        def move(t):
+            if t.device.type == "meta":
+                return torch.empty_like(t, device=device)
+            return t.to(device)
+
+        for pname, p in list(m.named_parameters(recurse=False)):
+            setattr(m, pname, torch.nn.Parameter(move(p), requires_grad=p.requires_grad))
+        for bname, b in list(m.named_buffers(recurse=False)):
+            setattr(m, bname, move(b))
+    model.load_state_dict(state_dict, strict=False, assign=True)
+    model.to(device)
+
+
+def freeze(model: torch.nn.Module):
+    for m in model.modules():
+        if isinstance(m, QModuleMixin):
+            m.freeze()
+
+
+def quantization_map(model: torch.nn.Module) -> Dict[str, Dict[str, str]]:
+    """``{module name: {"weights": qtype name | "none", "activations": ...}}`` for every quantized module."""
+    config = {}
+    for name, m in model.named_modules():
+        if isinstance(m, QModuleMixin):
+            config[name] = {
+                "weights": "none" if m.weight_qtype is None else m.weight_qtype.name,
+                "activations": "none" if m.activation_qtype is None else m.activation_qtype.name,
+            }
+    return config

@@ -1,0 +1,334 @@
+"""Quantized weight tensors and ``quantize_weight``.
+
+API mirror of optimum/quanto/tensor/weights/{qbytes,qbits,quantization}.py.  What differs is what happens on
+``F.linear``:
+
+* ``WeightQBytesTensor``: same as the reference - ``quanto::qbytes_mm(input, data, scale)``
+  (weights/qbytes.py:68-82) - but on a ROCm device the op is one fused HIP kernel (csrc/qbytes_gemv.hip,
+  csrc/qmm_mfma.hip) instead of "materialise scale*W, then matmul" (library/qbytes_mm.py:25-33).
+* ``WeightQBitsTensor``: the reference dequantizes the whole weight on every call (tensor/function.py:41-47 via
+  qfallback) unless a CUDA-only AWQ/TinyGemm subclass was selected by ``create()`` (weights/qbits.py:97-136).
+  Here every axis-0 2-D int4/int2 weight calls ``quanto::qbits_mm`` which consumes the *generic* PackedTensor
+  layout directly, so no device-specific re-packing subclass is needed: ``create()`` keeps the serialisable
+  layout, ``optimize()`` and ``weight_qbits_tensor()`` are identities, and checkpoints stay in the
+  kernel-agnostic format (weights/qbits.py:223-235).
+"""
+import ast
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from .base import QBitsTensor, QBytesTensor, qfallback
+from .dtypes import qint2, qint4, qtype, qtypes
+from .grouping import grouped_shape
+from .linear_function import QuantizedLinearFunction
+from .packing import PackedTensor
+
+__all__ = ["WeightQBytesTensor", "WeightQBitsTensor", "quantize_weight"]
+
+
+# ================================================================================================
+# 8-bit weights
+# ================================================================================================
+class _QuantizeBytesWeight(Function):
+    @staticmethod
+    def forward(ctx, base, qtype, axis, scale, activation_qtype, optimized):
+        if qtype.bits != 8:
+            raise ValueError("QBytesTensor can only be of 8-bit qtype")
+        data = torch.ops.quanto.quantize_symmetric(base, dtype=qtype.dtype, axis=axis, scale=scale)
+        make = WeightQBytesTensor.create if optimized else WeightQBytesTensor
+        return make(qtype, axis, size=base.size(), stride=base.stride(), data=data, scale=scale,
+                    activation_qtype=activation_qtype)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None, None, None, None, None
+
+
+class WeightQBytesLinearFunction(QuantizedLinearFunction):
+    """F.linear on an int8 / float8 weight: one ``quanto::qbytes_mm`` call (weights/qbytes.py:68-82)."""
+
+    @staticmethod
+    def forward(ctx, input, other, bias=None):
+        ctx.save_for_backward(input, other)
+        if isinstance(input, QBytesTensor):
+            # quantized activations: integer/fp8 product, rescaled by the product of both scales
+            output = torch.ops.quanto.qbytes_mm(input._data, other._data, input._scale * other._scale)
+        else:
+            k, n = input.shape[-1], other.shape[0]
+            output = torch.ops.quanto.qbytes_mm(input.reshape(-1, k), other._data, other._scale)
+            output = output.reshape(input.shape[:-1] + (n,))
+        if bias is not None:
+            output = output + bias
+        return output
+
+
+class WeightQBytesTensor(QBytesTensor):
+    @staticmethod
+    def create(qtype, axis, size, stride, data, scale, activation_qtype: Optional[qtype] = None, requires_grad=False):
+        """Factory used by quantize / ``.to(device)`` / reload (selection point of weights/qbytes.py:86-143).
+
+        The MI355X kernels read the plain [N, K] byte layout, so the generic class is already the optimized one.
+        """
+        return WeightQBytesTensor(qtype, axis, size, stride, data, scale, activation_qtype, requires_grad)
+
+    @staticmethod
+    def __new__(cls, qtype, axis, size, stride, data, scale, activation_qtype, requires_grad=False):
+        assert data.device == scale.device
+        return torch.Tensor._make_wrapper_subclass(
+            cls, size, strides=stride, dtype=scale.dtype, device=data.device, requires_grad=requires_grad)
+
+    def __init__(self, qtype, axis, size, stride, data, scale, activation_qtype, requires_grad=False):
+        super().__init__(qtype, axis, size, stride, data, scale, requires_grad=requires_grad)
+        self.activation_qtype = activation_qtype
+
+    @classmethod
+    def quantize(cls, base, qtype, axis, scale, activation_qtype: Optional[qtype] = None, optimized: Optional[bool] = True):
+        return _QuantizeBytesWeight.apply(base, qtype, axis, scale, activation_qtype, optimized)
+
+    # -- (de)serialization --------------------------------------------------------------------------
+    @staticmethod
+    def load_from_state_dict(state_dict, prefix, qtype, axis, size, stride, activation_qtype, missing_keys):
+        inner, missing = {}, False
+        for name in ("_data", "_scale"):
+            if prefix + name in state_dict:
+                inner[name] = state_dict.pop(prefix + name)
+            else:
+                missing_keys.append(prefix + name)
+                missing = True
+        if missing:
+            return None
+        meta = {"qtype": qtype.name, "axis": str(axis), "size": str(list(size)), "stride": str(list(stride)),
+                "activation_qtype": "none" if activation_qtype is None else activation_qtype.name}
+        return WeightQBytesTensor.__tensor_unflatten__(inner, meta, None, None)
+
+    def optimize(self):
+        return self
+
+    def weight_qbytes_tensor(self):
+        return self
+
+    def save_to_state_dict(self, destination, prefix, keep_vars):
+        super().save_to_state_dict(destination, prefix, keep_vars)
+
+    def __tensor_flatten__(self):
+        meta = {"qtype": self._qtype.name, "axis": str(self._axis), "size": str(list(self.size())),
+                "stride": str(list(self.stride())),
+                "activation_qtype": "none" if self.activation_qtype is None else self.activation_qtype.name}
+        return ["_data", "_scale"], meta
+
+    @staticmethod
+    def __tensor_unflatten__(inner_tensors, meta, outer_size, outer_stride):
+        assert len(inner_tensors) == 2 and len(meta) == 5
+        act = None if meta["activation_qtype"] == "none" else qtypes[meta["activation_qtype"]]
+        return WeightQBytesTensor(qtypes[meta["qtype"]], ast.literal_eval(meta["axis"]), ast.literal_eval(meta["size"]),
+                                  ast.literal_eval(meta["stride"]), inner_tensors["_data"], inner_tensors["_scale"], act)
+
+    # -- dispatch -----------------------------------------------------------------------------------
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.nn.functional.linear:
+            def qlinear(input, other, bias=None):
+                return WeightQBytesLinearFunction.apply(input, other, bias)
+
+            return qlinear(*args, **kwargs)
+        if func is torch.equal:
+            a, b = args
+            return a.equal(b)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+    @classmethod
+    def __torch_dispatch__(cls, op, types, args, kwargs=None):
+        kwargs = dict(kwargs or {})
+        op = op.overloadpacket
+        if op is torch.ops.aten.detach:
+            t = args[0]
+            names, meta = t.__tensor_flatten__()
+            return cls.__tensor_unflatten__({n: op(getattr(t, n)) for n in names}, meta, t.size(), t.stride())
+        if op in (torch.ops.aten._to_copy, torch.ops.aten.to):
+            t = args[0]
+            dtype = kwargs.pop("dtype", t.dtype)
+            device = kwargs.pop("device", t.device)
+            if dtype is not None and dtype != t.dtype:
+                raise ValueError("The dtype of a weights Tensor cannot be changed")
+            data = op(t._data, device=device, **kwargs)
+            scale = op(t._scale, device=device, **kwargs)
+            return WeightQBytesTensor.create(t.qtype, t.axis, t.size(), t.stride(), data, scale,
+                                             activation_qtype=t.activation_qtype, requires_grad=t.requires_grad)
+        if op is torch.ops.aten.t and cls is WeightQBytesTensor:
+            t = args[0]
+            rows, cols = t.size()
+            scale, axis = t._scale, t.axis
+            if axis is not None:
+                scale = op(scale)
+                axis = 0 if axis == -1 else -1
+            return WeightQBytesTensor(t.qtype, axis, torch.Size([cols, rows]), t.stride()[::-1], op(t._data), scale,
+                                      t.activation_qtype)
+        return qfallback(op, *args, **kwargs)
+
+
+# ================================================================================================
+# sub-byte weights
+# ================================================================================================
+class _QuantizeBitsWeight(Function):
+    @staticmethod
+    def forward(ctx, base, qtype, axis, group_size, scale, shift, optimized):
+        if qtype not in (qint2, qint4):
+            raise ValueError("WeightQBitsTensor can only be of qint2 or qint4 qtype")
+        if axis not in (0, -1):
+            raise ValueError("WeightQBitsTensor axis parameter must be 0 (first axis) or -1 (last axis)")
+        data = torch.ops.quanto.quantize_affine(base, bits=qtype.bits, axis=axis, group_size=group_size, scale=scale,
+                                                shift=shift)
+        make = WeightQBitsTensor.create if optimized else WeightQBitsTensor
+        return make(qtype, axis, group_size, base.size(), base.stride(), data, scale, shift)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None, None, None, None, None, None
+
+
+def _fusable(w) -> bool:
+    """True when ``quanto::qbits_mm`` can consume this weight (axis-0, 2-D, integer qtype, packed data)."""
+    return w.axis == 0 and w.ndim == 2 and isinstance(w._data, PackedTensor) and not w.qtype.is_floating_point
+
+
+class WeightQBitsLinearFunction(QuantizedLinearFunction):
+    """F.linear on an int4 / int2 weight through the fused ``quanto::qbits_mm`` op.
+
+    Same structure as the reference's optimized-subclass functions (weights/awq/qbits.py:53-74): dequantize a
+    quantized activation first, hand the packed data + scale + shift to the kernel, add the bias.
+    """
+
+    @staticmethod
+    def forward(ctx, input, other, bias=None):
+        ctx.save_for_backward(input, other)
+        if type(input) is not torch.Tensor:
+            input = input.dequantize()
+        n, k = other.shape
+        output = torch.ops.quanto.qbits_mm(input, other._data._data, other._scale, other._shift, bias, other._data.bits,
+                                           other._group_size, n, k)
+        return output
+
+
+class WeightQBitsTensor(QBitsTensor):
+    @staticmethod
+    def create(qtype, axis, group_size, size, stride, data, scale, shift, requires_grad=False):
+        """Factory / selection point (weights/qbits.py:66-138): the generic layout *is* the MI355X layout."""
+        return WeightQBitsTensor(qtype, axis, group_size, size, stride, data, scale, shift, requires_grad)
+
+    @staticmethod
+    def __new__(cls, qtype, axis, group_size, size, stride, data, scale, shift, requires_grad=False):
+        assert data.device == scale.device
+        assert data.device == shift.device
+        return torch.Tensor._make_wrapper_subclass(
+            cls, size, strides=stride, dtype=scale.dtype, device=data.device, requires_grad=requires_grad)
+
+    def __init__(self, qtype, axis, group_size, size, stride, data, scale, shift, requires_grad=False):
+        if type(data) is torch.Tensor:
+            data = PackedTensor.pack(data, qtype.bits)
+        super().__init__(qtype, axis, group_size, size, stride, data, scale, shift)
+
+    @classmethod
+    def quantize(cls, base, qtype, axis, group_size, scale, shift, optimized: Optional[bool] = True):
+        return _QuantizeBitsWeight.apply(base, qtype, axis, group_size, scale, shift, optimized)
+
+    # -- (de)serialization --------------------------------------------------------------------------
+    @staticmethod
+    def load_from_state_dict(state_dict, prefix, qtype, axis, group_size, size, stride, missing_keys):
+        if group_size is None:
+            data_size, data_stride = size, stride
+        else:
+            data_size = grouped_shape(size, axis, group_size)
+            data_stride = (data_size[1], 1)
+        inner = {"_data": PackedTensor.load_from_state_dict(state_dict, prefix + "_data.", qtype.bits, data_size,
+                                                            data_stride, missing_keys=missing_keys)}
+        missing = inner["_data"] is None
+        for name in ("_scale", "_shift"):
+            if prefix + name in state_dict:
+                inner[name] = state_dict.pop(prefix + name)
+            else:
+                missing_keys.append(prefix + name)
+                missing = True
+        if missing:
+            return None
+        meta = {"qtype": qtype.name, "axis": str(axis), "group_size": str(group_size), "size": str(list(size)),
+                "stride": str(list(stride))}
+        return WeightQBitsTensor.__tensor_unflatten__(inner, meta, None, None)
+
+    def optimize(self):
+        return self
+
+    def weight_qbits_tensor(self):
+        return self
+
+    def __tensor_flatten__(self):
+        meta = {"qtype": self._qtype.name, "axis": str(self._axis), "group_size": str(self._group_size),
+                "size": str(list(self.size())), "stride": str(list(self.stride()))}
+        return ["_data", "_scale", "_shift"], meta
+
+    @staticmethod
+    def __tensor_unflatten__(inner_tensors, meta, outer_size, outer_stride):
+        assert len(inner_tensors) == 3 and len(meta) == 5
+        return WeightQBitsTensor(qtypes[meta["qtype"]], ast.literal_eval(meta["axis"]), ast.literal_eval(meta["group_size"]),
+                                 ast.literal_eval(meta["size"]), ast.literal_eval(meta["stride"]), inner_tensors["_data"],
+                                 inner_tensors["_scale"], inner_tensors["_shift"])
+
+    # -- dispatch -----------------------------------------------------------------------------------
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.nn.functional.linear:
+            def qlinear(input, other, bias=None):
+                if _fusable(other):
+                    return WeightQBitsLinearFunction.apply(input, other, bias)
+                return QuantizedLinearFunction.apply(input, other, bias)
+
+            return qlinear(*args, **kwargs)
+        if func is torch.equal:
+            a, b = args
+            return a.equal(b)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+    @classmethod
+    def __torch_dispatch__(cls, op, types, args, kwargs=None):
+        kwargs = dict(kwargs or {})
+        op = op.overloadpacket
+        if op is torch.ops.aten.detach:
+            t = args[0]
+            names, meta = t.__tensor_flatten__()
+            return cls.__tensor_unflatten__({n: op(getattr(t, n)) for n in names}, meta, t.size(), t.stride())
+        if op in (torch.ops.aten._to_copy, torch.ops.aten.to):
+            t = args[0]
+            dtype = kwargs.pop("dtype", t.dtype)
+            device = kwargs.pop("device", t.device)
+            if dtype is not None and dtype != t.dtype:
+                raise ValueError("The dtype of a WeightQBitsTensor cannot be changed")
+            scale = op(t._scale, dtype=dtype, device=device, **kwargs)
+            data = op(t._data, device=device, **kwargs)
+            shift = op(t._shift, device=device, **kwargs)
+            return WeightQBitsTensor.create(t._qtype, t._axis, t._group_size, t.size(), t.stride(), data, scale, shift)
+        return qfallback(op, *args, **kwargs)
+
+
+# ================================================================================================
+def quantize_weight(t: torch.Tensor, qtype: qtype, axis: int, scale: torch.Tensor, shift: Optional[torch.Tensor] = None,
+                    group_size: Optional[int] = None, activation_qtype: Optional[qtype] = None,
+                    optimized: Optional[bool] = True):
+    """Quantize a weight per-axis (weights/quantization.py:27-73): 8-bit -> WeightQBytesTensor, else WeightQBitsTensor."""
+    if axis not in (0, -1):
+        raise ValueError("axis parameter must be 0 (first axis) or -1 (last axis)")
+    if qtype.bits == 8:
+        if shift is not None:
+            raise ValueError("shift cannot be specified for 8-bit qtypes")
+        if group_size is not None:
+            raise ValueError("group_size cannot be specified for 8-bit qtypes.")
+        if axis is not None and t.shape[axis] == 1:
+            axis = None  # per-axis over a dimension of size one is per-tensor
+        return WeightQBytesTensor.quantize(t, qtype, axis, scale, activation_qtype, optimized)
+    if shift is None:
+        raise ValueError("shift must be specified for qtypes lower than 8-bit")
+    return WeightQBitsTensor.quantize(t, qtype, axis, group_size, scale, shift, optimized)

@@ -1,0 +1,88 @@
+"""Shared helpers for the parity tests: oracle-built inputs and numpy <-> torch conversions."""
+import numpy as np
+import torch
+
+from oracle import quanto_oracle as O
+
+TORCH_DT = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
+FP8_TORCH = {"e4m3fn": torch.float8_e4m3fn, "e4m3fnuz": torch.float8_e4m3fnuz, "e5m2": torch.float8_e5m2}
+
+
+def to_torch(a: np.ndarray, dt: str, device="cpu") -> torch.Tensor:
+    """float32 array holding dt-representable values -> torch tensor of that dtype (exact)."""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(TORCH_DT[dt]).to(device)
+
+
+def to_numpy(t: torch.Tensor) -> np.ndarray:
+    if t.dtype in FP8_TORCH.values():
+        return t.view(torch.uint8).cpu().numpy()
+    if t.dtype.is_floating_point:
+        return t.detach().to(torch.float32).cpu().numpy()
+    return t.detach().cpu().numpy()
+
+
+def fp8_tensor(codes: np.ndarray, kind: str, device="cpu") -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(codes, dtype=np.uint8)).view(FP8_TORCH[kind]).to(device)
+
+
+def make_qbits_problem(M, N, K, dt, bits=4, group_size=128, zeropoint=False, seed=0, wscale=0.02):
+    """Seeded activations + a weight quantized by the (reference-pinned) oracle, generic PackedTensor layout."""
+    rng = np.random.default_rng(seed)
+    w = O.round_to((rng.standard_normal((N, K)) * wscale).astype(np.float32), dt)
+    x = O.round_to(rng.standard_normal((M, K)).astype(np.float32), dt)
+    scale, shift = O.max_scale_shift(w, bits, 0, group_size, dt)
+    if zeropoint:
+        shift = np.clip(np.rint(O.round_to(shift / scale, dt)), 0, 2**bits - 1).astype(np.uint8)
+    q = O.quantize_affine(w, bits, 0, group_size, scale, shift, dt)
+    packed = O.pack_weights(q, bits)
+    return dict(x=x, packed=packed, scale=scale, shift=shift, bits=bits, group_size=group_size, N=N, K=K, dt=dt)
+
+
+def make_qbytes_problem(M, N, K, dt, kind=None, seed=0, wscale=0.02):
+    """int8 (kind None) or fp8 weight with per-row absmax scale, built by the oracle."""
+    rng = np.random.default_rng(seed)
+    w = O.round_to((rng.standard_normal((N, K)) * wscale).astype(np.float32), dt)
+    x = O.round_to(rng.standard_normal((M, K)).astype(np.float32), dt)
+    if kind is None:
+        scale = O.absmax_scale(w, 127.0, 0, dt)
+        data = O.quantize_symmetric_int8(w, scale, dt)
+    else:
+        scale = O.absmax_scale(w, O.FP8_MAX[kind], 0, dt)
+        data = O.quantize_symmetric_fp8(w, scale, kind, dt)
+    return dict(x=x, data=data, scale=scale, kind=kind, N=N, K=K, dt=dt)
+
+
+def assert_close_to_exact(y: np.ndarray, y_exact: np.ndarray, dt: str, what=""):
+    """The parity gate (DESIGN.md "Parity"):
+
+    * fp32 / fp16 outputs: relative Frobenius AND relative max error vs exact math <= 1e-3 (north-star tolerance);
+      expected ~1e-6 (fp32) and ~3e-4 (fp16, pure output rounding).
+    * bf16 outputs: one bf16 ulp is 3.9e-3, so the gate is "within 1 ulp of the correctly rounded exact result on
+      >= 99.5 % of the elements, never more than 2 ulp, and <= 1e-3 Frobenius against that rounded result".
+    """
+    y = np.asarray(y, np.float64)
+    if dt in ("fp32", "fp16"):
+        fro, mx = O.rel_fro(y, y_exact), O.rel_max(y, y_exact)
+        assert fro <= 1e-3 and mx <= 1e-3, f"{what}: rel_fro={fro:.3e} rel_max={mx:.3e}"
+    else:
+        target = O.round_to(np.asarray(y_exact, np.float32), dt)
+        ulps = O.ulp_distance(y, target, dt)
+        frac = float((ulps <= 1).mean())
+        fro = O.rel_fro(y, target)
+        # tiny outputs (cancellation) can sit many bf16 ulps away while being accurate in absolute terms
+        scale_abs = np.abs(y_exact).max()
+        big = np.abs(y_exact) > 1e-2 * scale_abs
+        assert frac >= 0.995 and ulps[big].max(initial=0) <= 2 and fro <= 1e-3, \
+            f"{what}: frac<=1ulp={frac:.4f} max_ulp={ulps[big].max(initial=0)} rel_fro={fro:.3e}"
+
+
+def assert_similar(a: torch.Tensor, b: torch.Tensor, atol=None, rtol=None):
+    """The reference's own similarity check (tests/helpers.py:85-99): cosine similarity ~ 1."""
+    assert a.dtype == b.dtype and a.shape == b.shape
+    if atol is None:
+        atol = torch.finfo(a.dtype).resolution
+    if rtol is None:
+        rtol = {torch.float32: 1e-5, torch.float16: 1e-3, torch.bfloat16: 1e-1}[a.dtype]
+    sim = torch.nn.functional.cosine_similarity(a.flatten().float(), b.flatten().float(), dim=0)
+    assert torch.allclose(sim, torch.tensor(1.0, dtype=sim.dtype, device=sim.device), atol=atol, rtol=rtol), \
+        f"alignment {float(sim):.8f} deviates from 1"

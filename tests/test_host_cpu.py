@@ -1,0 +1,182 @@
+"""CPU-only checks of the host-side mirror (no GPU needed):
+
+* the torch host code reproduces the reference's golden vectors bit for bit (it is the data path that builds the
+  packed weights the kernels read);
+* libquanto_hip.so builds/loads and exports every symbol include/quanto_hip.h declares (no compute calls);
+* the product path refuses to run device work without the library (no silent CPU fallback).
+"""
+import ctypes
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import optimum_quanto_amd as Q
+from optimum_quanto_amd.library.hip import quanto_hip
+from optimum_quanto_amd.tensor.packing import PackedTensor, pack_weights
+
+from helpers import TORCH_DT, to_numpy, to_torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "quanto_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(quanto_hip_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 8
+    path = quanto_hip.build()  # no-op when up to date; hipcc cross-compiles without a GPU
+    lib = ctypes.CDLL(path)
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/quanto_hip.h but not exported"
+    lib.quanto_hip_abi_version.restype = ctypes.c_int
+    assert lib.quanto_hip_abi_version() == 1
+    lib.quanto_hip_status_string.restype = ctypes.c_char_p
+    assert lib.quanto_hip_status_string(-1) == b"invalid argument"
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu():
+    lib = quanto_hip.cdll
+    lib.quanto_hip_unpack.restype = ctypes.c_int
+    lib.quanto_hip_unpack.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    assert lib.quanto_hip_unpack(None, None, 16, 3, None) == -1  # bits must be 2 or 4
+    assert lib.quanto_hip_unpack(None, None, -1, 4, None) == -1
+    assert lib.quanto_hip_unpack(None, None, 16, 4, None) == -1  # null pointers
+    lib.quanto_hip_qbits_mm_workspace_size.restype = ctypes.c_int64
+    lib.quanto_hip_qbits_mm_workspace_size.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 4
+    assert lib.quanto_hip_qbits_mm_workspace_size(4096, 4096, 4096, 4, 128, 2, 0) == 32 * 4096 * 4
+    assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 4, 128, 2, 0) == 0  # GEMV needs none
+    assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 3, 128, 2, 0) == -1
+
+
+def test_extension_registry_matches_reference_contract():
+    # tests/library/test_extensions.py:19-39 in the reference: on ROCm the extension is called quanto_hip
+    assert Q.is_extension_available("quanto_hip") == (torch.version.hip is not None)
+    if torch.version.hip is not None:
+        assert Q.get_extension("quanto_hip") is quanto_hip
+    assert not Q.is_extension_available("quanto_cuda")
+
+
+def test_device_ops_have_no_cpu_fallback():
+    """A CPU tensor never reaches the HIP binding, and the binding refuses CPU tensors."""
+    with pytest.raises(Q.QuantoHipError):
+        quanto_hip.lib.unpack(torch.zeros(16, dtype=torch.uint8), 4)
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+def test_pack_unpack_golden(golden, bits):
+    cases = sorted({k[: k.rfind("/")] for k in golden if k.startswith(f"pack/b{bits}/")})
+    assert cases
+    for c in cases:
+        a = torch.from_numpy(golden[c + "/a"])
+        packed = pack_weights(a, bits)
+        assert np.array_equal(packed.numpy(), golden[c + "/packed"])
+        assert np.array_equal(torch.ops.quanto.unpack(packed, bits).numpy(), golden[c + "/unpacked"])
+        pt = PackedTensor.pack(a, bits)
+        assert torch.equal(pt.unpack(), a)
+
+
+def test_packed_tensor_serialization():
+    t = torch.randint(0, 16, (10, 32), dtype=torch.uint8)
+    packed = PackedTensor.pack(t, 4)
+    buf = io.BytesIO()
+    torch.save(packed, buf)
+    buf.seek(0)
+    again = torch.load(buf, weights_only=False)
+    assert isinstance(again, PackedTensor) and again.bits == 4 and again.shape == packed.shape
+    assert torch.equal(again._data, packed._data) and torch.equal(again.unpack(), t)
+
+
+QBITS = ["int4_g128_fp32", "int4_g128_fp16", "int4_g128_bf16", "int4_g128_fp16_zp", "int4_g64_fp32",
+         "int4_perchannel_fp32", "int4_oddrows_fp32", "int2_g128_fp32", "int2_g128_bf16", "int4_g128_bf16_small_w"]
+
+
+def _dt_of(tag):
+    return next(d for d in ("fp32", "fp16", "bf16") if d in tag)
+
+
+@pytest.mark.parametrize("tag", QBITS)
+def test_quantize_weight_qbits_golden(golden, tag):
+    k, dt = f"qbits/{tag}", _dt_of(tag)
+    N, K, bits, gs, zp = [int(v) for v in golden[k + "/meta"]]
+    gs = gs or None
+    qt = Q.qint4 if bits == 4 else Q.qint2
+    w = to_torch(golden[k + "/w"], dt)
+    scale, shift = Q.MaxOptimizer()(w, qtype=qt, axis=0, group_size=gs, zeropoint=bool(zp))
+    qw = Q.quantize_weight(w, qtype=qt, axis=0, scale=scale, shift=shift, group_size=gs)
+    assert isinstance(qw, Q.WeightQBitsTensor) and qw.dtype == TORCH_DT[dt]
+    assert np.array_equal(to_numpy(qw._scale), golden[k + "/scale"])
+    assert np.array_equal(to_numpy(qw._shift), golden[k + "/shift"])
+    assert np.array_equal(qw._data._data.numpy(), golden[k + "/packed"])
+    assert np.array_equal(to_numpy(qw.dequantize()), golden[k + "/dequantized"])
+    for key in [x for x in golden if x.startswith(k + "/x")]:
+        M = key.rsplit("/x", 1)[1]
+        y = torch.nn.functional.linear(to_torch(golden[key], dt), qw)
+        assert np.array_equal(to_numpy(y), golden[k + f"/y{M}"])  # same torch CPU ops as the reference
+
+
+QBYTES = ["int8_fp32", "int8_fp16", "int8_bf16", "e4m3fn_fp32", "e4m3fn_fp16", "e4m3fn_bf16", "e4m3fnuz_fp16", "e5m2_fp16",
+          "cfg1_int8_fp32_1x1024x1024"]
+
+
+@pytest.mark.parametrize("tag", QBYTES)
+def test_quantize_weight_qbytes_golden(golden, tag):
+    k, dt = f"qbytes/{tag}", _dt_of(tag)
+    qt = {"int8": Q.qint8, "e4m3fn": Q.qfloat8_e4m3fn, "e4m3fnuz": Q.qfloat8_e4m3fnuz, "e5m2": Q.qfloat8_e5m2}[
+        "int8" if "int8" in tag else tag.split("_")[0]]
+    if k + "/w" in golden:
+        w = to_torch(golden[k + "/w"], dt)
+        scale = Q.AbsmaxOptimizer()(w, qtype=qt, axis=0)
+        qw = Q.quantize_weight(w, qtype=qt, axis=0, scale=scale)
+        assert np.array_equal(to_numpy(qw._scale), golden[k + "/scale"])
+        assert np.array_equal(to_numpy(qw._data), golden[k + "/data"])
+    else:  # cfg1: the 1024x1024 float weight is not stored; rebuild the QTensor from its golden integers
+        data = torch.from_numpy(golden[k + "/data"])
+        scale = to_torch(golden[k + "/scale"], dt)
+        qw = Q.WeightQBytesTensor(qt, 0, data.shape, data.stride(), data, scale, None)
+    if k + "/dequantized" in golden:
+        assert np.array_equal(to_numpy(qw.dequantize()), golden[k + "/dequantized"])
+    for key in [x for x in golden if x.startswith(k + "/x")]:
+        M = key.rsplit("/x", 1)[1]
+        y = torch.nn.functional.linear(to_torch(golden[key], dt), qw)
+        assert np.array_equal(to_numpy(y), golden[k + f"/y{M}"])
+
+
+def test_qlinear_quantize_freeze_state_dict_roundtrip():
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(256, 128), torch.nn.ReLU(), torch.nn.Linear(128, 64, bias=False))
+    x = torch.randn(4, 256)
+    Q.quantize(model, weights=Q.qint4, exclude="2")
+    assert isinstance(model[0], Q.QLinear) and not isinstance(model[2], Q.QLinear)
+    assert model[0].weight_group_size == 128 and not model[0].frozen
+    y_dyn = model(x)
+    Q.freeze(model)
+    assert model[0].frozen and isinstance(model[0].weight, Q.WeightQBitsTensor)
+    y = model(x)
+    assert torch.equal(y, y_dyn)  # dynamic and frozen quantization agree
+    qmap = Q.quantization_map(model)
+    assert qmap == {"0": {"weights": "qint4", "activations": "none"}}
+    sd = model.state_dict()
+    assert {"0.weight._data._data", "0.weight._scale", "0.weight._shift", "0.bias"} <= set(sd)
+    fresh = torch.nn.Sequential(torch.nn.Linear(256, 128), torch.nn.ReLU(), torch.nn.Linear(128, 64, bias=False))
+    Q.requantize(fresh, sd, qmap)
+    assert torch.equal(fresh(x), y)
+
+
+def test_group_size_selection_follows_reference():
+    from optimum_quanto_amd.nn.module import select_group_size
+    assert [select_group_size(k) for k in (4096, 11008, 14336, 160, 96, 128, 200, 192)] == [128, 128, 128, 32, None, None, None, 96]
+
+
+def test_quantize_weight_argument_errors():
+    w = torch.randn(8, 8)
+    with pytest.raises(ValueError):
+        Q.quantize_weight(w, Q.qint8, axis=1, scale=torch.ones(8, 1))
+    with pytest.raises(ValueError):
+        Q.quantize_weight(w, Q.qint8, axis=0, scale=torch.ones(8, 1), shift=torch.zeros(8, 1))
+    with pytest.raises(ValueError):
+        Q.quantize_weight(w, Q.qint4, axis=0, scale=torch.ones(8, 1))
+    with pytest.raises(ValueError):
+        torch.ops.quanto.quantize_symmetric(torch.randn(8), torch.int8, 0, torch.ones(8))
