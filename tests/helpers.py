@@ -76,6 +76,20 @@ def assert_close_to_exact(y: np.ndarray, y_exact: np.ndarray, dt: str, what=""):
             f"{what}: frac<=1ulp={frac:.4f} max_ulp={ulps[big].max(initial=0)} rel_fro={fro:.3e}"
 
 
+def assert_close_with_bias(y: np.ndarray, prod_exact: np.ndarray, bias: np.ndarray, dt: str, what=""):
+    """Reference order of operations: round the product to ``dt``, add the bias, round again
+    (tensor/function.py:45-46, tensor/weights/qbytes.py:79-81).  A 1-ulp difference of the rounded product is
+    legitimate (accumulation order), so the bound is one ulp of the product plus one ulp of the result."""
+    y = np.asarray(y, np.float64)
+    prod = O.round_to(np.asarray(prod_exact, np.float32), dt).astype(np.float64)
+    want = O.round_to((prod + bias).astype(np.float32), dt).astype(np.float64)
+    eps = {"fp32": 2.0**-23, "fp16": 2.0**-10, "bf16": 2.0**-7}[dt]
+    bound = eps * (np.abs(prod) + np.abs(want)) * 1.01 + 1e-30
+    bad = np.abs(y - want) > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements beyond 1 ulp(product)+1 ulp(result); max err {np.abs(y - want).max():.3e}"
+    assert (y == want).mean() > 0.97, f"{what}: only {(y == want).mean():.4f} identical to the reference sequence"
+
+
 def assert_similar(a: torch.Tensor, b: torch.Tensor, atol=None, rtol=None):
     """The reference's own similarity check (tests/helpers.py:85-99): cosine similarity ~ 1."""
     assert a.dtype == b.dtype and a.shape == b.shape

@@ -1,0 +1,330 @@
+"""GPU parity tests: libquanto_hip (through the C ABI / quanto:: ops) against the CPU oracle.
+
+Run on the MI355X box with ``pytest -m gpu``.  Inputs are seeded numpy arrays quantized by the oracle (itself
+pinned bit-exact to the reference by tests/test_oracle_golden.py), so both sides consume identical integers.
+Integer / byte work is compared bit-exact; products against exact (float64) math with the tolerance documented in
+helpers.assert_close_to_exact.  Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+import optimum_quanto_amd as Q
+from optimum_quanto_amd.library.hip import quanto_hip
+from oracle import quanto_oracle as O
+
+from helpers import (TORCH_DT, assert_close_to_exact, assert_close_with_bias, assert_similar, fp8_tensor, make_qbits_problem, make_qbytes_problem,
+                     to_numpy, to_torch)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_native_library():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    assert quanto_hip.available, "libquanto_hip.so missing: run __graft_entry__.build() - no fallback exists"
+    quanto_hip.lib  # load now: fail loudly
+
+
+# ------------------------------------------------------------------------------------------------ unpack
+@pytest.mark.parametrize("bits", [2, 4])
+@pytest.mark.parametrize("shape", [(10,), (12,), (10, 10), (12, 10), (32, 32), (7, 5), (1, 3), (256, 128), (0, 16), (4099, 3)])
+def test_unpack_bit_exact(bits, shape):
+    rng = np.random.default_rng(hash((bits, shape)) % 2**32)
+    a = rng.integers(0, 2**bits, size=shape, dtype=np.uint8)
+    packed = O.pack_weights(a, bits)
+    out = torch.ops.quanto.unpack(torch.from_numpy(packed).to(DEV), bits)
+    assert out.dtype == torch.uint8 and out.is_cuda
+    np.testing.assert_array_equal(out.cpu().numpy(), O.unpack(packed, bits))
+    np.testing.assert_array_equal(out.cpu().numpy()[: a.shape[0]], a)
+
+
+def test_unpack_golden_and_packed_tensor(golden):
+    for c in sorted({k[: k.rfind("/")] for k in golden if k.startswith("pack/")}):
+        bits = int(c.split("/")[1][1:])
+        got = torch.ops.quanto.unpack(torch.from_numpy(golden[c + "/packed"]).to(DEV), bits)
+        np.testing.assert_array_equal(got.cpu().numpy(), golden[c + "/unpacked"])
+    t = torch.randint(0, 16, (12, 10), dtype=torch.uint8)
+    pt = Q.PackedTensor.pack(t, 4).to(DEV)
+    assert isinstance(pt, Q.PackedTensor) and torch.equal(pt.unpack().cpu(), t)
+
+
+def test_unpack_cfg3_shape_and_views():
+    """BASELINE config 3 packed tensor (176128, 128) and a non-16-byte-aligned view (scalar kernel path)."""
+    rng = np.random.default_rng(3)
+    packed = rng.integers(0, 256, size=(176128, 128), dtype=np.uint8)
+    tp = torch.from_numpy(packed).to(DEV)
+    out = torch.ops.quanto.unpack(tp, 4)
+    assert out.shape == (352256, 128)
+    assert torch.equal(out[:176128], tp & 0x0F) and torch.equal(out[176128:], tp >> 4)
+    # idempotence property: re-packing the unpacked planes gives the packed bytes back
+    assert torch.equal(out[:176128] | (out[176128:] << 4), tp)
+    view = tp.flatten()[3:3 + 1000 * 7].reshape(1000, 7)
+    np.testing.assert_array_equal(torch.ops.quanto.unpack(view, 2).cpu().numpy(), O.unpack(view.cpu().numpy(), 2))
+
+
+# ------------------------------------------------------------------------------------------------ dequantize
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("bits,group_size,N,K,zp", [(4, 128, 64, 256, False), (4, 128, 64, 256, True), (2, 128, 64, 256, False),
+                                                   (4, 64, 48, 192, False), (4, None, 33, 40, False), (4, 128, 5, 128, False),
+                                                   (4, 32, 16, 160, True), (4, 128, 256, 1024, False)])
+def test_dequantize_qbits_bit_exact(dt, bits, group_size, N, K, zp):
+    p = make_qbits_problem(1, N, K, dt, bits=bits, group_size=group_size, zeropoint=zp, seed=5, wscale=1.0)
+    shift_t = torch.from_numpy(p["shift"]).to(DEV) if zp else to_torch(p["shift"], dt, DEV)
+    got = torch.ops.quanto.dequantize_qbits(torch.from_numpy(p["packed"]).to(DEV), to_torch(p["scale"], dt, DEV), shift_t,
+                                            bits, group_size, N, K)
+    want = O.dequantize_qbits_ref(p["packed"], bits, p["scale"], p["shift"], 0, group_size, (N, K), dt)
+    np.testing.assert_array_equal(to_numpy(got), want)  # same rounding sequence as the reference
+
+
+def test_dequantize_golden(golden):
+    for tag in ["int4_g128_fp32", "int4_g128_fp16", "int4_g128_bf16", "int4_g128_fp16_zp", "int4_g64_fp32",
+                "int4_perchannel_fp32", "int4_oddrows_fp32", "int2_g128_fp32", "int2_g128_bf16"]:
+        k = f"qbits/{tag}"
+        dt = next(d for d in ("fp32", "fp16", "bf16") if d in tag)
+        N, K, bits, gs, zp = [int(v) for v in golden[k + "/meta"]]
+        shift = torch.from_numpy(golden[k + "/shift"]).to(DEV) if zp else to_torch(golden[k + "/shift"], dt, DEV)
+        got = torch.ops.quanto.dequantize_qbits(torch.from_numpy(golden[k + "/packed"]).to(DEV),
+                                                to_torch(golden[k + "/scale"], dt, DEV), shift, bits, gs or None, N, K)
+        np.testing.assert_array_equal(to_numpy(got), golden[k + "/dequantized"])
+
+
+# ------------------------------------------------------------------------------------------------ qbits_mm
+def _run_qbits(p, kernel, bias=None):
+    dt = p["dt"]
+    zp = not np.issubdtype(p["shift"].dtype, np.floating)
+    shift_t = torch.from_numpy(p["shift"]).to(DEV) if zp else to_torch(p["shift"], dt, DEV)
+    y = quanto_hip.lib.qbits_mm(to_torch(p["x"], dt, DEV), torch.from_numpy(p["packed"]).to(DEV), to_torch(p["scale"], dt, DEV),
+                                shift_t, None if bias is None else to_torch(bias, dt, DEV), p["bits"], p["group_size"], p["N"],
+                                p["K"], kernel=kernel)
+    if kernel != "auto":
+        assert quanto_hip.lib.last_kernel() == kernel
+    return to_numpy(y)
+
+
+def _exact_qbits(p, bias=None):
+    return O.qbits_mm_exact(p["x"], p["packed"], p["bits"], p["scale"], p["shift"], p["group_size"], p["N"], p["K"], bias)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("N,K", [(256, 1024), (512, 4096), (64, 2048), (384, 3072), (128, 8192), (96, 14336), (256, 128), (34, 11008)])
+def test_qbits_gemv(dt, M, N, K):
+    p = make_qbits_problem(M, N, K, dt, seed=M * 7 + N)
+    assert_close_to_exact(_run_qbits(p, "gemv"), _exact_qbits(p), dt, f"gemv {M}x{K}x{N}")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_qbits_gemv_zeropoint_and_bias(dt):
+    p = make_qbits_problem(3, 256, 1024, dt, zeropoint=True, seed=11)
+    bias = O.round_to(np.random.default_rng(1).standard_normal(256).astype(np.float32), dt)
+    assert_close_with_bias(_run_qbits(p, "gemv", bias), _exact_qbits(p), bias, dt, "gemv zp+bias")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K,gs", [(16, 256, 256, 128), (128, 128, 512, 128), (100, 384, 1024, 128), (9, 130, 256, 128),
+                                      (256, 512, 4096, 128), (64, 256, 512, 64), (33, 64, 192, 64), (300, 1024, 2048, 128)])
+def test_qbits_mfma(dt, M, N, K, gs):
+    p = make_qbits_problem(M, N, K, dt, group_size=gs, seed=M + N + K)
+    assert_close_to_exact(_run_qbits(p, "mfma"), _exact_qbits(p), dt, f"mfma {M}x{K}x{N} g{gs}")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_qbits_mfma_zeropoint_and_bias(dt):
+    p = make_qbits_problem(40, 256, 512, dt, zeropoint=True, seed=12)
+    bias = O.round_to(np.random.default_rng(2).standard_normal(256).astype(np.float32), dt)
+    assert_close_with_bias(_run_qbits(p, "mfma", bias), _exact_qbits(p), bias, dt, "mfma zp+bias")
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("bits,gs,M,N,K,zp", [(4, 128, 3, 64, 256, False), (2, 128, 4, 64, 256, False), (4, None, 3, 33, 40, False),
+                                              (4, 128, 2, 5, 128, False), (4, 32, 5, 16, 160, True), (2, 64, 7, 20, 128, True),
+                                              (4, 96, 2, 8, 192, False)])
+def test_qbits_naive_any_shape(dt, bits, gs, M, N, K, zp):
+    p = make_qbits_problem(M, N, K, dt, bits=bits, group_size=gs, zeropoint=zp, seed=21, wscale=1.0)
+    assert_close_to_exact(_run_qbits(p, "naive"), _exact_qbits(p), dt, "naive")
+    assert_close_to_exact(_run_qbits(p, "auto"), _exact_qbits(p), dt, "auto")
+
+
+def test_qbits_auto_picks_fast_kernels():
+    p = make_qbits_problem(1, 256, 1024, "bf16")
+    _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "gemv"
+    p = make_qbits_problem(64, 256, 1024, "bf16")
+    _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "mfma"
+
+
+def test_qbits_golden_linear(golden):
+    """F.linear on weights moved to the device reproduces the reference outputs within its own test tolerance."""
+    for tag in ["int4_g128_fp16", "int4_g128_bf16", "int4_g128_bf16_bias", "int4_g128_fp16_zp", "int2_g128_bf16",
+                "int4_g128_bf16_small_w", "int4_g128_fp32", "int4_perchannel_fp32"]:
+        k = f"qbits/{tag}"
+        dt = next(d for d in ("fp32", "fp16", "bf16") if d in tag)
+        N, K, bits, gs, zp = [int(v) for v in golden[k + "/meta"]]
+        shift = torch.from_numpy(golden[k + "/shift"]) if zp else to_torch(golden[k + "/shift"], dt)
+        data = torch.from_numpy(golden[k + "/unpacked"])
+        qw = Q.WeightQBitsTensor(Q.qint4 if bits == 4 else Q.qint2, 0, gs or None, torch.Size([N, K]), (K, 1), data,
+                                 to_torch(golden[k + "/scale"], dt), shift).to(DEV)
+        assert isinstance(qw, Q.WeightQBitsTensor) and qw._data._data.is_cuda
+        np.testing.assert_array_equal(qw._data._data.cpu().numpy(), golden[k + "/packed"])
+        bias = to_torch(golden[k + "/bias"], dt, DEV) if k + "/bias" in golden else None
+        for key in [x for x in golden if x.startswith(k + "/x")]:
+            M = key.rsplit("/x", 1)[1]
+            y = torch.nn.functional.linear(to_torch(golden[key], dt, DEV), qw, bias)
+            want = to_torch(golden[k + f"/y{M}"], dt, DEV)
+            assert_similar(want, y)
+            err = (y.float() - want.float()).abs().max() / want.float().abs().max()
+            assert err < 2e-2  # tests/tensor/weights/weight_helpers.py:33-37 (cuda tolerance)
+
+
+# ------------------------------------------------------------------------------------------------ qbytes_mm
+def _run_qbytes(p, kernel, bias=None, a_override=None):
+    dt = p["dt"]
+    b = fp8_tensor(p["data"], p["kind"], DEV) if p["kind"] else torch.from_numpy(p["data"]).to(DEV)
+    a = to_torch(p["x"], dt, DEV) if a_override is None else a_override
+    y = quanto_hip.lib.qbytes_mm(a, b, to_torch(p["scale"], dt, DEV), None if bias is None else to_torch(bias, dt, DEV),
+                                 kernel=kernel)
+    if kernel != "auto":
+        assert quanto_hip.lib.last_kernel() == kernel
+    return to_numpy(y)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("kind", [None, "e4m3fn", "e5m2"])
+@pytest.mark.parametrize("M,N,K", [(1, 256, 1024), (2, 100, 4096), (3, 64, 2048), (8, 48, 512), (1, 33, 8192), (5, 16, 14336), (1, 64, 48)])
+def test_qbytes_gemv(dt, kind, M, N, K):
+    p = make_qbytes_problem(M, N, K, dt, kind, seed=M + N)
+    assert_close_to_exact(_run_qbytes(p, "gemv"), O.qbytes_mm_exact(p["x"], p["data"], p["scale"], kind), dt, "qbytes gemv")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("kind", [None, "e4m3fn", "e5m2"])
+@pytest.mark.parametrize("M,N,K", [(16, 128, 64), (128, 128, 512), (100, 200, 1024), (9, 130, 256), (512, 512, 2048), (257, 48, 128)])
+def test_qbytes_mfma(dt, kind, M, N, K):
+    p = make_qbytes_problem(M, N, K, dt, kind, seed=M + K)
+    assert_close_to_exact(_run_qbytes(p, "mfma"), O.qbytes_mm_exact(p["x"], p["data"], p["scale"], kind), dt, "qbytes mfma")
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("kind", [None, "e4m3fn", "e4m3fnuz", "e5m2"])
+@pytest.mark.parametrize("M,N,K", [(1, 48, 32), (10, 50, 50), (32, 64, 50), (7, 3, 5)])
+def test_qbytes_naive_any_shape(dt, kind, M, N, K):
+    p = make_qbytes_problem(M, N, K, dt, kind, seed=N + K, wscale=1.0)
+    want = O.qbytes_mm_exact(p["x"], p["data"], p["scale"], kind)
+    assert_close_to_exact(_run_qbytes(p, "naive"), want, dt, "qbytes naive")
+    assert_close_to_exact(_run_qbytes(p, "auto"), want, dt, "qbytes auto")
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+def test_qbytes_int8_activations_bit_exact(dt):
+    """library/qbytes_mm.py:36-50: int32 accumulate, fp32 rescale, one rounding -> reproducible bit for bit."""
+    rng = np.random.default_rng(30)
+    a = rng.integers(-127, 127, size=(32, 64), dtype=np.int8)
+    b = rng.integers(-127, 127, size=(48, 64), dtype=np.int8)
+    s = O.round_to(((rng.random((48, 1)) * 2 - 1) / 1e3).astype(np.float32), dt)
+    y = quanto_hip.lib.qbytes_mm(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), to_torch(s, dt, DEV))
+    np.testing.assert_array_equal(to_numpy(y), O.qbytes_int_mm_ref(a, b, s, dt))
+
+
+def test_qbytes_mm_reference_test_grid():
+    """The parameter grid of the reference's tests/library/test_mm.py:27-49, same assertion (assert_similar)."""
+    g = torch.Generator().manual_seed(0)
+    for batch in (1, 10, None):
+        for K in (32, 50):
+            for N in (48, 50, 64):
+                for wdt in (torch.float8_e4m3fn, torch.float8_e4m3fnuz, torch.int8):
+                    for odt in (torch.float16, torch.bfloat16):
+                        for idt in (odt, torch.int8):
+                            shape = (32, K) if batch is None else (batch, 32, K)
+                            if idt == torch.int8:
+                                x = torch.randint(-127, 127, shape, dtype=torch.int8, generator=g)
+                            else:
+                                x = (torch.rand(shape, generator=g) * 2 - 1).to(idt)
+                            if wdt == torch.int8:
+                                w = torch.randint(-127, 127, (N, K), dtype=torch.int8, generator=g)
+                            else:
+                                w = (torch.rand((N, K), generator=g) * 2 - 1).to(torch.float16).to(wdt)
+                            scale = ((torch.rand((N, 1), generator=g) * 2 - 1) / 1e3).to(odt)
+                            out = torch.ops.quanto.qbytes_mm(x.to(DEV), w.to(DEV), scale.to(DEV))
+                            expected = torch.matmul(x.to(DEV).to(odt), (w.to(DEV).to(odt) * scale.to(DEV)).t())
+                            assert out.shape == expected.shape
+                            assert_similar(expected, out)
+
+
+def test_qbytes_golden_linear(golden):
+    for tag in ["int8_fp16", "int8_bf16", "e4m3fn_fp16", "e4m3fn_bf16", "int8_bf16_bias", "e4m3fnuz_fp16", "e5m2_fp16", "int8_fp32",
+                "cfg1_int8_fp32_1x1024x1024"]:
+        k = f"qbytes/{tag}"
+        dt = next(d for d in ("fp32", "fp16", "bf16") if d in tag)
+        kind = next((x for x in ("e4m3fnuz", "e4m3fn", "e5m2") if tag.startswith(x)), None)
+        qt = {None: Q.qint8, "e4m3fn": Q.qfloat8_e4m3fn, "e4m3fnuz": Q.qfloat8_e4m3fnuz, "e5m2": Q.qfloat8_e5m2}[kind]
+        data = fp8_tensor(golden[k + "/data"], kind) if kind else torch.from_numpy(golden[k + "/data"])
+        N, K = data.shape
+        qw = Q.WeightQBytesTensor(qt, 0, torch.Size([N, K]), (K, 1), data, to_torch(golden[k + "/scale"], dt), None).to(DEV)
+        bias = to_torch(golden[k + "/bias"], dt, DEV) if k + "/bias" in golden else None
+        for key in [x for x in golden if x.startswith(k + "/x")]:
+            M = key.rsplit("/x", 1)[1]
+            y = torch.nn.functional.linear(to_torch(golden[key], dt, DEV), qw, bias)
+            want = to_torch(golden[k + f"/y{M}"], dt, DEV)
+            assert_similar(want, y)
+            assert (y.float() - want.float()).abs().max() / want.float().abs().max() < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE sizes
+def _sample_rows_check(y, x, w_exact_fn, rows, dt, what):
+    want = w_exact_fn(x[rows])
+    assert_close_to_exact(y[rows], want, dt, what)
+
+
+def test_cfg2_bf16_int8_4096_cubed():
+    """BASELINE configs[1]: direct oracle check on 48 sampled rows + linearity over the full output."""
+    p = make_qbytes_problem(4096, 4096, 4096, "bf16", None, seed=2)
+    y = _run_qbytes(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "mfma"
+    rows = np.random.default_rng(0).choice(4096, 48, replace=False)
+    _sample_rows_check(y, p["x"], lambda xr: O.qbytes_mm_exact(xr, p["data"], p["scale"]), rows, "bf16", "cfg2")
+    # size-independent property: y(2x) == 2 y(x) exactly (power-of-two scaling commutes with every rounding)
+    p2 = dict(p, x=p["x"] * 2)
+    np.testing.assert_array_equal(_run_qbytes(p2, "auto"), y * 2)
+
+
+@pytest.mark.parametrize("N,K", [(11008, 4096), (4096, 4096)])
+def test_cfg3_bf16_int4_decode(N, K):
+    """BASELINE configs[2] (1,4096,11008) and the north-star shape (1,4096,4096): full oracle check."""
+    p = make_qbits_problem(1, N, K, "bf16", seed=3)
+    y = _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "gemv"
+    assert_close_to_exact(y, _exact_qbits(p), "bf16", "cfg3")
+    ym = _run_qbits(p, "mfma")
+    assert_close_to_exact(ym, _exact_qbits(p), "bf16", "cfg3 via mfma")
+
+
+def test_cfg4_fp8_512x8192x8192():
+    p = make_qbytes_problem(512, 8192, 8192, "bf16", "e4m3fn", seed=4)
+    y = _run_qbytes(p, "auto")
+    rows = np.random.default_rng(1).choice(512, 32, replace=False)
+    _sample_rows_check(y, p["x"], lambda xr: O.qbytes_mm_exact(xr, p["data"], p["scale"], "e4m3fn"), rows, "bf16", "cfg4")
+
+
+# ------------------------------------------------------------------------------------------------ QLinear end to end
+@pytest.mark.parametrize("weights", ["qint4", "qint8", "qfloat8"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tokens", [1, 33])
+def test_qlinear_on_device(weights, dtype, tokens):
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(1024, 512, bias=True).to(dtype)
+    model = torch.nn.Sequential(lin)
+    Q.quantize(model, weights=weights)
+    Q.freeze(model)
+    x = torch.randn(2, tokens, 1024).to(dtype)
+    with torch.no_grad():
+        ref = model(x)  # CPU path (default/CPU op implementations)
+    model.to(DEV)
+    assert model[0].weight._data.is_cuda
+    with torch.no_grad():
+        y = model(x.to(DEV))
+    assert y.shape == ref.shape and y.dtype == dtype
+    assert_similar(ref.to(DEV), y)
+    assert (y.float().cpu() - ref.float()).abs().max() / ref.float().abs().max() < 2e-2
