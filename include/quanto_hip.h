@@ -57,7 +57,8 @@ typedef enum {
   QUANTO_HIP_KERNEL_AUTO = 0,
   QUANTO_HIP_KERNEL_NAIVE = 1, /* one thread per output element, any shape                      */
   QUANTO_HIP_KERNEL_GEMV = 2,  /* weight-streaming kernel for M <= QUANTO_HIP_GEMV_MAX_M         */
-  QUANTO_HIP_KERNEL_MFMA = 3   /* LDS-tiled MFMA kernel                                          */
+  QUANTO_HIP_KERNEL_MFMA = 3,  /* LDS-tiled MFMA kernel, 128x128 tile (any M)                   */
+  QUANTO_HIP_KERNEL_MFMA_LARGE = 4 /* 256x256 tile, LDS-DMA pipeline (prefill-sized M and N)     */
 } quanto_hip_kernel;
 
 #define QUANTO_HIP_GEMV_MAX_M 8

@@ -21,6 +21,8 @@ bool qbytes_gemv_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_gemv(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 bool qbytes_mfma_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_mfma(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
+bool qbytes_mfma_v2_supported(int64_t, int64_t, int64_t, int, int, int);
+int qbytes_mm_mfma_v2(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 bool qbits_mfma_supported(int64_t, const PackedGeom&, int);
 size_t qbits_mfma_workspace(int64_t, const PackedGeom&);
 int qbits_mm_mfma(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, void*,
@@ -45,6 +47,9 @@ static int check_qbits(int64_t M, int64_t N, int64_t K, int bits, int group_size
 
 // M above which the weight-streaming GEMV stops being the better choice (it re-reads W once per 4 (int4) / 2 (int8) rows of x)
 static bool prefer_gemv(int64_t M) { return M <= QUANTO_HIP_GEMV_MAX_M; }
+
+// 256x256 tiles pay off once they can fill a good part of the 256 CUs; below that the 128x128 kernel has 4x the blocks
+static bool prefer_large_tile(int64_t M, int64_t N) { return ((M + 255) / 256) * ((N + 255) / 256) >= 96; }
 
 }  // namespace qh
 
@@ -141,6 +146,8 @@ int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const
   if (kernel == QUANTO_HIP_KERNEL_AUTO) {
     if (prefer_gemv(M) && qbytes_gemv_supported(M, N, K, a_dtype, b_dtype, out_dtype))
       kernel = QUANTO_HIP_KERNEL_GEMV;
+    else if (qbytes_mfma_v2_supported(M, N, K, a_dtype, b_dtype, out_dtype) && prefer_large_tile(M, N))
+      kernel = QUANTO_HIP_KERNEL_MFMA_LARGE;
     else if (qbytes_mfma_supported(M, N, K, a_dtype, b_dtype, out_dtype))
       kernel = QUANTO_HIP_KERNEL_MFMA;
     else
@@ -159,6 +166,10 @@ int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const
     case QUANTO_HIP_KERNEL_MFMA:
       r = qbytes_mm_mfma(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("mfma");
+      return r;
+    case QUANTO_HIP_KERNEL_MFMA_LARGE:
+      r = qbytes_mm_mfma_v2(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("mfma_large");
       return r;
   }
   return QUANTO_HIP_EINVAL;

@@ -207,6 +207,15 @@ def test_qbytes_mfma(dt, kind, M, N, K):
     assert_close_to_exact(_run_qbytes(p, "mfma"), O.qbytes_mm_exact(p["x"], p["data"], p["scale"], kind), dt, "qbytes mfma")
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("kind", [None, "e4m3fn", "e5m2"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1024), (300, 700, 256), (1, 17, 192), (1024, 256, 4096)])
+def test_qbytes_mfma_large_tile(dt, kind, M, N, K):
+    """256x256 LDS-DMA kernel incl. ragged M / N edges (clamped loads, masked stores) and 2..64 K-tiles."""
+    p = make_qbytes_problem(M, N, K, dt, kind, seed=M + K + 1)
+    assert_close_to_exact(_run_qbytes(p, "mfma_large"), O.qbytes_mm_exact(p["x"], p["data"], p["scale"], kind), dt, "qbytes mfma_large")
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("kind", [None, "e4m3fn", "e4m3fnuz", "e5m2"])
 @pytest.mark.parametrize("M,N,K", [(1, 48, 32), (10, 50, 50), (32, 64, 50), (7, 3, 5)])
@@ -282,7 +291,7 @@ def test_cfg2_bf16_int8_4096_cubed():
     """BASELINE configs[1]: direct oracle check on 48 sampled rows + linearity over the full output."""
     p = make_qbytes_problem(4096, 4096, 4096, "bf16", None, seed=2)
     y = _run_qbytes(p, "auto")
-    assert quanto_hip.lib.last_kernel() == "mfma"
+    assert quanto_hip.lib.last_kernel() == "mfma_large"
     rows = np.random.default_rng(0).choice(4096, 48, replace=False)
     _sample_rows_check(y, p["x"], lambda xr: O.qbytes_mm_exact(xr, p["data"], p["scale"]), rows, "bf16", "cfg2")
     # size-independent property: y(2x) == 2 y(x) exactly (power-of-two scaling commutes with every rounding)
