@@ -75,32 +75,16 @@ struct Mma<QUANTO_HIP_F16> {
 
 enum { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2 };
 
-// 8 one-byte weights (two dwords) -> one MFMA operand (8 x 16-bit)
-template <int DT, int FMT>
-__device__ __forceinline__ typename Mma<DT>::V8 convert8(uint32_t w0, uint32_t w1) {
-  uint32_t out[4];
-  const uint32_t in[2] = {w0, w1};
-#pragma unroll
-  for (int d = 0; d < 2; ++d) {
-    float f0, f1, f2, f3;
-    if constexpr (FMT == W_I8) {
-      f0 = (float)(int8_t)(in[d] & 0xFFu);
-      f1 = (float)(int8_t)((in[d] >> 8) & 0xFFu);
-      f2 = (float)(int8_t)((in[d] >> 16) & 0xFFu);
-      f3 = (float)(int8_t)(in[d] >> 24);
-    } else if constexpr (FMT == W_F8E4M3) {
-      const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)in[d], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)in[d], true);
-      f0 = lo.x; f1 = lo.y; f2 = hi.x; f3 = hi.y;
-    } else {
-      const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_bf8((int)in[d], false), hi = __builtin_amdgcn_cvt_pk_f32_bf8((int)in[d], true);
-      f0 = lo.x; f1 = lo.y; f2 = hi.x; f3 = hi.y;
-    }
-    out[2 * d] = Mma<DT>::pack(f0, f1);
-    out[2 * d + 1] = Mma<DT>::pack(f2, f3);
-  }
-  const uint4 v = make_uint4(out[0], out[1], out[2], out[3]);
-  return __builtin_bit_cast(typename Mma<DT>::V8, v);
+// LDS swizzles (chunk position = logical 16-byte chunk ^ swz(row)); derived for the ds_read_b128 service groups of
+// gfx950 ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32) so that every fragment read is conflict free:
+//  * activations (128-byte rows, 8 chunks, fragment lanes read chunk 2*(lane>>4)+kk): rows 4..11 of each 16-row
+//    fragment take positions {0..3} ^ c, rows 0..3 and 12..15 take {4..7} ^ c, distinct inside each row parity;
+//  * weights (64-byte rows, 4 chunks, lanes read chunk lane>>4).
+__device__ __forceinline__ int swz_a(int row) {
+  const int q = (row + 4) & 15;
+  return ((((q >> 3) ^ 1) << 2) | ((q >> 1) & 3));
 }
+__device__ __forceinline__ int swz_w(int row) { return (-(row >> 2)) & 3; }
 
 struct Args {
   const void* x;
@@ -110,6 +94,26 @@ struct Args {
   void* y;
   int M, N, K;
 };
+
+// One output dword of a converted operand: bytes (2p, 2p+1) of `word` -> two 16-bit elements.  3 VALU ops
+// (int8: 2x v_cvt_f32_i32 with SDWA byte select + v_cvt_pk_bf16_f32), sized to fit the issue gap of one 16x16x32 MFMA.
+template <int DT, int FMT>
+__device__ __forceinline__ uint32_t convert_pair(uint32_t word, int p /* 0 or 1 */) {
+  float f0, f1;
+  if constexpr (FMT == W_I8) {
+    f0 = p == 0 ? (float)(int8_t)(word & 0xFFu) : (float)(int8_t)((word >> 16) & 0xFFu);
+    f1 = p == 0 ? (float)(int8_t)((word >> 8) & 0xFFu) : (float)(int8_t)(word >> 24);
+  } else if constexpr (FMT == W_F8E4M3) {
+    const f32x2 v = p == 0 ? __builtin_amdgcn_cvt_pk_f32_fp8((int)word, false) : __builtin_amdgcn_cvt_pk_f32_fp8((int)word, true);
+    f0 = v.x;
+    f1 = v.y;
+  } else {
+    const f32x2 v = p == 0 ? __builtin_amdgcn_cvt_pk_f32_bf8((int)word, false) : __builtin_amdgcn_cvt_pk_f32_bf8((int)word, true);
+    f0 = v.x;
+    f1 = v.y;
+  }
+  return Mma<DT>::pack(f0, f1);
+}
 
 template <int DT, int FMT>
 __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
@@ -145,7 +149,7 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int R = (j * 8 + wave) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (R & 7);
+    const int c = (lane & 7) ^ swz_a(R);
     int m = m0 + R;
     m = m < M ? m : M - 1;
     asrc[j] = reinterpret_cast<const uint8_t*>(xg + (size_t)m * K + c * 8);
@@ -154,15 +158,15 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int R = (j * 8 + wave) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((-(R >> 2)) & 3);
+    const int c = (lane & 3) ^ swz_w(R);
     int n = n0 + R;
     n = n < N ? n : N - 1;
     wsrc[j] = a.w + (size_t)n * K + c * 16;
     wdst[j] = A_BYTES + (j * 8 + wave) * 1024;
   }
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
-  auto issue = [&](int kt) {
-    const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + (kt % STAGES) * STAGE_BYTES);
+  auto issue = [&](int kt, int stage) {
+    const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
 #pragma unroll
     for (int j = 0; j < 4; ++j) glds16(asrc[j] + (size_t)kt * (BK * 2), st + adst[j]);
 #pragma unroll
@@ -170,77 +174,176 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
   };
 
   // ---- fragment read offsets (constant per lane) ------------------------------------------------------
+  // activation fragment mf (16 rows) of this wave, k-half kk: logical chunk 2*(lane>>4) + kk of row R
+  // weight fragment j (16 rows): ONE 16-byte read per K-tile, logical chunk lane>>4
   int aoff[8][2], boff[4];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int R = wm * 128 + i * 16 + (lane & 15);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) aoff[i][kk] = R * 128 + ((((lane >> 4) * 2 + kk) ^ (R & 7)) << 4);
+    for (int kk = 0; kk < 2; ++kk) aoff[i][kk] = R * 128 + ((((lane >> 4) * 2 + kk) ^ swz_a(R)) << 4);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int R = wn * 64 + j * 16 + (lane & 15);
-    boff[j] = A_BYTES + R * 64 + (((lane >> 4) ^ ((-(R >> 2)) & 3)) << 4);
+    boff[j] = A_BYTES + R * 64 + (((lane >> 4) ^ swz_w(R)) << 4);
   }
 
-  f32x4 acc[8][4];
+  // acc[j][mf]: weight fragment j is the MFMA A operand (rows n), activation fragment mf the B operand (cols m):
+  // D[n][m], so a lane ends up with 4 CONSECUTIVE output features of one token -> 8-byte stores in the epilogue.
+  f32x4 acc[4][8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
-  if (nk > 1) issue(1);
+  // Software pipeline.  A K-tile is consumed in four 16-MFMA blocks S0..S3 = (k-half, token-half).  Activation
+  // fragments ping-pong between two register sets (xa / xb) one block ahead of their use.  The weight tile is read
+  // once per K-tile (wraw, 16 bytes per fragment) and converted in 3-instruction pieces placed in the issue gaps of
+  // the MFMAs: the k-half-1 operand (w1) during S0, the NEXT tile's k-half-0 operand (w0) during S3.
+  // Two barriers per K-tile: B1 (before S2) makes tile kt+1 visible so its weight bytes can be fetched during S2;
+  // B2 (before S3) retires every wave's reads of tile kt, after which its stage is refilled by the DMA of tile kt+3.
+  uint4 wraw[4];
+  uint32_t w0[4][4], w1[4][4];
+  V8 xa[4], xb[4];
+  auto read_w = [&](const uint8_t* st) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wraw[j] = *reinterpret_cast<const uint4*>(st + boff[j]);
+  };
+  auto read_x = [&](V8(&f)[4], const uint8_t* st, int kk, int h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const V8*>(st + aoff[h * 4 + i][kk]);
+  };
+  auto wword = [&](int j, int kk, int d) -> uint32_t {  // source dword of output dword d of fragment j, k-half kk
+    const uint32_t lo = kk == 0 ? wraw[j].x : wraw[j].z, hi = kk == 0 ? wraw[j].y : wraw[j].w;
+    return d < 2 ? lo : hi;
+  };
+  auto as_v8 = [&](const uint32_t(&w)[4]) { return __builtin_bit_cast(V8, make_uint4(w[0], w[1], w[2], w[3])); };
 
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  if (nk > 2) issue(2, 2);
+  if (nk > 2)
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (nk > 1)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_w(smem);
+  read_x(xa, smem, 0, 0);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) w0[q >> 2][q & 3] = convert_pair<DT, FMT>(wword(q >> 2, 0, q & 3), q & 1);
+
+  int cur = 0;  // stage of tile kt
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed once at most the 6 DMA instructions of tile kt+1 are still outstanding
-    if (kt + 1 < nk)
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave's part of tile kt is visible; every wave is done reading stage (kt+2)%3
-    asm volatile("" ::: "memory");
-    if (kt + 2 < nk) issue(kt + 2);
+    const uint8_t* st = smem + cur * STAGE_BYTES;
+    const int nxt = cur == STAGES - 1 ? 0 : cur + 1;
+    const uint8_t* sn = smem + nxt * STAGE_BYTES;
+    const bool more = kt + 1 < nk;
 
-    const uint8_t* st = smem + (kt % STAGES) * STAGE_BYTES;
-    uint4 braw[4];
+    // ---- S0: k-half 0, tokens 0..63 | convert w1 -----------------------------------------------------------
+    read_x(xb, st, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) braw[j] = *reinterpret_cast<const uint4*>(st + boff[j]);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      V8 fa[8], fb[4];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const V8*>(st + aoff[i][kk]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        fb[j] = kk == 0 ? convert8<DT, FMT>(braw[j].x, braw[j].y) : convert8<DT, FMT>(braw[j].z, braw[j].w);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = Mma<DT>::run(fa[i], fb[j], acc[i][j]);
+    for (int q = 0; q < 16; ++q) {
+      acc[q & 3][q >> 2] = Mma<DT>::run(as_v8(w0[q & 3]), xa[q >> 2], acc[q & 3][q >> 2]);
+      w1[q >> 2][q & 3] = convert_pair<DT, FMT>(wword(q >> 2, 1, q & 3), q & 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // ---- S1: k-half 0, tokens 64..127 --------------------------------------------------------------------------
+    read_x(xa, st, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q & 3][4 + (q >> 2)] = Mma<DT>::run(as_v8(w0[q & 3]), xb[q >> 2], acc[q & 3][4 + (q >> 2)]);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- B1: tile kt+1 visible ------------------------------------------------------------------------------------
+    if (more) {
+      if (kt + 2 < nk)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile kt+1 landed; tile kt+2 may still be in flight
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    // ---- S2: k-half 1, tokens 0..63 | fetch next tile's weight bytes ------------------------------------------------
+    read_x(xb, st, 1, 1);
+    if (more) read_w(sn);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q & 3][q >> 2] = Mma<DT>::run(as_v8(w1[q & 3]), xa[q >> 2], acc[q & 3][q >> 2]);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- B2: every read of tile kt has returned -> refill its stage ----------------------------------------------
+    if (more) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 3 < nk) issue(kt + 3, cur);
+      read_x(xa, sn, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S3: k-half 1, tokens 64..127 | convert next tile's w0 ---------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      acc[q & 3][4 + (q >> 2)] = Mma<DT>::run(as_v8(w1[q & 3]), xb[q >> 2], acc[q & 3][4 + (q >> 2)]);
+      w0[q >> 2][q & 3] = convert_pair<DT, FMT>(wword(q >> 2, 0, q & 3), q & 1);  // (harmless on the last tile)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    cur = nxt;
   }
 
-  // ---- epilogue: per-channel scale on the fp32 accumulator, optional bias, store -------------------------
+  // ---- epilogue: per-channel scale on the fp32 accumulator, optional bias, full-line stores ------------------
+  // The stage memory is free once every wave has left the K loop.  Each wave parks its 128x64 result (16 KiB, rows of
+  // 128 bytes, 8-byte chunks XOR-swizzled by ((row & 7) << 1) so that both the ds_write_b64 below and the ds_read_b128
+  // that follows stay (nearly) conflict free) and streams it out as whole 128-byte lines: 8 rows x 128 B per store
+  // instruction instead of 16 rows x 32 B.
   T* yg = reinterpret_cast<T*>(a.y);
   const bool has_bias = a.bias != nullptr;
+  const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (N % 8 == 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  uint8_t* park = smem + wave * (128 * 128);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-    if (n >= N) continue;
-    const float sc = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
-    const float bv = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
+    const int nb = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;  // 4 consecutive output features nb..nb+3
+    float sc[4], bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nb + r < N ? nb + r : N - 1;
+      sc[r] = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
+      bv[r] = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+      T out[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 128 + i * 16 + (lane >> 4) * 4 + r;
-        if (m < M) {
-          float v = acc[i][j][r] * sc;
-          if (has_bias) v = E::to_f32(E::from_f32(v)) + bv;
-          yg[(size_t)m * N + n] = E::from_f32(v);
-        }
+        float v = acc[j][i][r] * sc[r];
+        if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[r];
+        out[r] = E::from_f32(v);
       }
+      const int row = i * 16 + (lane & 15);
+      const int chunk = (j * 4 + (lane >> 4)) ^ ((row & 7) << 1);
+      *reinterpret_cast<uint2*>(park + row * 128 + chunk * 8) = *reinterpret_cast<const uint2*>(out);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier needed
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int row = t * 8 + (lane >> 3);
+    const int c16 = lane & 7;  // 16-byte column chunk = 8 output features
+    const uint4 v = *reinterpret_cast<const uint4*>(park + row * 128 + (((c16 * 2) ^ ((row & 7) << 1)) * 8));
+    const int m = m0 + wm * 128 + row;
+    const int n = n0 + wn * 64 + c16 * 8;
+    if (full) {
+      *reinterpret_cast<uint4*>(yg + (size_t)m * N + n) = v;
+    } else if (m < M) {
+      const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (n + r < N) yg[(size_t)m * N + n + r] = e[r];
     }
   }
 }
