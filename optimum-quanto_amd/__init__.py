@@ -10,3 +10,4 @@ from .library import *
 from .tensor import *
 from .nn import *
 from .model_api import *
+from . import parallel  # noqa: E402,F401  (column shard over RCCL / gloo)
