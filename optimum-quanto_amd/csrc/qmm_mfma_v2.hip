@@ -220,78 +220,131 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
   };
   auto as_v8 = [&](const uint32_t(&w)[4]) { return __builtin_bit_cast(V8, make_uint4(w[0], w[1], w[2], w[3])); };
 
+  // Alternating-phase schedule.  Waves 0-3 ("G0", token rows 0..127) and waves 4-7 ("G1") share the four SIMDs
+  // pairwise.  Each wave alternates LOAD phases (LDS-DMA issue, fragment ds_reads, weight conversion - no MFMA) and
+  // COMPUTE phases (16 back-to-back MFMAs with every operand already in registers, s_setprio 1); every phase ends with
+  // a workgroup barrier and G1 runs exactly one phase behind G0, so while one wave of a SIMD computes its partner
+  // loads: the matrix pipe always has a wave with ready operands and the VALU/LDS/DMA work never sits in an MFMA
+  // wave's own instruction stream.  Per K-tile and wave: L0 C0 L1 C1 L2 C2 L3 C3 (blocks S0..S3 = k-half x token-half).
+  //   L0: DMA pieces 0,1 of tile kt+2 | x(kk0,lo) -> xa | convert w0 half 1
+  //   L1: DMA piece 2                 | x(kk0,hi) -> xb | convert w1 half 0 | wait: own share of tile kt+1 landed
+  //   L2: DMA pieces 3,4              | x(kk1,lo) -> xa | convert w1 half 1, then fetch next tile's weight bytes
+  //   L3: DMA piece 5                 | x(kk1,hi) -> xb | convert next tile's w0 half 0
+  // A load phase drains its ds_reads (lgkmcnt(0)) BEFORE its barrier, so "every wave passed the barrier" implies
+  // "every read issued so far has returned": the stage of tile kt-1 can be refilled from L0 of tile kt on, and
+  // tile kt+1 is visible to all from L2 of tile kt on (the vmcnt wait sits at the end of L1).
+  const int grp = wave >> 2;
+  auto issue_piece = [&](int kt, int stage, int piece) {
+    const uint32_t stb = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
+    if (piece < 4)
+      glds16(asrc[piece] + (size_t)kt * (BK * 2), stb + adst[piece]);
+    else
+      glds16(wsrc[piece - 4] + (size_t)kt * BK, stb + wdst[piece - 4]);
+  };
+  auto cvt_half = [&](uint32_t(&w)[4][4], int kk, int half) {
+#pragma unroll
+    for (int q = half * 8; q < half * 8 + 8; ++q) w[q >> 2][q & 3] = convert_pair<DT, FMT>(wword(q >> 2, kk, q & 3), q & 1);
+  };
+  auto end_load_phase = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto end_compute_phase = [&]() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
   issue(0, 0);
   if (nk > 1) issue(1, 1);
-  if (nk > 2) issue(2, 2);
-  if (nk > 2)
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if (nk > 1)
+  if (nk > 1)
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();  // tile 0 visible
   asm volatile("" ::: "memory");
   read_w(smem);
-  read_x(xa, smem, 0, 0);
-#pragma unroll
-  for (int q = 0; q < 16; ++q) w0[q >> 2][q & 3] = convert_pair<DT, FMT>(wword(q >> 2, 0, q & 3), q & 1);
+  cvt_half(w0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (grp == 1) end_compute_phase();  // G1 starts one phase late
 
   int cur = 0;  // stage of tile kt
   for (int kt = 0; kt < nk; ++kt) {
     const uint8_t* st = smem + cur * STAGE_BYTES;
     const int nxt = cur == STAGES - 1 ? 0 : cur + 1;
+    const int nxt2 = nxt == STAGES - 1 ? 0 : nxt + 1;
     const uint8_t* sn = smem + nxt * STAGE_BYTES;
-    const bool more = kt + 1 < nk;
+    const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
 
-    // ---- S0: k-half 0, tokens 0..63 | convert w1 -----------------------------------------------------------
-    read_x(xb, st, 0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      acc[q & 3][q >> 2] = Mma<DT>::run(as_v8(w0[q & 3]), xa[q >> 2], acc[q & 3][q >> 2]);
-      w1[q >> 2][q & 3] = convert_pair<DT, FMT>(wword(q >> 2, 1, q & 3), q & 1);
-      __builtin_amdgcn_sched_barrier(0);
+    // ---- L0 ----
+    if (more2) {
+      issue_piece(kt + 2, nxt2, 0);
+      issue_piece(kt + 2, nxt2, 1);
     }
-    // ---- S1: k-half 0, tokens 64..127 --------------------------------------------------------------------------
-    read_x(xa, st, 1, 0);
+    read_x(xa, st, 0, 0);
+    cvt_half(w0, 0, 1);
+    end_load_phase();
     __builtin_amdgcn_sched_barrier(0);
+    // ---- C0 ----
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q & 3][4 + (q >> 2)] = Mma<DT>::run(as_v8(w0[q & 3]), xb[q >> 2], acc[q & 3][4 + (q >> 2)]);
+    for (int q = 0; q < 16; ++q) acc[q & 3][q >> 2] = Mma<DT>::run(as_v8(w0[q & 3]), xa[q >> 2], acc[q & 3][q >> 2]);
+    __builtin_amdgcn_s_setprio(0);
+    end_compute_phase();
     __builtin_amdgcn_sched_barrier(0);
-    // ---- B1: tile kt+1 visible ------------------------------------------------------------------------------------
+    // ---- L1 ----
+    if (more2) issue_piece(kt + 2, nxt2, 2);
+    read_x(xb, st, 0, 1);
+    cvt_half(w1, 1, 0);
     if (more) {
-      if (kt + 2 < nk)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile kt+1 landed; tile kt+2 may still be in flight
+      if (more2)
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // all of tile kt+1; the 3 pieces of tile kt+2 may be in flight
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
     }
-    // ---- S2: k-half 1, tokens 0..63 | fetch next tile's weight bytes ------------------------------------------------
-    read_x(xb, st, 1, 1);
-    if (more) read_w(sn);
+    end_load_phase();
     __builtin_amdgcn_sched_barrier(0);
+    // ---- C1 ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q & 3][4 + (q >> 2)] = Mma<DT>::run(as_v8(w0[q & 3]), xb[q >> 2], acc[q & 3][4 + (q >> 2)]);
+    __builtin_amdgcn_s_setprio(0);
+    end_compute_phase();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- L2 ----
+    if (more2) {
+      issue_piece(kt + 2, nxt2, 3);
+      issue_piece(kt + 2, nxt2, 4);
+    }
+    read_x(xa, st, 1, 0);
+    cvt_half(w1, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) read_w(sn);  // after the conversions above were issued: they read wraw before these loads overwrite it
+    end_load_phase();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C2 ----
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q & 3][q >> 2] = Mma<DT>::run(as_v8(w1[q & 3]), xa[q >> 2], acc[q & 3][q >> 2]);
+    __builtin_amdgcn_s_setprio(0);
+    end_compute_phase();
     __builtin_amdgcn_sched_barrier(0);
-    // ---- B2: every read of tile kt has returned -> refill its stage ----------------------------------------------
-    if (more) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kt + 3 < nk) issue(kt + 3, cur);
-      read_x(xa, sn, 0, 0);
-    }
+    // ---- L3 ----
+    if (more2) issue_piece(kt + 2, nxt2, 5);
+    read_x(xb, st, 1, 1);
+    cvt_half(w0, 0, 0);  // next tile's k-half-0 operand, first half (garbage but unused on the last tile)
+    end_load_phase();
     __builtin_amdgcn_sched_barrier(0);
-    // ---- S3: k-half 1, tokens 64..127 | convert next tile's w0 ---------------------------------------------------
+    // ---- C3 ----
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      acc[q & 3][4 + (q >> 2)] = Mma<DT>::run(as_v8(w1[q & 3]), xb[q >> 2], acc[q & 3][4 + (q >> 2)]);
-      w0[q >> 2][q & 3] = convert_pair<DT, FMT>(wword(q >> 2, 0, q & 3), q & 1);  // (harmless on the last tile)
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int q = 0; q < 16; ++q) acc[q & 3][4 + (q >> 2)] = Mma<DT>::run(as_v8(w1[q & 3]), xb[q >> 2], acc[q & 3][4 + (q >> 2)]);
+    __builtin_amdgcn_s_setprio(0);
+    end_compute_phase();
+    __builtin_amdgcn_sched_barrier(0);
     cur = nxt;
   }
+  if (grp == 0) end_compute_phase();  // G0 finishes one phase early: same barrier count for every wave
 
   // ---- epilogue: per-channel scale on the fp32 accumulator, optional bias, full-line stores ------------------
   // The stage memory is free once every wave has left the K loop.  Each wave parks its 128x64 result (16 KiB, rows of
