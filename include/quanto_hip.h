@@ -56,12 +56,15 @@ typedef enum {
 typedef enum {
   QUANTO_HIP_KERNEL_AUTO = 0,
   QUANTO_HIP_KERNEL_NAIVE = 1, /* one thread per output element, any shape                      */
-  QUANTO_HIP_KERNEL_GEMV = 2,  /* weight-streaming kernel for M <= QUANTO_HIP_GEMV_MAX_M         */
+  QUANTO_HIP_KERNEL_GEMV = 2,  /* weight-streaming kernel for M <= QUANTO_HIP_GEMV_MAX_M[_QBITS] */
   QUANTO_HIP_KERNEL_MFMA = 3,  /* LDS-tiled MFMA kernel, 128x128 tile (any M)                   */
-  QUANTO_HIP_KERNEL_MFMA_LARGE = 4 /* 256x256 tile, LDS-DMA pipeline (prefill-sized M and N)     */
+  QUANTO_HIP_KERNEL_MFMA_LARGE = 4, /* 256x256 tile, LDS-DMA pipeline (prefill-sized M and N)    */
+  QUANTO_HIP_KERNEL_SKINNY = 5 /* qbits_mm: weight-streaming MFMA kernel for M <= QUANTO_HIP_SKINNY_MAX_M */
 } quanto_hip_kernel;
 
-#define QUANTO_HIP_GEMV_MAX_M 8
+#define QUANTO_HIP_GEMV_MAX_M 8         /* qbytes_mm: rows of x the GEMV kernel accepts                    */
+#define QUANTO_HIP_SKINNY_MAX_M 64       /* qbits_mm: rows of x the streaming MFMA kernel accepts            */
+#define QUANTO_HIP_GEMV_MAX_M_QBITS 64  /* qbits_mm: ditto (passes of up to 8 rows; weights re-read from MALL) */
 
 int quanto_hip_abi_version(void);
 const char* quanto_hip_status_string(int status);

@@ -23,6 +23,10 @@ bool qbytes_mfma_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_mfma(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 bool qbytes_mfma_v2_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_mfma_v2(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
+bool qbits_skinny_supported(int64_t, const PackedGeom&, int);
+size_t qbits_skinny_workspace(int64_t, const PackedGeom&);
+int qbits_mm_skinny(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, void*,
+                    size_t, hipStream_t);
 bool qbits_mfma_supported(int64_t, const PackedGeom&, int);
 size_t qbits_mfma_workspace(int64_t, const PackedGeom&);
 int qbits_mm_mfma(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, void*,
@@ -47,6 +51,17 @@ static int check_qbits(int64_t M, int64_t N, int64_t K, int bits, int group_size
 
 // M above which the weight-streaming GEMV stops being the better choice (it re-reads W once per 4 (int4) / 2 (int8) rows of x)
 static bool prefer_gemv(int64_t M) { return M <= QUANTO_HIP_GEMV_MAX_M; }
+
+// qbits_mm kernel choice.  M <= 8: dot2 GEMV (x in registers, every CU busy even for N = 4096; measured 11 us at M = 8
+// vs 19 us for the streaming MFMA kernel on 4096x4096).  9..64: streaming MFMA
+// kernel (cost per weight byte independent of M); GEMV passes when it does not apply.  Above: LDS-tiled MFMA GEMM.
+static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {
+  if (M <= 8 && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
+  if (qbits_skinny_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_SKINNY;
+  if (qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
+  if (have_workspace && qbits_mfma_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MFMA;
+  return QUANTO_HIP_KERNEL_NAIVE;
+}
 
 // 256x256 tiles pay off once they can fill a good part of the 256 CUs; below that the 128x128 kernel has 4x the blocks
 static bool prefer_large_tile(int64_t M, int64_t N) { return ((M + 255) / 256) * ((N + 255) / 256) >= 96; }
@@ -94,10 +109,10 @@ int64_t quanto_hip_qbits_mm_workspace_size(int64_t M, int64_t N, int64_t K, int 
   const int st = check_qbits(M, N, K, bits, group_size, dtype, dtype, &int_shift);
   if (st != QUANTO_HIP_OK) return st;
   const PackedGeom g = make_geom(N, K, bits, group_size);
-  if (kernel == QUANTO_HIP_KERNEL_NAIVE || kernel == QUANTO_HIP_KERNEL_GEMV) return 0;
-  if (kernel == QUANTO_HIP_KERNEL_AUTO && prefer_gemv(M) && qbits_gemv_supported(M, g, dtype)) return 0;
-  if (!qbits_mfma_supported(M, g, dtype)) return 0;
-  return (int64_t)qbits_mfma_workspace(M, g);
+  if (kernel == QUANTO_HIP_KERNEL_AUTO) kernel = pick_qbits_kernel(M, g, dtype, true);
+  if (kernel == QUANTO_HIP_KERNEL_SKINNY) return qbits_skinny_supported(M, g, dtype) ? (int64_t)qbits_skinny_workspace(M, g) : 0;
+  if (kernel == QUANTO_HIP_KERNEL_MFMA) return qbits_mfma_supported(M, g, dtype) ? (int64_t)qbits_mfma_workspace(M, g) : 0;
+  return 0;
 }
 
 int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t M,
@@ -111,12 +126,9 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const PackedGeom g = make_geom(N, K, bits, group_size);
   if (kernel == QUANTO_HIP_KERNEL_AUTO) {
-    if (prefer_gemv(M) && qbits_gemv_supported(M, g, dtype))
-      kernel = QUANTO_HIP_KERNEL_GEMV;
-    else if (qbits_mfma_supported(M, g, dtype) && workspace != nullptr && workspace_bytes >= qbits_mfma_workspace(M, g))
-      kernel = QUANTO_HIP_KERNEL_MFMA;
-    else
-      kernel = QUANTO_HIP_KERNEL_NAIVE;
+    kernel = pick_qbits_kernel(M, g, dtype, workspace != nullptr);
+    if (kernel == QUANTO_HIP_KERNEL_SKINNY && workspace_bytes < qbits_skinny_workspace(M, g)) kernel = QUANTO_HIP_KERNEL_NAIVE;
+    if (kernel == QUANTO_HIP_KERNEL_MFMA && workspace_bytes < qbits_mfma_workspace(M, g)) kernel = QUANTO_HIP_KERNEL_NAIVE;
   }
   int r;
   switch (kernel) {
@@ -131,6 +143,10 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
     case QUANTO_HIP_KERNEL_MFMA:
       r = qbits_mm_mfma(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, workspace, workspace_bytes, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("mfma");
+      return r;
+    case QUANTO_HIP_KERNEL_SKINNY:
+      r = qbits_mm_skinny(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, workspace, workspace_bytes, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("skinny");
       return r;
   }
   return QUANTO_HIP_EINVAL;

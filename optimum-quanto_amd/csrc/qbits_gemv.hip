@@ -1,4 +1,4 @@
-// qbits_mm for decode shapes (M <= 8): weight-streaming GEMV over the generic PackedTensor layout.
+// qbits_mm for decode shapes (M <= 64, in passes of up to 8 rows of x): weight-streaming GEMV over the generic PackedTensor layout.
 //
 // HBM-bound.  With axis-0 grouping, group size 128 and N even, the packed tensor is simply
 // P[N/2][K] bytes: byte (p, k) holds W[p, k] in its low nibble and W[p + N/2, k] in its high
@@ -252,11 +252,19 @@ static int gemv_launch_iters(const void* x, const uint8_t* packed, const void* s
 #define QH_LAUNCH(IT)                                                                                                        \
   hipLaunchKernelGGL((qbits_gemv_g128_kernel<DT, MT, IT, INT_SHIFT>), dim3(grid), dim3(256), 0, stream, xs, packed, ss, shift, bs, \
                      ys, N, K, wpr)
-  switch (iters) {
-    case 1: QH_LAUNCH(1); break;
-    case 2: QH_LAUNCH(2); break;
-    case 3: QH_LAUNCH(3); break;
-    case 4: QH_LAUNCH(4); break;
+  if constexpr (MT == 8) {
+    switch (iters) {
+      case 1: QH_LAUNCH(1); break;
+      case 2: QH_LAUNCH(2); break;
+      default: return QUANTO_HIP_ENOTSUP;
+    }
+  } else {
+    switch (iters) {
+      case 1: QH_LAUNCH(1); break;
+      case 2: QH_LAUNCH(2); break;
+      case 3: QH_LAUNCH(3); break;
+      case 4: QH_LAUNCH(4); break;
+    }
   }
 #undef QH_LAUNCH
   return launch_status();
@@ -265,14 +273,22 @@ static int gemv_launch_iters(const void* x, const uint8_t* packed, const void* s
 template <int DT, bool INT_SHIFT>
 static int gemv_launch_m(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int M,
                          int N, int K, hipStream_t stream) {
-  // rows of x are processed in passes of at most 4 (register-resident x); weights of later passes come from L2/MALL
+  // Rows of x are processed in passes of at most 8 (x lives in registers: 8 VGPRs per slab and row); the weights of
+  // later passes come from the Infinity Cache (a Linear's packed weight is 8-30 MB).  8 rows per pass need
+  // iters <= 2 slabs per wave (K <= 8192) to stay inside the register file.
+  const int nslab = (K + 1023) / 1024;
+  const int iters = (nslab + (nslab >= 3 ? 4 : nslab) - 1) / (nslab >= 3 ? 4 : nslab);
+  const int mt_max = iters <= 2 ? 8 : 4;
   int m0 = 0;
   while (m0 < M) {
-    const int mt = (M - m0) >= 4 ? 4 : ((M - m0) >= 2 ? 2 : 1);
+    const int left = M - m0;
+    const int mt = (left >= 8 && mt_max >= 8) ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1));
     const void* xp = reinterpret_cast<const uint16_t*>(x) + (size_t)m0 * K;
     void* yp = reinterpret_cast<uint16_t*>(y) + (size_t)m0 * N;
     int st;
-    if (mt == 4)
+    if (mt == 8)
+      st = gemv_launch_iters<DT, 8, INT_SHIFT>(xp, packed, scale, shift, bias, yp, N, K, stream);
+    else if (mt == 4)
       st = gemv_launch_iters<DT, 4, INT_SHIFT>(xp, packed, scale, shift, bias, yp, N, K, stream);
     else if (mt == 2)
       st = gemv_launch_iters<DT, 2, INT_SHIFT>(xp, packed, scale, shift, bias, yp, N, K, stream);
@@ -286,7 +302,7 @@ static int gemv_launch_m(const void* x, const uint8_t* packed, const void* scale
 
 bool qbits_gemv_supported(int64_t M, const PackedGeom& g, int dtype) {
   return g.bits == 4 && g.C == 128 && (g.N % 2 == 0) && (g.K % 128 == 0) && g.K <= 16384 && M >= 1 &&
-         M <= QUANTO_HIP_GEMV_MAX_M && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30);
+         M <= QUANTO_HIP_GEMV_MAX_M_QBITS && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30);
 }
 
 int qbits_mm_gemv(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t M,

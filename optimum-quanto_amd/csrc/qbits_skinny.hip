@@ -1,0 +1,318 @@
+// qbits_mm for small batches (8 < M <= 64, e.g. batched decode): weight-streaming MFMA kernel over the generic
+// PackedTensor layout (int4, group size 128, N even).
+//
+// HBM-bound like the GEMV, but the products run on the matrix cores so the cost per weight byte does not grow with M:
+//   * a block of 4 waves owns 64 output features = 32 packed rows (byte (p,k) = W[p,k] | W[p+N/2,k] << 4) and streams
+//     them over the whole K in tiles of 128 byte-columns (= one quantization group) through a 4..8-stage LDS-DMA pipeline
+//     (`global_load_lds_dwordx4`, counted vmcnt, one s_barrier per tile); the loop contains no other memory instruction,
+//     so nothing ever drains the DMA queue;
+//   * wave w owns packed rows 8w..8w+7.  Its MFMA A operand is 16 FEATURES = those 8 rows x both nibble planes: lane
+//     (i = lane & 15, g = lane >> 4) reads 16 bytes of row i%8 and keeps the low nibbles (i < 8) or the high nibbles
+//     (i >= 8) - lanes i and i+8 read the same LDS address (broadcast).  128+q is built exactly as a bf16/fp16 number
+//     (v_perm + v_and_or), 1 VALU op per weight;
+//   * the activation tile (16*TF tokens x 128 k) is shared by the 4 waves; D[feature][token] accumulates one group in
+//     fp32, then   acc += s[f,g]*acc_g - (z[f,g] + 128 s[f,g]) * XS[token,g],  with XS[token,g] = sum_k x from one extra
+//     MFMA per k-step against an all-ones operand (no pre-kernel, no workspace).  The scales/shifts of the block's 64
+//     features (16-bit) are parked in LDS before the loop (8 KB; 28 KB for K = 14336);
+//   * a lane ends with 4 consecutive output features of one token: 8-byte stores.
+// LDS images are linear per DMA instruction; bank-conflict swizzles are applied to the DMA source address and undone on
+// the fragment reads: weights (128-byte rows, 8 chunks) chunk ^ (row & 7); activations (256-byte rows, 16 chunks)
+// chunk ^ (row & 15).
+#include "qh_common.h"
+
+namespace qh {
+namespace skinny {
+
+constexpr int BK = 128;             // byte-columns (= k) per tile = one group
+constexpr int ROWS = 32;            // packed rows per block (64 output features)
+constexpr int W_BYTES = ROWS * BK;  // 4 KiB
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+template <int DT>
+struct Mma;
+template <>
+struct Mma<QUANTO_HIP_BF16> {
+  using V8 = bf16x8;
+  static __device__ __forceinline__ f32x4 run(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static constexpr uint32_t MAGIC = 0x43004300u;
+  static constexpr float OFFSET = 128.f;
+};
+template <>
+struct Mma<QUANTO_HIP_F16> {
+  using V8 = f16x8;
+  static __device__ __forceinline__ f32x4 run(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static constexpr uint32_t MAGIC = 0x64006400u;
+  static constexpr float OFFSET = 1024.f;
+};
+
+template <int DT>
+__device__ __forceinline__ uint32_t ONE2() { return DT == QUANTO_HIP_BF16 ? 0x3F803F80u : 0x3C003C00u; }  // (1.0, 1.0)
+
+// s_waitcnt vmcnt(n * PER) for n = 0 .. MAXN/PER: the immediate must be a literal, hence the ladder
+template <int MAXN, int PER>
+__device__ __forceinline__ void wait_vmcnt(int younger_tiles) {
+  if constexpr (MAXN > 0) {
+    if (younger_tiles * PER >= MAXN) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXN) : "memory");
+      return;
+    }
+    wait_vmcnt<MAXN - PER, PER>(younger_tiles);
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+struct Args {
+  const void* x;        // [M, K]
+  const uint8_t* w;     // packed [N/2, K]
+  const void* scale;    // [N*G]
+  const void* shift;    // [N*G]
+  const void* bias;     // [N] or null
+  void* y;              // [M, N]
+  int M, N, K, G;
+};
+
+template <int DT, int TF, int STAGES, bool INT_SHIFT>
+__global__ void __launch_bounds__(256) qbits_skinny_kernel(const Args a) {
+  using E = Elem<DT>;
+  using T = typename E::T;
+  using V8 = typename Mma<DT>::V8;
+  constexpr int X_BYTES = TF * 16 * BK * 2;
+  constexpr int STAGE_BYTES = W_BYTES + X_BYTES;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // layout: [STAGES x (W tile | x tile)] [sz: G x 2 x 64 elements of T]
+  T* sz = reinterpret_cast<T*>(smem + STAGES * STAGE_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = a.M, N = a.N, K = a.K, G = a.G;
+  const int P = N >> 1;
+  const int p0 = blockIdx.x * ROWS;
+  const int nk = K / BK;
+
+  // ---- per-lane DMA sources ---------------------------------------------------------------------------
+  // weights: this wave's 8 rows x 128 B = 1 KiB per tile; lane -> row lane>>3, position lane&7 holds chunk pos ^ (row & 7)
+  const uint8_t* wsrc;
+  {
+    const int r = lane >> 3, c = (lane & 7) ^ (r & 7);
+    wsrc = a.w + (size_t)(p0 + wave * 8 + r) * K + c * 16;
+  }
+  // activations: TF KiB-instructions per wave; instruction u covers tile rows 4*(wave*TF+u) .. +3
+  const uint8_t* xsrc[TF];
+#pragma unroll
+  for (int u = 0; u < TF; ++u) {
+    const int row = 4 * (wave * TF + u) + (lane >> 4);
+    const int c = (lane & 15) ^ (row & 15);
+    const int m = row < M ? row : M - 1;
+    xsrc[u] = reinterpret_cast<const uint8_t*>(reinterpret_cast<const T*>(a.x) + (size_t)m * K + c * 8);
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+  auto issue = [&](int kt, int stage) {
+    const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
+    glds16(wsrc + (size_t)kt * BK, st + wave * 1024);
+#pragma unroll
+    for (int u = 0; u < TF; ++u) glds16(xsrc[u] + (size_t)kt * (BK * 2), st + W_BYTES + (wave * TF + u) * 1024);
+  };
+#pragma unroll
+  for (int t = 0; t < STAGES - 2; ++t)
+    if (t < nk) issue(t, t);
+
+  // ---- park scale / (shift + OFFSET*scale) of the block's 64 features and the XS rows in LDS ---------------------
+  // sz[g][0][f] = scale, sz[g][1][f] = shift (zero-points converted to T: small integers are exact),
+  // f = plane*32 + local packed row (0..31); kept in the 16-bit storage type so that K = 14336 (112 groups) fits
+  for (int e = tid; e < 64 * G; e += 256) {
+    const int f = e / G, g = e - f * G;
+    const size_t idx = (size_t)(p0 + (f & 31) + (f >> 5) * P) * G + g;
+    sz[(g * 2 + 0) * 64 + f] = reinterpret_cast<const T*>(a.scale)[idx];
+    if constexpr (INT_SHIFT)
+      sz[(g * 2 + 1) * 64 + f] = E::from_f32((float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[idx]);
+    else
+      sz[(g * 2 + 1) * 64 + f] = reinterpret_cast<const T*>(a.shift)[idx];
+  }
+
+  // ---- fragment read offsets ----------------------------------------------------------------------------------------
+  const int fi = lane & 15, fg = lane >> 4;
+  const int wrow = wave * 8 + (fi & 7);
+  int woff[2];  // 16-byte chunks fg and 4+fg of the lane's row
+#pragma unroll
+  for (int h = 0; h < 2; ++h) woff[h] = wrow * 128 + (((4 * h + fg) ^ (wrow & 7)) << 4);
+  const uint32_t nib_shift = (fi >> 3) * 4;  // high-nibble plane for lanes 8..15 of each 16
+  int xoff[TF][4];
+#pragma unroll
+  for (int tf = 0; tf < TF; ++tf) {
+    const int row = tf * 16 + fi;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xoff[tf][t] = W_BYTES + row * 256 + (((8 * (t >> 1) + 2 * fg + (t & 1)) ^ (row & 15)) << 4);
+  }
+  // this lane's 4 consecutive features inside the block: plane (fg>>1), local packed rows wave*8 + 4*(fg&1) + r
+  const int floc = (fg >> 1) * 32 + wave * 8 + 4 * (fg & 1);
+
+  f32x4 acc[TF];
+#pragma unroll
+  for (int tf = 0; tf < TF; ++tf) acc[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint32_t kmask = 0x000F000Fu, kmagic = Mma<DT>::MAGIC;
+  asm volatile("" : "+s"(kmask));
+  asm volatile("" : "+v"(kmagic));
+
+  // all-ones operand: one extra MFMA per k-step returns sum_k x[token, k] (the XS term of the group fold) in fp32,
+  // without any VALU work or a pre-kernel; the matrix pipe is idle most of the time in this HBM-bound kernel.
+  const V8 ones = __builtin_bit_cast(V8, make_uint4(ONE2<DT>(), ONE2<DT>(), ONE2<DT>(), ONE2<DT>()));
+
+  // One tile = one group: read the wave's weight bytes, 4 k-steps x (TF + TF) MFMAs, fold into acc.
+  auto compute_tile = [&](const uint8_t* st, int kt) {
+    uint4 wr[2];
+    wr[0] = *reinterpret_cast<const uint4*>(st + woff[0]);
+    wr[1] = *reinterpret_cast<const uint4*>(st + woff[1]);
+    f32x4 accg[TF], accx[TF];
+#pragma unroll
+    for (int tf = 0; tf < TF; ++tf) {
+      accg[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accx[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      // k-step t uses bytes 8*(t&1) .. +7 of chunk (t>>1): two dwords -> four operand dwords (natural k order)
+      const uint32_t d0 = (t & 1) ? wr[t >> 1].z : wr[t >> 1].x, d1 = (t & 1) ? wr[t >> 1].w : wr[t >> 1].y;
+      const uint32_t s0 = d0 >> nib_shift, s1 = d1 >> nib_shift;
+      uint32_t op[4];
+      op[0] = (__builtin_amdgcn_perm(0u, s0, 0x0C010C00u) & kmask) | kmagic;  // bytes 0,1
+      op[1] = (__builtin_amdgcn_perm(0u, s0, 0x0C030C02u) & kmask) | kmagic;  // bytes 2,3
+      op[2] = (__builtin_amdgcn_perm(0u, s1, 0x0C010C00u) & kmask) | kmagic;
+      op[3] = (__builtin_amdgcn_perm(0u, s1, 0x0C030C02u) & kmask) | kmagic;
+      const V8 wa = __builtin_bit_cast(V8, make_uint4(op[0], op[1], op[2], op[3]));
+#pragma unroll
+      for (int tf = 0; tf < TF; ++tf) {
+        const V8 xb = *reinterpret_cast<const V8*>(st + xoff[tf][t]);
+        accg[tf] = Mma<DT>::run(wa, xb, accg[tf]);
+        accx[tf] = Mma<DT>::run(ones, xb, accx[tf]);
+      }
+    }
+    // fold the group: acc += s * acc_g - zz * XS
+    T s4t[4], z4t[4];
+    *reinterpret_cast<uint2*>(s4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 0) * 64 + floc);
+    *reinterpret_cast<uint2*>(z4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 1) * 64 + floc);
+    float s4[4], z4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s4[r] = E::to_f32(s4t[r]);
+      const float z = E::to_f32(z4t[r]);
+      z4[r] = INT_SHIFT ? s4[r] * (z + Mma<DT>::OFFSET) : z + Mma<DT>::OFFSET * s4[r];
+    }
+#pragma unroll
+    for (int tf = 0; tf < TF; ++tf) {
+      const float xs = accx[tf][0];  // every row of the ones-product holds sum_k x[token, k] of this group
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[tf][r] += s4[r] * accg[tf][r] - z4[r] * xs;
+    }
+  };
+
+  // Tiles are consumed in PAIRS per barrier: twice the work between synchronisations and two independent MFMA/LDS
+  // chains for the scheduler to interleave.  Ring of STAGES (even) stages; tiles kt.. are in flight up to kt+STAGES-1.
+  int cur = 0;
+  for (int kt = 0; kt < nk; kt += 2) {
+    const bool pair = kt + 1 < nk;
+    // tiles kt (and kt+1) have landed when at most the DMA of the tiles younger than them is outstanding
+    const int last = pair ? kt + 1 : kt;
+    const int younger = nk - 1 - last < STAGES - 4 ? nk - 1 - last : STAGES - 4;
+    wait_vmcnt<(STAGES - 4) * (1 + TF), 1 + TF>(younger);
+    __builtin_amdgcn_s_barrier();  // both tiles visible to all; everybody is done with the previous pair (and the tables are written)
+    asm volatile("" ::: "memory");
+    const int nxt = cur + 1 == STAGES ? 0 : cur + 1;
+    {  // refill the two stages the previous pair occupied
+      const int s0 = cur >= 2 ? cur - 2 : cur + STAGES - 2, s1 = s0 + 1 == STAGES ? 0 : s0 + 1;
+      if (kt + STAGES - 2 < nk) issue(kt + STAGES - 2, s0);
+      if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, s1);
+    }
+    compute_tile(smem + cur * STAGE_BYTES, kt);
+    if (pair) compute_tile(smem + nxt * STAGE_BYTES, kt + 1);
+    cur = nxt + 1 == STAGES ? 0 : nxt + 1;
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------------------------------------
+  T* yg = reinterpret_cast<T*>(a.y);
+  const int n0 = p0 + wave * 8 + 4 * (fg & 1) + (fg >> 1) * P;  // 4 consecutive output features n0..n0+3
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool has_bias = a.bias != nullptr;
+  if (has_bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = E::to_f32(reinterpret_cast<const T*>(a.bias)[n0 + r]);
+  }
+#pragma unroll
+  for (int tf = 0; tf < TF; ++tf) {
+    const int m = tf * 16 + fi;
+    if (m < M) {
+      T out[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[tf][r];
+        if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[r];
+        out[r] = E::from_f32(v);
+      }
+      *reinterpret_cast<uint2*>(yg + (size_t)m * N + n0) = *reinterpret_cast<const uint2*>(out);
+    }
+  }
+}
+
+constexpr int lds_bytes(int tf, int stages, int G) { return stages * (W_BYTES + tf * 16 * BK * 2) + G * 128 * 2; }
+
+template <int DT, int TF, int STAGES, bool INT_SHIFT>
+static int launch_s(const Args& a, hipStream_t stream) {
+  const int lds = lds_bytes(TF, STAGES, a.G);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT>), dim3(a.N / 2 / ROWS), dim3(256), lds, stream, a);
+  return launch_status();
+}
+
+// Deepest DMA pipeline that fits: the kernel is latency-bound per block (bytes in flight = stages x tile bytes)
+template <int DT, int TF, bool INT_SHIFT>
+static int launch(const Args& a, hipStream_t stream) {
+  constexpr int budget = 150 * 1024;
+  if (lds_bytes(TF, 8, a.G) <= budget) return launch_s<DT, TF, 8, INT_SHIFT>(a, stream);
+  if (lds_bytes(TF, 6, a.G) <= budget) return launch_s<DT, TF, 6, INT_SHIFT>(a, stream);
+  return launch_s<DT, TF, 4, INT_SHIFT>(a, stream);
+}
+
+template <int DT, bool INT_SHIFT>
+static int launch_tf(const Args& a, hipStream_t stream) {
+  if (a.M <= 16) return launch<DT, 1, INT_SHIFT>(a, stream);
+  if (a.M <= 32) return launch<DT, 2, INT_SHIFT>(a, stream);
+  return launch<DT, 4, INT_SHIFT>(a, stream);
+}
+
+}  // namespace skinny
+
+bool qbits_skinny_supported(int64_t M, const PackedGeom& g, int dtype) {
+  const int tf = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+  return g.bits == 4 && g.C == 128 && (g.N % 64 == 0) && (g.K % 128 == 0) && M >= 1 && M <= QUANTO_HIP_SKINNY_MAX_M &&
+         (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30) && g.K < (1 << 30) &&
+         skinny::lds_bytes(tf, 4, (int)g.G) <= 160 * 1024;
+}
+
+size_t qbits_skinny_workspace(int64_t, const PackedGeom&) { return 0; }
+
+int qbits_mm_skinny(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t M,
+                    const PackedGeom& g, int dtype, bool int_shift, void*, size_t, hipStream_t stream) {
+  if (!qbits_skinny_supported(M, g, dtype)) return QUANTO_HIP_ENOTSUP;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed)) % 16) return QUANTO_HIP_EALIGN;
+  skinny::Args a{x, packed, scale, shift, bias, y, (int)M, (int)g.N, (int)g.K, (int)g.G};
+  if (dtype == QUANTO_HIP_BF16)
+    return int_shift ? skinny::launch_tf<QUANTO_HIP_BF16, true>(a, stream) : skinny::launch_tf<QUANTO_HIP_BF16, false>(a, stream);
+  return int_shift ? skinny::launch_tf<QUANTO_HIP_F16, true>(a, stream) : skinny::launch_tf<QUANTO_HIP_F16, false>(a, stream);
+}
+
+}  // namespace qh

@@ -317,6 +317,17 @@ __global__ void __launch_bounds__(256) group_sums_kernel(const typename Elem<DT>
   }
 }
 
+int qbits_group_sums(const void* x, float* xs, int M, int K, int C, int Mpad, int dtype, hipStream_t stream) {
+  const dim3 grid((unsigned)((M + 3) / 4));
+  if (dtype == QUANTO_HIP_BF16)
+    hipLaunchKernelGGL(group_sums_kernel<QUANTO_HIP_BF16>, grid, dim3(256), 0, stream, reinterpret_cast<const __bf16*>(x), xs, M, K, C, Mpad);
+  else if (dtype == QUANTO_HIP_F16)
+    hipLaunchKernelGGL(group_sums_kernel<QUANTO_HIP_F16>, grid, dim3(256), 0, stream, reinterpret_cast<const _Float16*>(x), xs, M, K, C, Mpad);
+  else
+    return QUANTO_HIP_ENOTSUP;
+  return launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int DT, int FMT, bool INT_SHIFT>
 static int mma_launch(const MmaArgs& a, hipStream_t stream) {

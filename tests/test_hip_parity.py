@@ -108,7 +108,7 @@ def _exact_qbits(p, bias=None):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
-@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8, 13, 32, 64])
 @pytest.mark.parametrize("N,K", [(256, 1024), (512, 4096), (64, 2048), (384, 3072), (128, 8192), (96, 14336), (256, 128), (34, 11008)])
 def test_qbits_gemv(dt, M, N, K):
     p = make_qbits_problem(M, N, K, dt, seed=M * 7 + N)
@@ -120,6 +120,22 @@ def test_qbits_gemv_zeropoint_and_bias(dt):
     p = make_qbits_problem(3, 256, 1024, dt, zeropoint=True, seed=11)
     bias = O.round_to(np.random.default_rng(1).standard_normal(256).astype(np.float32), dt)
     assert_close_with_bias(_run_qbits(p, "gemv", bias), _exact_qbits(p), bias, dt, "gemv zp+bias")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M", [1, 5, 16, 17, 32, 33, 64])
+@pytest.mark.parametrize("N,K", [(64, 128), (256, 256), (128, 384), (512, 4096), (192, 14336), (1024, 1024)])
+def test_qbits_skinny(dt, M, N, K):
+    """Streaming MFMA kernel: 1..4 token fragments, 1..112 K-tiles (pipeline prologue/epilogue paths), ragged M."""
+    p = make_qbits_problem(M, N, K, dt, seed=M * 3 + N + K)
+    assert_close_to_exact(_run_qbits(p, "skinny"), _exact_qbits(p), dt, f"skinny {M}x{K}x{N}")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_qbits_skinny_zeropoint_and_bias(dt):
+    p = make_qbits_problem(24, 256, 512, dt, zeropoint=True, seed=13)
+    bias = O.round_to(np.random.default_rng(3).standard_normal(256).astype(np.float32), dt)
+    assert_close_with_bias(_run_qbits(p, "skinny", bias), _exact_qbits(p), bias, dt, "skinny zp+bias")
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
@@ -151,7 +167,13 @@ def test_qbits_auto_picks_fast_kernels():
     p = make_qbits_problem(1, 256, 1024, "bf16")
     _run_qbits(p, "auto")
     assert quanto_hip.lib.last_kernel() == "gemv"
-    p = make_qbits_problem(64, 256, 1024, "bf16")
+    p = make_qbits_problem(32, 256, 1024, "bf16")
+    _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "skinny"
+    p = make_qbits_problem(32, 34, 1024, "bf16")  # N not a multiple of 64: GEMV passes
+    _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "gemv"
+    p = make_qbits_problem(65, 256, 1024, "bf16")
     _run_qbits(p, "auto")
     assert quanto_hip.lib.last_kernel() == "mfma"
 

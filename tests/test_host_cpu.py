@@ -47,6 +47,8 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     lib.quanto_hip_qbits_mm_workspace_size.restype = ctypes.c_int64
     lib.quanto_hip_qbits_mm_workspace_size.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 4
     assert lib.quanto_hip_qbits_mm_workspace_size(4096, 4096, 4096, 4, 128, 2, 0) == 32 * 4096 * 4
+    assert lib.quanto_hip_qbits_mm_workspace_size(64, 4096, 4096, 4, 128, 2, 0) == 0  # streaming MFMA kernel needs no scratch
+    assert lib.quanto_hip_qbits_mm_workspace_size(4, 4096, 4096, 4, 128, 2, 0) == 0
     assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 4, 128, 2, 0) == 0  # GEMV needs none
     assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 3, 128, 2, 0) == -1
 
