@@ -86,6 +86,16 @@ __device__ __forceinline__ int swz_a(int row) {
 }
 __device__ __forceinline__ int swz_w(int row) { return (-(row >> 2)) & 3; }
 
+#ifdef QH_PHASE_TIMING
+#define QH_PRIO_UP() do { if (a.variant == 0) __builtin_amdgcn_s_setprio(1); } while (0)
+#define QH_PRIO_DOWN() do { if (a.variant == 0) __builtin_amdgcn_s_setprio(0); } while (0)
+#define QH_STAMP(i) do { if (stamp_on) { asm volatile("s_waitcnt lgkmcnt(0)"); stamps[i] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define QH_PRIO_UP() __builtin_amdgcn_s_setprio(1)
+#define QH_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
+#define QH_STAMP(i) do { } while (0)
+#endif
+
 struct Args {
   const void* x;
   const uint8_t* w;
@@ -93,6 +103,10 @@ struct Args {
   const void* bias;
   void* y;
   int M, N, K;
+#ifdef QH_PHASE_TIMING
+  unsigned long long* dbg;
+  int variant;  // priority experiment: 0 = flip prio around every MFMA phase, 1 = static prio 1 for waves 4-7, 2 = none
+#endif
 };
 
 // One output dword of a converted operand: bytes (2p, 2p+1) of `word` -> two 16-bit elements.  3 VALU ops
@@ -233,7 +247,12 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
   // A load phase drains its ds_reads (lgkmcnt(0)) BEFORE its barrier, so "every wave passed the barrier" implies
   // "every read issued so far has returned": the stage of tile kt-1 can be refilled from L0 of tile kt on, and
   // tile kt+1 is visible to all from L2 of tile kt on (the vmcnt wait sits at the end of L1).
+#ifdef QH_PHASE_TIMING
+  const int grp = a.variant == 3 ? (wave >> 2) ^ 1 : wave >> 2;  // variant 3: the younger waves lead
+  if (a.variant == 1 && grp == 1) __builtin_amdgcn_s_setprio(1);
+#else
   const int grp = wave >> 2;
+#endif
   auto issue_piece = [&](int kt, int stage, int piece) {
     const uint32_t stb = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
     if (piece < 4)
@@ -269,12 +288,21 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
   if (grp == 1) end_compute_phase();  // G1 starts one phase late
 
   int cur = 0;  // stage of tile kt
+#ifdef QH_PHASE_TIMING
+  unsigned long long stamps[17];
+  int stamp_base = 0;
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const uint8_t* st = smem + cur * STAGE_BYTES;
     const int nxt = cur == STAGES - 1 ? 0 : cur + 1;
     const int nxt2 = nxt == STAGES - 1 ? 0 : nxt + 1;
     const uint8_t* sn = smem + nxt * STAGE_BYTES;
     const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
+#ifdef QH_PHASE_TIMING
+    const bool stamp_on = (kt == 20 || kt == 21) && blockIdx.x == 7;
+    stamp_base = (kt - 20) * 17;
+#endif
+    QH_STAMP(0);
 
     // ---- L0 ----
     if (more2) {
@@ -283,14 +311,18 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
     }
     read_x(xa, st, 0, 0);
     cvt_half(w0, 0, 1);
+    QH_STAMP(1);
     end_load_phase();
+    QH_STAMP(2);
     __builtin_amdgcn_sched_barrier(0);
     // ---- C0 ----
-    __builtin_amdgcn_s_setprio(1);
+    QH_PRIO_UP();
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q & 3][q >> 2] = Mma<DT>::run(as_v8(w0[q & 3]), xa[q >> 2], acc[q & 3][q >> 2]);
-    __builtin_amdgcn_s_setprio(0);
+    QH_PRIO_DOWN();
+    QH_STAMP(3);
     end_compute_phase();
+    QH_STAMP(4);
     __builtin_amdgcn_sched_barrier(0);
     // ---- L1 ----
     if (more2) issue_piece(kt + 2, nxt2, 2);
@@ -302,14 +334,18 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    QH_STAMP(5);
     end_load_phase();
+    QH_STAMP(6);
     __builtin_amdgcn_sched_barrier(0);
     // ---- C1 ----
-    __builtin_amdgcn_s_setprio(1);
+    QH_PRIO_UP();
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q & 3][4 + (q >> 2)] = Mma<DT>::run(as_v8(w0[q & 3]), xb[q >> 2], acc[q & 3][4 + (q >> 2)]);
-    __builtin_amdgcn_s_setprio(0);
+    QH_PRIO_DOWN();
+    QH_STAMP(7);
     end_compute_phase();
+    QH_STAMP(8);
     __builtin_amdgcn_sched_barrier(0);
     // ---- L2 ----
     if (more2) {
@@ -320,28 +356,40 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
     cvt_half(w1, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
     if (more) read_w(sn);  // after the conversions above were issued: they read wraw before these loads overwrite it
+    QH_STAMP(9);
     end_load_phase();
+    QH_STAMP(10);
     __builtin_amdgcn_sched_barrier(0);
     // ---- C2 ----
-    __builtin_amdgcn_s_setprio(1);
+    QH_PRIO_UP();
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q & 3][q >> 2] = Mma<DT>::run(as_v8(w1[q & 3]), xa[q >> 2], acc[q & 3][q >> 2]);
-    __builtin_amdgcn_s_setprio(0);
+    QH_PRIO_DOWN();
+    QH_STAMP(11);
     end_compute_phase();
+    QH_STAMP(12);
     __builtin_amdgcn_sched_barrier(0);
     // ---- L3 ----
     if (more2) issue_piece(kt + 2, nxt2, 5);
     read_x(xb, st, 1, 1);
     cvt_half(w0, 0, 0);  // next tile's k-half-0 operand, first half (garbage but unused on the last tile)
+    QH_STAMP(13);
     end_load_phase();
+    QH_STAMP(14);
     __builtin_amdgcn_sched_barrier(0);
     // ---- C3 ----
-    __builtin_amdgcn_s_setprio(1);
+    QH_PRIO_UP();
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q & 3][4 + (q >> 2)] = Mma<DT>::run(as_v8(w1[q & 3]), xb[q >> 2], acc[q & 3][4 + (q >> 2)]);
-    __builtin_amdgcn_s_setprio(0);
+    QH_PRIO_DOWN();
+    QH_STAMP(15);
     end_compute_phase();
+    QH_STAMP(16);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef QH_PHASE_TIMING
+    if (stamp_on && lane == 0) for (int i = 0; i < 17; ++i) a.dbg[wave * 34 + stamp_base + i] = stamps[i];
+    if (stamp_on && lane == 0 && kt == 21) a.dbg[wave * 34 + 33] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+#endif
     cur = nxt;
   }
   if (grp == 0) end_compute_phase();  // G0 finishes one phase early: same barrier count for every wave
