@@ -87,10 +87,12 @@ __device__ __forceinline__ int swz_a(int row) {
 __device__ __forceinline__ int swz_w(int row) { return (-(row >> 2)) & 3; }
 
 #ifdef QH_PHASE_TIMING
+#define QH_VARIANT4 (a.variant == 4)
 #define QH_PRIO_UP() do { if (a.variant == 0) __builtin_amdgcn_s_setprio(1); } while (0)
 #define QH_PRIO_DOWN() do { if (a.variant == 0) __builtin_amdgcn_s_setprio(0); } while (0)
 #define QH_STAMP(i) do { if (stamp_on) { asm volatile("s_waitcnt lgkmcnt(0)"); stamps[i] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
+#define QH_VARIANT4 false
 #define QH_PRIO_UP() __builtin_amdgcn_s_setprio(1)
 #define QH_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
 #define QH_STAMP(i) do { } while (0)
@@ -235,18 +237,12 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
   auto as_v8 = [&](const uint32_t(&w)[4]) { return __builtin_bit_cast(V8, make_uint4(w[0], w[1], w[2], w[3])); };
 
   // Alternating-phase schedule.  Waves 0-3 ("G0", token rows 0..127) and waves 4-7 ("G1") share the four SIMDs
-  // pairwise.  Each wave alternates LOAD phases (LDS-DMA issue, fragment ds_reads, weight conversion - no MFMA) and
-  // COMPUTE phases (16 back-to-back MFMAs with every operand already in registers, s_setprio 1); every phase ends with
-  // a workgroup barrier and G1 runs exactly one phase behind G0, so while one wave of a SIMD computes its partner
-  // loads: the matrix pipe always has a wave with ready operands and the VALU/LDS/DMA work never sits in an MFMA
-  // wave's own instruction stream.  Per K-tile and wave: L0 C0 L1 C1 L2 C2 L3 C3 (blocks S0..S3 = k-half x token-half).
-  //   L0: DMA pieces 0,1 of tile kt+2 | x(kk0,lo) -> xa | convert w0 half 1
-  //   L1: DMA piece 2                 | x(kk0,hi) -> xb | convert w1 half 0 | wait: own share of tile kt+1 landed
-  //   L2: DMA pieces 3,4              | x(kk1,lo) -> xa | convert w1 half 1, then fetch next tile's weight bytes
-  //   L3: DMA piece 5                 | x(kk1,hi) -> xb | convert next tile's w0 half 0
-  // A load phase drains its ds_reads (lgkmcnt(0)) BEFORE its barrier, so "every wave passed the barrier" implies
-  // "every read issued so far has returned": the stage of tile kt-1 can be refilled from L0 of tile kt on, and
-  // tile kt+1 is visible to all from L2 of tile kt on (the vmcnt wait sits at the end of L1).
+  // pairwise (wave w and w+4 sit on the same SIMD).  Each wave alternates LOAD phases (LDS-DMA issue, fragment
+  // ds_reads, weight conversion - no MFMA) and COMPUTE phases (back-to-back MFMAs with every operand already in
+  // registers); every phase ends with a workgroup barrier and G1 runs exactly one phase behind G0, so while one wave
+  // of a SIMD computes its partner loads.  A load phase drains its ds_reads (lgkmcnt(0)) BEFORE its barrier, so "every
+  // wave passed the barrier" implies "every read issued so far has returned": the stage of tile kt-1 can be refilled
+  // from the first load phase of tile kt on, and tile kt+1 is visible to all from the second load phase of tile kt on.
 #ifdef QH_PHASE_TIMING
   const int grp = a.variant == 3 ? (wave >> 2) ^ 1 : wave >> 2;  // variant 3: the younger waves lead
   if (a.variant == 1 && grp == 1) __builtin_amdgcn_s_setprio(1);
@@ -265,11 +261,15 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
     for (int q = half * 8; q < half * 8 + 8; ++q) w[q >> 2][q & 3] = convert_pair<DT, FMT>(wword(q >> 2, kk, q & 3), q & 1);
   };
   auto end_load_phase = [&]() {
+    // Pin the schedule first: hipcc otherwise sinks register-only VALU work (the conversions) below the barrier, into
+    // the head of the compute phase, where it delays the first MFMAs of a wave that should only be issuing MFMAs.
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
   auto end_compute_phase = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -284,9 +284,14 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
   asm volatile("" ::: "memory");
   read_w(smem);
   cvt_half(w0, 0, 0);
+  cvt_half(w0, 0, 1);
   __builtin_amdgcn_sched_barrier(0);
   if (grp == 1) end_compute_phase();  // G1 starts one phase late
 
+  // Four phases per K-tile and wave: La Ca Lb Cb, 32 MFMAs per compute phase (k-half 0, then k-half 1, all 8 token
+  // fragments), G1 one phase behind G0.
+  //   La: DMA pieces 0-2 of tile kt+2 | x(kk0) -> xa,xb | convert w1 (k-half 1 of this tile) | wait: own share of tile kt+1
+  //   Lb: DMA pieces 3-5              | next tile's weight bytes -> wraw, x(kk1) -> xa,xb | convert next tile's w0
   int cur = 0;  // stage of tile kt
 #ifdef QH_PHASE_TIMING
   unsigned long long stamps[17];
@@ -303,88 +308,63 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
     stamp_base = (kt - 20) * 17;
 #endif
     QH_STAMP(0);
-
-    // ---- L0 ----
+    // ---- La ----
     if (more2) {
       issue_piece(kt + 2, nxt2, 0);
       issue_piece(kt + 2, nxt2, 1);
+      issue_piece(kt + 2, nxt2, 2);
     }
     read_x(xa, st, 0, 0);
-    cvt_half(w0, 0, 1);
-    QH_STAMP(1);
-    end_load_phase();
-    QH_STAMP(2);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- C0 ----
-    QH_PRIO_UP();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q & 3][q >> 2] = Mma<DT>::run(as_v8(w0[q & 3]), xa[q >> 2], acc[q & 3][q >> 2]);
-    QH_PRIO_DOWN();
-    QH_STAMP(3);
-    end_compute_phase();
-    QH_STAMP(4);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- L1 ----
-    if (more2) issue_piece(kt + 2, nxt2, 2);
     read_x(xb, st, 0, 1);
     cvt_half(w1, 1, 0);
+    cvt_half(w1, 1, 1);
     if (more) {
       if (more2)
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // all of tile kt+1; the 3 pieces of tile kt+2 may be in flight
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    QH_STAMP(1);
+    end_load_phase();
+    QH_STAMP(2);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- Ca ----
+    QH_PRIO_UP();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q & 3][q >> 2] = Mma<DT>::run(as_v8(w0[q & 3]), xa[q >> 2], acc[q & 3][q >> 2]);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q & 3][4 + (q >> 2)] = Mma<DT>::run(as_v8(w0[q & 3]), xb[q >> 2], acc[q & 3][4 + (q >> 2)]);
+    QH_PRIO_DOWN();
+    QH_STAMP(3);
+    end_compute_phase();
+    QH_STAMP(4);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- Lb ----
+    if (more) read_w(sn);  // w1 of this tile was converted in La: wraw is free
+    if (more2) {
+      issue_piece(kt + 2, nxt2, 3);
+      issue_piece(kt + 2, nxt2, 4);
+      issue_piece(kt + 2, nxt2, 5);
+    }
+    read_x(xa, st, 1, 0);
+    read_x(xb, st, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    cvt_half(w0, 0, 0);  // next tile's k-half-0 operand (garbage but unused on the last tile)
+    cvt_half(w0, 0, 1);
     QH_STAMP(5);
     end_load_phase();
     QH_STAMP(6);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- C1 ----
+    // ---- Cb ----
     QH_PRIO_UP();
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q & 3][4 + (q >> 2)] = Mma<DT>::run(as_v8(w0[q & 3]), xb[q >> 2], acc[q & 3][4 + (q >> 2)]);
+    for (int q = 0; q < 16; ++q) acc[q & 3][q >> 2] = Mma<DT>::run(as_v8(w1[q & 3]), xa[q >> 2], acc[q & 3][q >> 2]);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q & 3][4 + (q >> 2)] = Mma<DT>::run(as_v8(w1[q & 3]), xb[q >> 2], acc[q & 3][4 + (q >> 2)]);
     QH_PRIO_DOWN();
     QH_STAMP(7);
     end_compute_phase();
     QH_STAMP(8);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- L2 ----
-    if (more2) {
-      issue_piece(kt + 2, nxt2, 3);
-      issue_piece(kt + 2, nxt2, 4);
-    }
-    read_x(xa, st, 1, 0);
-    cvt_half(w1, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) read_w(sn);  // after the conversions above were issued: they read wraw before these loads overwrite it
-    QH_STAMP(9);
-    end_load_phase();
-    QH_STAMP(10);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- C2 ----
-    QH_PRIO_UP();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q & 3][q >> 2] = Mma<DT>::run(as_v8(w1[q & 3]), xa[q >> 2], acc[q & 3][q >> 2]);
-    QH_PRIO_DOWN();
-    QH_STAMP(11);
-    end_compute_phase();
-    QH_STAMP(12);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- L3 ----
-    if (more2) issue_piece(kt + 2, nxt2, 5);
-    read_x(xb, st, 1, 1);
-    cvt_half(w0, 0, 0);  // next tile's k-half-0 operand, first half (garbage but unused on the last tile)
-    QH_STAMP(13);
-    end_load_phase();
-    QH_STAMP(14);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- C3 ----
-    QH_PRIO_UP();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q & 3][4 + (q >> 2)] = Mma<DT>::run(as_v8(w1[q & 3]), xb[q >> 2], acc[q & 3][4 + (q >> 2)]);
-    QH_PRIO_DOWN();
-    QH_STAMP(15);
-    end_compute_phase();
-    QH_STAMP(16);
     __builtin_amdgcn_sched_barrier(0);
 #ifdef QH_PHASE_TIMING
     if (stamp_on && lane == 0) for (int i = 0; i < 17; ++i) a.dbg[wave * 34 + stamp_base + i] = stamps[i];
