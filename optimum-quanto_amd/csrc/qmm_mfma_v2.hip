@@ -87,11 +87,13 @@ __device__ __forceinline__ int swz_a(int row) {
 __device__ __forceinline__ int swz_w(int row) { return (-(row >> 2)) & 3; }
 
 #ifdef QH_PHASE_TIMING
+#define QH_STAGGER (a.variant != 2)
 #define QH_VARIANT4 (a.variant == 4)
 #define QH_PRIO_UP() do { if (a.variant == 0) __builtin_amdgcn_s_setprio(1); } while (0)
 #define QH_PRIO_DOWN() do { if (a.variant == 0) __builtin_amdgcn_s_setprio(0); } while (0)
 #define QH_STAMP(i) do { if (stamp_on) { asm volatile("s_waitcnt lgkmcnt(0)"); stamps[i] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
+#define QH_STAGGER true
 #define QH_VARIANT4 false
 #define QH_PRIO_UP() __builtin_amdgcn_s_setprio(1)
 #define QH_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
   cvt_half(w0, 0, 0);
   cvt_half(w0, 0, 1);
   __builtin_amdgcn_sched_barrier(0);
-  if (grp == 1) end_compute_phase();  // G1 starts one phase late
+  if (grp == 1 && QH_STAGGER) end_compute_phase();  // G1 starts one phase late
 
   // Four phases per K-tile and wave: La Ca Lb Cb, 32 MFMAs per compute phase (k-half 0, then k-half 1, all 8 token
   // fragments), G1 one phase behind G0.
@@ -372,7 +374,7 @@ __global__ void __launch_bounds__(512, 1) qbytes_mfma_v2_kernel(const Args a) {
 #endif
     cur = nxt;
   }
-  if (grp == 0) end_compute_phase();  // G0 finishes one phase early: same barrier count for every wave
+  if (grp == 0 && QH_STAGGER) end_compute_phase();  // G0 finishes one phase early: same barrier count for every wave
 
   // ---- epilogue: per-channel scale on the fp32 accumulator, optional bias, full-line stores ------------------
   // The stage memory is free once every wave has left the K loop.  Each wave parks its 128x64 result (16 KiB, rows of
