@@ -59,7 +59,8 @@ typedef enum {
   QUANTO_HIP_KERNEL_GEMV = 2,  /* weight-streaming kernel for M <= QUANTO_HIP_GEMV_MAX_M[_QBITS] */
   QUANTO_HIP_KERNEL_MFMA = 3,  /* LDS-tiled MFMA kernel, 128x128 tile (any M)                   */
   QUANTO_HIP_KERNEL_MFMA_LARGE = 4, /* 256x256 tile, LDS-DMA pipeline (prefill-sized M and N)    */
-  QUANTO_HIP_KERNEL_SKINNY = 5 /* qbits_mm: weight-streaming MFMA kernel for M <= QUANTO_HIP_SKINNY_MAX_M */
+  QUANTO_HIP_KERNEL_SKINNY = 5, /* qbits_mm: weight-streaming MFMA kernel for M <= QUANTO_HIP_SKINNY_MAX_M */
+  QUANTO_HIP_KERNEL_NATIVE8 = 6 /* qbytes_mm with quantized activations: int8 x int8 (i32 MFMA) / fp8 x fp8 (fp8 MFMA) */
 } quanto_hip_kernel;
 
 #define QUANTO_HIP_GEMV_MAX_M 8         /* qbytes_mm: rows of x the GEMV kernel accepts                    */

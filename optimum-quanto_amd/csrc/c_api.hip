@@ -23,6 +23,8 @@ bool qbytes_mfma_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_mfma(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 bool qbytes_mfma_v2_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_mfma_v2(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
+bool qbytes_native8_supported(int64_t, int64_t, int64_t, int, int, int);
+int qbytes_mm_native8(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 bool qbits_skinny_supported(int64_t, const PackedGeom&, int);
 size_t qbits_skinny_workspace(int64_t, const PackedGeom&);
 int qbits_mm_skinny(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, void*,
@@ -162,6 +164,8 @@ int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const
   if (kernel == QUANTO_HIP_KERNEL_AUTO) {
     if (prefer_gemv(M) && qbytes_gemv_supported(M, N, K, a_dtype, b_dtype, out_dtype))
       kernel = QUANTO_HIP_KERNEL_GEMV;
+    else if (qbytes_native8_supported(M, N, K, a_dtype, b_dtype, out_dtype))
+      kernel = QUANTO_HIP_KERNEL_NATIVE8;
     else if (qbytes_mfma_v2_supported(M, N, K, a_dtype, b_dtype, out_dtype) && prefer_large_tile(M, N))
       kernel = QUANTO_HIP_KERNEL_MFMA_LARGE;
     else if (qbytes_mfma_supported(M, N, K, a_dtype, b_dtype, out_dtype))
@@ -186,6 +190,10 @@ int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const
     case QUANTO_HIP_KERNEL_MFMA_LARGE:
       r = qbytes_mm_mfma_v2(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("mfma_large");
+      return r;
+    case QUANTO_HIP_KERNEL_NATIVE8:
+      r = qbytes_mm_native8(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("mfma_native8");
       return r;
   }
   return QUANTO_HIP_EINVAL;

@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(256)
       for (int64_t k = 0; k < K; ++k) acc = __builtin_fmaf(ALoad<ADT>::ld(a, m * K + k), decode8<BDT>(b[n * K + k]), acc);
     }
     float r = acc * E::to_f32(scales[n]);
+    asm volatile("" : "+v"(r));  // keep the fp32 rounding of the product (no fused v_fma_mixlo_f16): reference rounds twice
     if (bias) r = E::to_f32(E::from_f32(r)) + E::to_f32(bias[n]);  // output rounded, then bias added (tensor/weights/qbytes.py:79-81)
     y[i] = E::from_f32(r);
   }

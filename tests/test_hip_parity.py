@@ -259,6 +259,43 @@ def test_qbytes_int8_activations_bit_exact(dt):
     np.testing.assert_array_equal(to_numpy(y), O.qbytes_int_mm_ref(a, b, s, dt))
 
 
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 1024), (300, 700, 256), (1, 17, 192), (33, 64, 4096),
+                                   (1024, 256, 2048)])
+def test_qbytes_int8_int8_mfma_bit_exact(dt, M, N, K):
+    """v_mfma_i32_16x16x64_i8 kernel (quantized activations): exact int32 sums -> bit-identical to library/qbytes_mm.py:36-50,
+    on full and ragged tiles and 1..64 K-tiles, with and without bias."""
+    rng = np.random.default_rng(M + N + K)
+    a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    b = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+    s = O.round_to(((rng.random((N, 1)) + 0.5) / 1e4).astype(np.float32), dt)
+    ta, tb = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)
+    y = quanto_hip.lib.qbytes_mm(ta, tb, to_torch(s, dt, DEV), kernel="mfma_native8")
+    assert quanto_hip.lib.last_kernel() == "mfma_native8"
+    want = O.qbytes_int_mm_ref(a, b, s, dt)
+    np.testing.assert_array_equal(to_numpy(y), want)
+    y = quanto_hip.lib.qbytes_mm(ta, tb, to_torch(s, dt, DEV))  # AUTO picks it as well
+    assert quanto_hip.lib.last_kernel() == "mfma_native8"
+    np.testing.assert_array_equal(to_numpy(y), want)
+    bias = O.round_to(rng.standard_normal(N).astype(np.float32), dt)
+    yb = quanto_hip.lib.qbytes_mm(ta, tb, to_torch(s, dt, DEV), to_torch(bias, dt, DEV), kernel="mfma_native8")
+    np.testing.assert_array_equal(to_numpy(yb), O.round_to(want + bias.reshape(1, -1), dt))
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("kind", ["e4m3fn", "e5m2"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 1024), (300, 700, 256), (1, 17, 192), (64, 128, 4096)])
+def test_qbytes_fp8_fp8_mfma(dt, kind, M, N, K):
+    """Native fp8 x fp8 MFMA: products exact, fp32 accumulate -> within the float tolerance of the float64 oracle."""
+    rng = np.random.default_rng(M + N + K + 7)
+    a = O.fp8_encode(rng.standard_normal((M, K)).astype(np.float32), kind)
+    b = O.fp8_encode(rng.standard_normal((N, K)).astype(np.float32), kind)
+    s = O.round_to(((rng.random((N, 1)) + 0.5) / 1e2).astype(np.float32), dt)
+    y = quanto_hip.lib.qbytes_mm(fp8_tensor(a, kind, DEV), fp8_tensor(b, kind, DEV), to_torch(s, dt, DEV), kernel="mfma_native8")
+    want = np.matmul(O.fp8_decode(a, kind).astype(np.float64), O.fp8_decode(b, kind).astype(np.float64).T) * s.astype(np.float64).reshape(1, -1)
+    assert_close_to_exact(to_numpy(y), want, dt, "fp8 x fp8 native")
+
+
 def test_qbytes_mm_reference_test_grid():
     """The parameter grid of the reference's tests/library/test_mm.py:27-49, same assertion (assert_similar)."""
     g = torch.Generator().manual_seed(0)
