@@ -137,6 +137,21 @@ int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const
                          int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype, int kernel,
                          void* stream);
 
+/*
+ * quanto::quantize_symmetric(Tensor base, ScalarType dtype, int? axis, Tensor scale) -> Tensor
+ *   replaces library/quantize.py:26-55 (div, round, clamp, cast = four elementwise passes) with one pass; it is the
+ *   per-forward step of quantized activations (tensor/activations/qbytes.py:31-39, nn/qmodule.py:281-291).
+ * base: in_dtype[numel] contiguous, in_dtype in {F32, F16, BF16}; scale: in_dtype, laid out per scale_mode:
+ *   QUANTO_HIP_SCALE_PER_TENSOR  one value (axis=None; activations are always per-tensor);
+ *   QUANTO_HIP_SCALE_AXIS_FIRST  numel/inner values, element i uses scale[i / inner]   (axis=0);
+ *   QUANTO_HIP_SCALE_AXIS_LAST   inner values,       element i uses scale[i % inner]   (axis=-1).
+ * out: out_dtype[numel], out_dtype in {I8, F8_E4M3FN, F8_E5M2}.  out = cast(clamp(q)) with q = base / scale rounded
+ *   to in_dtype, and additionally rounded half-to-even to an integer for I8 - bit-identical to the reference sequence.
+ */
+enum quanto_hip_scale_mode { QUANTO_HIP_SCALE_PER_TENSOR = 0, QUANTO_HIP_SCALE_AXIS_FIRST = 1, QUANTO_HIP_SCALE_AXIS_LAST = 2 };
+int quanto_hip_quantize_symmetric(const void* base, const void* scale, void* out, int64_t numel, int64_t inner,
+                                  int scale_mode, int in_dtype, int out_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

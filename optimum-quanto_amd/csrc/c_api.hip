@@ -23,6 +23,7 @@ bool qbytes_mfma_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_mfma(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 bool qbytes_mfma_v2_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_mfma_v2(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
+int quantize_symmetric(const void*, const void*, void*, int64_t, int64_t, int, int, int, hipStream_t);
 bool qbytes_native8_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_native8(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 bool qbits_skinny_supported(int64_t, const PackedGeom&, int);
@@ -197,6 +198,19 @@ int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const
       return r;
   }
   return QUANTO_HIP_EINVAL;
+}
+
+int quanto_hip_quantize_symmetric(const void* base, const void* scale, void* out, int64_t numel, int64_t inner, int scale_mode,
+                                  int in_dtype, int out_dtype, void* stream) {
+  if (numel < 0) return QUANTO_HIP_EINVAL;
+  if (scale_mode != QUANTO_HIP_SCALE_PER_TENSOR && scale_mode != QUANTO_HIP_SCALE_AXIS_FIRST && scale_mode != QUANTO_HIP_SCALE_AXIS_LAST)
+    return QUANTO_HIP_EINVAL;
+  if (scale_mode != QUANTO_HIP_SCALE_PER_TENSOR && (inner <= 0 || numel % inner != 0)) return QUANTO_HIP_EINVAL;
+  if (!is_float_dtype(in_dtype)) return QUANTO_HIP_ENOTSUP;
+  if (out_dtype != QUANTO_HIP_I8 && out_dtype != QUANTO_HIP_F8_E4M3FN && out_dtype != QUANTO_HIP_F8_E5M2) return QUANTO_HIP_ENOTSUP;
+  if (numel == 0) return QUANTO_HIP_OK;
+  if (!base || !scale || !out) return QUANTO_HIP_EINVAL;
+  return quantize_symmetric(base, scale, out, numel, inner, scale_mode, in_dtype, out_dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

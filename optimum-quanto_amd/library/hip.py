@@ -70,6 +70,8 @@ class _Bindings:
         c.quanto_hip_qbits_mm_workspace_size.argtypes = [i64, i64, i64, ci, ci, ci, ci]
         c.quanto_hip_qbytes_mm.restype = ci
         c.quanto_hip_qbytes_mm.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, ci, ci, vp]
+        c.quanto_hip_quantize_symmetric.restype = ci
+        c.quanto_hip_quantize_symmetric.argtypes = [vp, vp, vp, i64, i64, ci, ci, ci, vp]
         self._c = c
         if c.quanto_hip_abi_version() != 1:
             raise QuantoHipError("libquanto_hip.so ABI version mismatch: rebuild with __graft_entry__.build()")
@@ -92,6 +94,29 @@ class _Bindings:
 
     def last_kernel(self) -> str:
         return self._c.quanto_hip_last_kernel().decode()
+
+    # -- quanto::quantize_symmetric -----------------------------------------------------------------
+    QUANTIZE_TARGETS = (torch.int8, torch.float8_e4m3fn, torch.float8_e5m2)
+
+    def quantize_symmetric(self, base: torch.Tensor, dtype: torch.dtype, axis, scale: torch.Tensor) -> torch.Tensor:
+        """One-pass clamp(round(base / scale)).to(dtype); ``axis`` in (None, 0, -1) as validated by the op wrapper."""
+        self._require_cuda(base, scale)
+        if dtype not in self.QUANTIZE_TARGETS or base.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+            raise QuantoHipError(f"quantize_symmetric: unsupported dtypes {base.dtype} -> {dtype}")
+        base = base.contiguous()
+        scale = scale.to(base.dtype).contiguous()
+        out = torch.empty(base.shape, dtype=dtype, device=base.device)
+        if axis is None:
+            mode, inner = 0, 1
+        elif axis == 0:
+            mode, inner = 1, (base.numel() // base.shape[0] if base.numel() else 1)
+        else:
+            mode, inner = 2, base.shape[-1]
+        with torch.cuda.device(base.device):
+            st = self._c.quanto_hip_quantize_symmetric(_ptr(base), _ptr(scale), _ptr(out), base.numel(), inner, mode, _dt(base),
+                                                       _dt(out), self._stream(base))
+        self._check(st, "quantize_symmetric")
+        return out
 
     # -- quanto::unpack ---------------------------------------------------------------------------
     def unpack(self, t: torch.Tensor, bits: int) -> torch.Tensor:
@@ -177,7 +202,7 @@ class QuantoHipExtension(NativeLibrary):
             "quanto_hip",
             root_dir=csrc,
             lib_path=os.path.join(_PKG_DIR, "lib", "libquanto_hip.so"),
-            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qmm_mfma_v2.hip", "qbits_skinny.hip", "qmm_native8.hip",
+            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qmm_mfma_v2.hip", "qbits_skinny.hip", "qmm_native8.hip", "quantize.hip",
                      "qh_common.h", os.path.join("..", "..", "include", "quanto_hip.h")],
         )
         self._bindings = None

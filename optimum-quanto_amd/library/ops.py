@@ -136,30 +136,47 @@ _impl("qbytes_mm", "CUDA", qbytes_mm_hip, _owned)
 # ------------------------------------------------------------------------------------------------
 # quanto::quantize_symmetric / quantize_affine (quantize-time, plain torch on every device)
 # ------------------------------------------------------------------------------------------------
-def quantize_symmetric(base: torch.Tensor, dtype: torch.dtype, axis: Union[int, None], scale: torch.Tensor) -> torch.Tensor:
-    """clamp(round(base / scale)) to ``dtype`` (library/quantize.py:26-55; float8 targets are not rounded first)."""
+def _check_symmetric_args(base: torch.Tensor, axis: Union[int, None], scale: torch.Tensor) -> Union[int, None]:
+    """Argument contract of library/quantize.py:26-49; returns the normalised axis (None, 0 or -1)."""
     if axis is None:
         if scale.ndim > 0:
             raise ValueError("Scale must be a scalar when quantizing per-tensor")
-    else:
-        if base.ndim == 1:
-            raise ValueError("1D Tensors cannot be quantized per-axis")
-        if axis == base.ndim - 1:
-            axis = -1
-        if axis not in (0, -1):
-            raise ValueError("Quantization is only supported along the first or last axis.")
-        if base.shape[axis] == 1:
-            raise ValueError(f"Cannot quantize Tensor of shape {base.shape} along axis {axis} of size 1")
-        if torch.squeeze(scale).ndim > 1:
-            raise ValueError("Quantizing along multiple axis is not supported")
-        if scale.ndim != base.ndim:
-            raise ValueError(
-                "When quantizing per-axis, the scale must be broadcastable to the base (Tip: try to add missing dims of length zero).")
+        return None
+    if base.ndim == 1:
+        raise ValueError("1D Tensors cannot be quantized per-axis")
+    if axis == base.ndim - 1:
+        axis = -1
+    if axis not in (0, -1):
+        raise ValueError("Quantization is only supported along the first or last axis.")
+    if base.shape[axis] == 1:
+        raise ValueError(f"Cannot quantize Tensor of shape {base.shape} along axis {axis} of size 1")
+    if torch.squeeze(scale).ndim > 1:
+        raise ValueError("Quantizing along multiple axis is not supported")
+    if scale.ndim != base.ndim:
+        raise ValueError(
+            "When quantizing per-axis, the scale must be broadcastable to the base (Tip: try to add missing dims of length zero).")
+    return axis
+
+
+def quantize_symmetric(base: torch.Tensor, dtype: torch.dtype, axis: Union[int, None], scale: torch.Tensor) -> torch.Tensor:
+    """clamp(round(base / scale)) to ``dtype`` (library/quantize.py:26-55; float8 targets are not rounded first)."""
+    _check_symmetric_args(base, axis, scale)
     data = base / scale
     if not dtype.is_floating_point:
         data = torch.round(data)
     info = dtype_info(dtype)
     return torch.clamp(data, min=info.min, max=info.max).to(dtype)
+
+
+def quantize_symmetric_hip(base: torch.Tensor, dtype: torch.dtype, axis: Union[int, None], scale: torch.Tensor) -> torch.Tensor:
+    """Device tensors: the one-pass kernel (csrc/quantize.hip) for int8 / OCP float8 targets; the formats the hardware
+    converters do not produce (e4m3fnuz) and non-float bases keep the elementwise torch sequence - still on the device."""
+    axis = _check_symmetric_args(base, axis, scale)
+    lib = quanto_hip.lib
+    if dtype in lib.QUANTIZE_TARGETS and base.dtype in (torch.float32, torch.float16, torch.bfloat16) and (
+            axis is None or scale.numel() == base.shape[axis]):
+        return lib.quantize_symmetric(base, dtype, axis, scale)
+    return quantize_symmetric(base, dtype, axis, scale)
 
 
 def quantize_affine(base: torch.Tensor, bits: int, axis: int, group_size: Union[int, None], scale: torch.Tensor,
@@ -178,6 +195,9 @@ def quantize_affine(base: torch.Tensor, bits: int, axis: int, group_size: Union[
 
 if _define("quantize_symmetric", "(Tensor base, ScalarType dtype, int? axis, Tensor scale) -> Tensor"):
     _impl("quantize_symmetric", "CompositeExplicitAutograd", quantize_symmetric, True)
+    _impl("quantize_symmetric", "CUDA", quantize_symmetric_hip, True)
+else:
+    _impl("quantize_symmetric", "CUDA", quantize_symmetric_hip, False)
 if _define("quantize_affine", "(Tensor base, int bits, int axis, int? group_size, Tensor scale, Tensor shift) -> Tensor"):
     _impl("quantize_affine", "CompositeExplicitAutograd", quantize_affine, True)
 

@@ -1,4 +1,4 @@
-"""Quantized module mixin (API of optimum/quanto/nn/qmodule.py:38-308) for the weight-only QLinear path.
+"""Quantized module mixin (API of optimum/quanto/nn/qmodule.py:38-308) for the QLinear path.
 
 ``QModuleMixin`` keeps the float weight until ``freeze()`` replaces it by a ``WeightQBytesTensor`` /
 ``WeightQBitsTensor`` parameter; ``qweight`` quantizes dynamically while unfrozen so gradients reach the float
@@ -10,8 +10,8 @@ from typing import Optional, Union
 
 import torch
 
-from ..tensor import (AbsmaxOptimizer, MaxOptimizer, Optimizer, QTensor, SymmetricOptimizer, WeightQBitsTensor,
-                      WeightQBytesTensor, qint2, qint4, qtype, qtypes, quantize_weight)
+from ..tensor import (AbsmaxOptimizer, ActivationQBytesTensor, MaxOptimizer, Optimizer, QTensor, SymmetricOptimizer,
+                      WeightQBitsTensor, WeightQBytesTensor, qint2, qint4, qtype, qtypes, quantize_activation, quantize_weight)
 
 __all__ = ["QModuleMixin", "register_qmodule", "quantize_module"]
 
@@ -60,10 +60,6 @@ class QModuleMixin(ABC):
             raise TypeError("QModuleMixin must be placed before any torch.nn.Module class in quantized module inheritance.")
         super().__init__(*args, device=device, **kwargs)
         weights, activations = _as_qtype(weights), _as_qtype(activations)
-        if activations is not None:
-            raise NotImplementedError(
-                "optimum-quanto_amd: quantized activations are not part of the weight-only QLinear hot path yet "
-                "(SURVEY.md section 8f, rank 1)")
         self.weight_qtype = weights
         self.weight_group_size = None
         if weights in (qint2, qint4):
@@ -71,6 +67,12 @@ class QModuleMixin(ABC):
             self.weight_group_size = select_group_size(self.weight.numel() // out_features)
         self.activation_qtype = activations
         self._quantize_hooks = {}
+        if activations is not None:
+            # inputs are quantized with `input_scale` before forward, outputs with `output_scale` after it
+            # (qmodule.py:131-134); both scales come from a Calibration pass
+            if quantize_input:
+                self._quantize_hooks["input"] = self.register_forward_pre_hook(self.quantize_input)
+            self._quantize_hooks["output"] = self.register_forward_hook(self.quantize_output)
         if optimizer is None and weights is not None:
             optimizer = AbsmaxOptimizer() if weights.bits == 8 else MaxOptimizer()
         self.optimizer = optimizer
@@ -153,6 +155,19 @@ class QModuleMixin(ABC):
 
     def qforward(self, input: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
+
+    # -- quantized activations (qmodule.py:281-299) -----------------------------------------------------
+    def quantize_input(self, module: torch.nn.Module, input: torch.Tensor) -> torch.Tensor:
+        input = input[0]
+        if isinstance(input, ActivationQBytesTensor):
+            if input.qtype != self.activation_qtype:
+                raise ValueError("Models with heterogeneous quantized activations are not supported:"
+                                 f" expected {self.activation_qtype.name} input but got {input.qtype.name} instead.")
+            return input
+        return quantize_activation(input, qtype=self.activation_qtype, scale=self.input_scale)
+
+    def quantize_output(self, module: torch.nn.Module, input: torch.Tensor, output: torch.Tensor) -> torch.Tensor:
+        return quantize_activation(output, qtype=self.activation_qtype, scale=self.output_scale)
 
     def freeze(self):
         qweight = self.qweight

@@ -5,3 +5,4 @@ from .linear_function import *
 from .packing import *
 from .scale_search import *
 from .weights import *
+from .activations import *

