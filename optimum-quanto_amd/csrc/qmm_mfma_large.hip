@@ -1,0 +1,407 @@
+// qbytes_mm MFMA GEMM, v3: 256x256x64 tile, FOUR waves, each owning a 128x128 output block (256 accumulator registers).
+//
+// y[M,N] = (x[M,K] @ q[N,K]^T) * scale[N]   with x bf16/fp16 and q int8 / fp8 (1 byte per weight).
+//
+// Why four big waves instead of v2's eight 128x64 waves: the LDS read traffic of a K-tile is set by the per-wave block
+// shape, (rows_m + rows_n) * BK bytes per wave.  v2 moves 8 x 20 KiB = 160 KiB of fragments (+48 KiB of DMA writes)
+// through the 128 B/clk LDS per K-tile - 1664 cycles next to 2048 cycles of MFMA work per SIMD, i.e. the LDS is as
+// busy as the matrix pipe and every imperfect overlap shows (measured 40% of the MFMA peak).  128x128 blocks read
+// 4 x 24 KiB = 96 KiB: 1150 cycles including the DMA writes, 56% of the MFMA time.
+//
+// One wave per SIMD means no partner wave hides anything: the K loop is a single software-pipelined instruction stream
+// in which every MFMA (16 cycles of matrix pipe, one 4-cycle issue slot) is followed by at most three other
+// instructions.  Per K-tile and wave: 128 MFMA + 192 VALU (weight conversion) + 24 ds_read_b128 + 12 LDS-DMA issues.
+//   step s = (kk, i), 16 per K-tile: 8 MFMAs acc[j][i] += W_kk[j] * x(i, kk), j = 0..7
+//     phase kk=0 converts the k-half-1 operand of THIS tile (W1[i]) in the MFMA issue gaps,
+//     phase kk=1 converts the k-half-0 operand of the NEXT tile (W0[i]); the raw 16-byte weight fragments of the next
+//     tile are fetched from LDS as soon as their register is dead; activation fragments stream two steps ahead.
+//   ONE workgroup barrier per K-tile (at the tile boundary): before it every wave waits for its own DMA share of tile
+//   kt+1 (issued a full tile earlier); after it the stage of tile kt-1 is refilled with tile kt+2.
+// LDS image, swizzles, XCD-aware tile order and the D[n][m] accumulator orientation are v2's (qmm_mfma_v2.hip).
+#include <cstdlib>
+#include <type_traits>
+
+#include "qh_common.h"
+
+#ifndef QH_V3_ABLATE
+#define QH_V3_ABLATE 0  // timing experiments only (wrong results): 1 no conversion, 2 no fragment reads, 4 no DMA, 8 no barrier,
+                        // 16 no output stores, 32 no epilogue at all
+#endif
+
+namespace qh {
+namespace lt {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int A_BYTES = BM * BK * 2;  // 32 KiB
+constexpr int W_BYTES = BN * BK;      // 16 KiB
+constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+constexpr int STAGES = 3;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// LDS-DMA, 16 bytes per lane, wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset (see v2 for why asm).
+// M0 is written and not restored: on gfx9+ the compiler only needs M0 for constructs this kernel does not contain
+// (movrel, GWS, sendmsg, its own LDS-DMA builtins), and two SALU instructions per piece matter in a one-wave-per-SIMD
+// instruction stream where every issue slot next to an MFMA is accounted for.
+__device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+
+template <int DT>
+struct Mma;
+template <>
+struct Mma<QUANTO_HIP_BF16> {
+  using V8 = bf16x8;
+  static __device__ __forceinline__ f32x4 run(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) {
+    bf16x2 r;
+    r.x = (__bf16)a;
+    r.y = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, r);
+  }
+};
+template <>
+struct Mma<QUANTO_HIP_F16> {
+  using V8 = f16x8;
+  static __device__ __forceinline__ f32x4 run(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));  // exact for int8 / fp8 values
+  }
+};
+
+enum { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2 };
+
+__device__ __forceinline__ int swz_a(int row) {
+  const int q = (row + 4) & 15;
+  return ((((q >> 3) ^ 1) << 2) | ((q >> 1) & 3));
+}
+__device__ __forceinline__ int swz_w(int row) { return (-(row >> 2)) & 3; }
+
+// bytes (2p, 2p+1) of `word` -> two 16-bit elements: 3 VALU ops
+template <int DT, int FMT>
+__device__ __forceinline__ uint32_t convert_pair(uint32_t word, int p) {
+  float f0, f1;
+  if constexpr (FMT == W_I8) {
+    f0 = p == 0 ? (float)(int8_t)(word & 0xFFu) : (float)(int8_t)((word >> 16) & 0xFFu);
+    f1 = p == 0 ? (float)(int8_t)((word >> 8) & 0xFFu) : (float)(int8_t)(word >> 24);
+  } else if constexpr (FMT == W_F8E4M3) {
+    const f32x2 v = p == 0 ? __builtin_amdgcn_cvt_pk_f32_fp8((int)word, false) : __builtin_amdgcn_cvt_pk_f32_fp8((int)word, true);
+    f0 = v.x;
+    f1 = v.y;
+  } else {
+    const f32x2 v = p == 0 ? __builtin_amdgcn_cvt_pk_f32_bf8((int)word, false) : __builtin_amdgcn_cvt_pk_f32_bf8((int)word, true);
+    f0 = v.x;
+    f1 = v.y;
+  }
+  return Mma<DT>::pack(f0, f1);
+}
+
+#ifdef QH_V3_STAMPS
+__device__ unsigned long long g_stamps[256 * 8];  // per workgroup: s_memrealtime (100 MHz) at entry / loop start / loop end / exit
+#define QH_V3_STAMP(i) do { if (threadIdx.x == 0) g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define QH_V3_STAMP(i) do { } while (0)
+#endif
+
+struct Args {
+  const void* x;
+  const uint8_t* w;
+  const void* scale;
+  const void* bias;
+  void* y;
+  int M, N, K;
+};
+
+// WN = waves along the feature dimension: 2 -> four waves of 128x128 (one per SIMD), 4 -> eight waves of 128x64 (two per SIMD)
+template <int DT, int FMT, int WN>
+__global__ void __launch_bounds__(128 * WN, 1) qbytes_mfma_large_kernel(const Args a) {
+  constexpr int NWAVES = 2 * WN;
+  constexpr int NJ = 16 / WN;          // 16-feature fragments per wave (8 or 4)
+  constexpr int APIECES = 32 / NWAVES;  // activation DMA pieces per wave and K-tile (8 or 4)
+  constexpr int WPIECES = 16 / NWAVES;  // weight DMA pieces per wave and K-tile (4 or 2)
+  constexpr int NPIECES = APIECES + WPIECES;
+  constexpr int ND = NJ / 2;           // converted dwords per step (one phase converts NJ*4 dwords in 8 steps)
+  using E = Elem<DT>;
+  using T = typename E::T;
+  using V8 = typename Mma<DT>::V8;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+  QH_V3_STAMP(0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int M = a.M, N = a.N, K = a.K;
+  const int nk = K / BK;
+
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int nwg = tiles_n * tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- DMA: per K-tile 32 activation pieces (8 rows x 128 B) + 16 weight pieces (16 rows x 64 B) of 1 KiB; 8 + 4 per wave
+  uint32_t asrc[APIECES], wsrc[WPIECES];
+#pragma unroll
+  for (int j = 0; j < APIECES; ++j) {
+    const int R = (j * NWAVES + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz_a(R);
+    int m = m0 + R;
+    m = m < M ? m : M - 1;
+    asrc[j] = (uint32_t)(((size_t)m * K + c * 8) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < WPIECES; ++j) {
+    const int R = (j * NWAVES + wave) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ swz_w(R);
+    int n = n0 + R;
+    n = n < N ? n : N - 1;
+    wsrc[j] = (uint32_t)((size_t)n * K + c * 16);
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+  const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.x);
+  auto issue_piece = [&](int kt, int stage, int piece) {
+    const uint32_t stb = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
+    if (piece < APIECES)
+      glds16(xbase + (size_t)kt * (BK * 2), asrc[piece], stb + (piece * NWAVES + wave) * 1024);
+    else
+      glds16(a.w + (size_t)kt * BK, wsrc[piece - APIECES], stb + A_BYTES + ((piece - APIECES) * NWAVES + wave) * 1024);
+  };
+
+  // ---- fragment read offsets: fragment i / j only adds a compile-time multiple of 2048 / 1024 bytes ----------------
+  const int ra = wm * 128 + (lane & 15), rw = wn * (NJ * 16) + (lane & 15);
+  int aoff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) aoff[kk] = ra * 128 + ((((lane >> 4) * 2 + kk) ^ swz_a(ra)) << 4);
+  const int boff = A_BYTES + rw * 64 + (((lane >> 4) ^ swz_w(rw)) << 4);
+
+  f32x4 acc[NJ][8];  // acc[j][i]: features j*16.., tokens i*16..
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 raw[NJ];         // 16 weight bytes per fragment: k-half 0 in .xy, k-half 1 in .zw
+  uint32_t w0[NJ][4], w1[NJ][4];
+  V8 xf[4];              // activation fragments, two steps ahead (ring of 4: 16 steps per tile keep the ring aligned)
+  auto as_v8 = [&](const uint32_t(&w)[4]) { return __builtin_bit_cast(V8, make_uint4(w[0], w[1], w[2], w[3])); };
+  auto rawword = [&](int j, int kk, int d) -> uint32_t {
+    const uint32_t lo = kk == 0 ? raw[j].x : raw[j].z, hi = kk == 0 ? raw[j].y : raw[j].w;
+    return d < 2 ? lo : hi;
+  };
+  auto read_x = [&](const uint8_t* st, int i, int kk) -> V8 { return *reinterpret_cast<const V8*>(st + aoff[kk] + i * 2048); };
+  auto read_raw = [&](const uint8_t* st, int j) -> uint4 { return *reinterpret_cast<const uint4*>(st + boff + j * 1024); };
+
+  // ---- prologue: tiles 0 and 1 in flight, tile 0 visible, W0(0) converted, x(0..1, kk0) of tile 0 in registers -----------
+#pragma unroll
+  for (int p = 0; p < NPIECES; ++p) issue_piece(0, 0, p);
+  if (nk > 1) {
+#pragma unroll
+    for (int p = 0; p < NPIECES; ++p) issue_piece(1, 1, p);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile 1 too: its weight bytes are fetched during tile 0
+  QH_V3_STAMP(1);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  QH_V3_STAMP(2);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) raw[j] = read_raw(smem, j);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) w0[j][d] = convert_pair<DT, FMT>(rawword(j, 0, d), d & 1);
+  xf[0] = read_x(smem, 0, 0);
+  xf[1] = read_x(smem, 1, 0);
+
+  // One K-tile.  The source order below IS the schedule: a sched_barrier after every MFMA group keeps hipcc from
+  // clustering the conversions (it otherwise hoists ~50 VALU ops in front of the first MFMA of a tile, which leaves the
+  // matrix pipe idle for their whole issue time).
+  int cur = 0;
+  auto tile = [&](int kt, auto dma_tag, auto barrier_tag) {
+    constexpr bool DMA = decltype(dma_tag)::value, BARRIER = decltype(barrier_tag)::value;
+    const uint8_t* st = smem + cur * STAGE_BYTES;
+    const int nxt = cur == STAGES - 1 ? 0 : cur + 1;
+    const int nxt2 = nxt == STAGES - 1 ? 0 : nxt + 1;
+    const uint8_t* sn = smem + nxt * STAGE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int kk = s >> 3, i = s & 7;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (kk == 0)
+          acc[j][i] = Mma<DT>::run(as_v8(w0[j]), xf[s & 3], acc[j][i]);
+        else
+          acc[j][i] = Mma<DT>::run(as_v8(w1[j]), xf[s & 3], acc[j][i]);
+        if (j < ND) {
+          // conversion: step i of a phase produces dwords i*ND .. i*ND+ND-1 of the phase's NJ*4 (fragment-major)
+          const int c = i * ND + j, f = c >> 2, d = c & 3;
+#if QH_V3_ABLATE & 1
+          if (kk == 0) w1[f][d] = rawword(f, 1, d); else w0[f][d] = rawword(f, 0, d);
+#else
+          if (kk == 0)
+            w1[f][d] = convert_pair<DT, FMT>(rawword(f, 1, d), d & 1);  // this tile's k-half 1
+          else
+            w0[f][d] = convert_pair<DT, FMT>(rawword(f, 0, d), d & 1);  // next tile's k-half 0 (raw[f] already holds tile kt+1)
+#endif
+        } else if (j == ND) {
+          // activation fragment of step s+2 (the first two of the next tile at the end; garbage, unused, on the last tile)
+#if !(QH_V3_ABLATE & 2)
+          xf[(s + 2) & 3] = s + 2 < 16 ? read_x(st, (s + 2) & 7, (s + 2) >> 3) : read_x(sn, (s + 2) & 7, 0);
+#endif
+        } else if (j == ND + 1) {
+          // next tile's raw weight bytes: fragment f is dead once its k-half 1 is converted, i.e. after phase-0 step
+          // (f+1)*(8/NJ) - 1; it is reloaded in the step after that (the last one at the first step of phase 1)
+          constexpr int SPF = 8 / NJ;  // steps per fragment (1 or 2)
+#if !(QH_V3_ABLATE & 2)
+          if (s >= SPF && s <= 8 && s % SPF == 0) raw[s / SPF - 1] = read_raw(sn, s / SPF - 1);
+#endif
+        }
+        if (DMA && !(QH_V3_ABLATE & 4) && j >= NJ - NPIECES / 6 && s < 6) issue_piece(kt + 2, nxt2, (NPIECES / 6) * s + (j - (NJ - NPIECES / 6)));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (BARRIER && !(QH_V3_ABLATE & 8)) {
+      // tile boundary: own DMA share of tile kt+1 landed (issued one tile ago) -> barrier -> everybody's share visible and
+      // every wave done with tile kt, whose stage the next tile refills
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    cur = nxt;
+  };
+  using yes = std::integral_constant<bool, true>;
+  using no = std::integral_constant<bool, false>;
+  QH_V3_STAMP(3);
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) tile(kt, yes{}, yes{});
+  tile(kt, no{}, yes{});  // nk >= 2: tiles nk-2 and nk-1 have nothing left to prefetch
+  tile(kt + 1, no{}, no{});
+  QH_V3_STAMP(4);
+
+  // ---- epilogue: scale (+bias) on the fp32 accumulator; each wave parks 128 tokens x 64 features (16 KiB) twice ----------
+  T* yg = reinterpret_cast<T*>(a.y);
+#if QH_V3_ABLATE & 32
+  {
+    float sum = 0.f;
+    for (int j = 0; j < NJ; ++j)
+      for (int i = 0; i < 8; ++i) sum += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+    if (sum == 1.2345f) yg[0] = E::from_f32(sum);
+    return;
+  }
+#endif
+  const bool has_bias = a.bias != nullptr;
+  const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (N % 8 == 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  uint8_t* park = smem + wave * (128 * 128);
+#pragma unroll
+  for (int p = 0; p < NJ / 4; ++p) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = p * 4 + jj;
+      const int nb = n0 + wn * (NJ * 16) + j * 16 + (lane >> 4) * 4;
+      float sc[4], bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nb + r < N ? nb + r : N - 1;
+        sc[r] = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
+        bv[r] = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        T out[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[j][i][r] * sc[r];
+          if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[r];
+          out[r] = E::from_f32(v);
+        }
+        const int row = i * 16 + (lane & 15);
+        const int chunk = (jj * 4 + (lane >> 4)) ^ ((row & 7) << 1);
+        *reinterpret_cast<uint2*>(park + row * 128 + chunk * 8) = *reinterpret_cast<const uint2*>(out);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier needed
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int row = t * 8 + (lane >> 3);
+      const int c16 = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(park + row * 128 + (((c16 * 2) ^ ((row & 7) << 1)) * 8));
+      const int m = m0 + wm * 128 + row;
+      const int n = n0 + wn * (NJ * 16) + p * 64 + c16 * 8;
+#if QH_V3_ABLATE & 16
+      if (v.x == 0x12345678u) *reinterpret_cast<uint4*>(yg + (size_t)m * N + n) = v;
+      else
+#endif
+      if (full) {
+        *reinterpret_cast<uint4*>(yg + (size_t)m * N + n) = v;
+      } else if (m < M) {
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (n + r < N) yg[(size_t)m * N + n + r] = e[r];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  QH_V3_STAMP(5);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  QH_V3_STAMP(6);
+}
+
+int g_wn = 4;  // wave layout picked at run time (QUANTO_HIP_LARGE_WN=2 selects four 128x128 waves; experiments)
+
+template <int DT, int FMT>
+static int launch(const Args& a, hipStream_t stream) {
+  constexpr int lds = STAGES * STAGE_BYTES;
+  const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
+  if (g_wn == 2) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_mfma_large_kernel<DT, FMT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((qbytes_mfma_large_kernel<DT, FMT, 2>), dim3(tiles), dim3(256), lds, stream, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_mfma_large_kernel<DT, FMT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((qbytes_mfma_large_kernel<DT, FMT, 4>), dim3(tiles), dim3(512), lds, stream, a);
+  }
+  return launch_status();
+}
+
+}  // namespace lt
+
+bool qbytes_mfma_v2_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
+  const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2;
+  return bd && a_dtype == out_dtype && (out_dtype == QUANTO_HIP_BF16 || out_dtype == QUANTO_HIP_F16) && K % lt::BK == 0 &&
+         K >= 2 * lt::BK && M >= 1 && M * K < (1ll << 30) && N * K < (1ll << 31) && M < (1 << 30) && N < (1 << 30);
+}
+
+int qbytes_mm_mfma_v2(const void* x, const void* w, const void* s, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int a_dtype,
+                      int b_dtype, int out_dtype, hipStream_t stream) {
+  if (!qbytes_mfma_v2_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
+  {
+    static const int wn_env = [] { const char* e = getenv("QUANTO_HIP_LARGE_WN"); return e && e[0] == '2' ? 2 : 4; }();
+    lt::g_wn = wn_env;
+  }
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
+  lt::Args a{x, reinterpret_cast<const uint8_t*>(w), s, bias, y, (int)M, (int)N, (int)K};
+#define QH_CASE(DT, FMT) return lt::launch<DT, FMT>(a, stream)
+  if (out_dtype == QUANTO_HIP_BF16) {
+    if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_BF16, lt::W_I8);
+    if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_BF16, lt::W_F8E4M3);
+    QH_CASE(QUANTO_HIP_BF16, lt::W_F8E5M2);
+  }
+  if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_F16, lt::W_I8);
+  if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_F16, lt::W_F8E4M3);
+  QH_CASE(QUANTO_HIP_F16, lt::W_F8E5M2);
+#undef QH_CASE
+}
+
+}  // namespace qh

@@ -6,11 +6,15 @@
 //                rounding to the output dtype -> bit-identical to the reference's _int_mm path;
 //   fp8  x fp8 : every product of two e4m3/e5m2 values is exact in fp32; fp32 accumulation.
 //
-// Same skeleton as qmm_mfma_v2.hip (256x256 tile, 8 waves as 2x4, LDS-DMA with counted vmcnt, swizzled 64-byte rows,
+// Same LDS image as qmm_mfma_large.hip (256x256 tile, 8 waves as 2x4, LDS-DMA with counted vmcnt, swizzled 64-byte rows,
 // alternating load / compute phases with waves 4-7 one phase behind waves 0-3, LDS-transposed full-line epilogue), but a
 // K-tile of 64 bytes per row for BOTH operands (4 stages of 32 KiB) and one load + one compute phase per K-tile:
 // 12 ds_read_b128 and 32 (int8) or 64 (fp8) MFMAs per wave.
 #include "qh_common.h"
+
+#ifndef QH_N8_ABLATE
+#define QH_N8_ABLATE 0  // experiments only: 1 = no DMA in the steady loop, 2 = no MFMA, 3 = no fragment reads
+#endif
 
 namespace qh {
 namespace n8 {
@@ -165,6 +169,9 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
   // which is why the refill (tile kt+3 -> stage of tile kt-1) is issued in L(kt), after G1's L(kt-1) completed.
   int cur = 0;
   auto compute = [&]() {
+#if QH_N8_ABLATE == 2
+    return;
+#endif
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -191,9 +198,13 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
   // steady state: tiles kt+1 .. kt+3 exist; the own share of tile kt+1 has landed once at most 8 DMAs are in flight
   int kt = 0;
   for (; kt + 3 < nk; ++kt) {
+#if QH_N8_ABLATE != 3
     read_frags(smem + cur * STAGE_BYTES);
+#endif
+#if QH_N8_ABLATE != 1
     issue(kt + 3, (cur + 3) & 3);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
     end_load_phase();
     compute();
     end_compute_phase();

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--shapes", nargs="+", default=["4096x4096x4096", "512x8192x8192", "8192x8192x8192", "2048x14336x4096"])
     ap.add_argument("--pairs", nargs="+", default=["i8:i8", "f8:f8", "bf16:i8", "bf16:f8"])
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--kernel", default="auto")
     args = ap.parse_args()
     from optimum_quanto_amd.library.hip import quanto_hip
 
@@ -38,13 +39,13 @@ def main():
             a, b = make(ak, M, K), make(bk, N, K)
             s = (torch.rand(N, device=dev) * 1e-3).to(torch.bfloat16)
             for _ in range(3):
-                lib.qbytes_mm(a, b, s)
+                lib.qbytes_mm(a, b, s, kernel=args.kernel)
             kern = lib.last_kernel()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.iters):
-                lib.qbytes_mm(a, b, s)
+                lib.qbytes_mm(a, b, s, kernel=args.kernel)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / args.iters

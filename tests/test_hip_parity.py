@@ -231,9 +231,10 @@ def test_qbytes_mfma(dt, kind, M, N, K):
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("kind", [None, "e4m3fn", "e5m2"])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1024), (300, 700, 256), (1, 17, 192), (1024, 256, 4096)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1024), (300, 700, 256), (1, 17, 192), (1024, 256, 4096), (256, 512, 192)])
 def test_qbytes_mfma_large_tile(dt, kind, M, N, K):
-    """256x256 LDS-DMA kernel incl. ragged M / N edges (clamped loads, masked stores) and 2..64 K-tiles."""
+    """256x256 LDS-DMA kernel incl. ragged M / N edges (clamped loads, masked stores), 2..64 K-tiles, odd and even tile
+    counts for the 3-stage ring."""
     p = make_qbytes_problem(M, N, K, dt, kind, seed=M + K + 1)
     assert_close_to_exact(_run_qbytes(p, "mfma_large"), O.qbytes_mm_exact(p["x"], p["data"], p["scale"], kind), dt, "qbytes mfma_large")
 
