@@ -60,7 +60,8 @@ typedef enum {
   QUANTO_HIP_KERNEL_MFMA = 3,  /* LDS-tiled MFMA kernel, 128x128 tile (any M)                   */
   QUANTO_HIP_KERNEL_MFMA_LARGE = 4, /* 256x256 tile, LDS-DMA pipeline (prefill-sized M and N)    */
   QUANTO_HIP_KERNEL_SKINNY = 5, /* qbits_mm: weight-streaming MFMA kernel for M <= QUANTO_HIP_SKINNY_MAX_M */
-  QUANTO_HIP_KERNEL_NATIVE8 = 6 /* qbytes_mm with quantized activations: int8 x int8 (i32 MFMA) / fp8 x fp8 (fp8 MFMA) */
+  QUANTO_HIP_KERNEL_NATIVE8 = 6, /* qbytes_mm with quantized activations: int8 x int8 (i32 MFMA) / fp8 x fp8 (fp8 MFMA) */
+  QUANTO_HIP_KERNEL_DEQUANT_MFMA = 7 /* qbits_mm, prefill-sized M: fused dequantize into the workspace + 256x256 dense MFMA GEMM */
 } quanto_hip_kernel;
 
 #define QUANTO_HIP_GEMV_MAX_M 8         /* qbytes_mm: rows of x the GEMV kernel accepts                    */
@@ -119,7 +120,8 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
  * Scratch bytes quanto_hip_qbits_mm needs for this problem (0 when the selected kernel needs none).
  * The caller allocates it (16-byte aligned), passes it as `workspace` and may reuse it for any later
  * call on the same stream.  The MFMA kernel stores the per-group row sums of x there
- * (fp32 [K/group_size][roundup(M,128)]).  Returns a negative status on invalid arguments.
+ * (fp32 [K/group_size][roundup(M,128)]); the DEQUANT_MFMA path stores the dequantized weight (dtype[N, K]).
+ * Returns a negative status on invalid arguments.
  */
 int64_t quanto_hip_qbits_mm_workspace_size(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype,
                                            int kernel);

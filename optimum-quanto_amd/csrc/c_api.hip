@@ -24,6 +24,8 @@ int qbytes_mm_mfma(const void*, const void*, const void*, const void*, void*, in
 bool qbytes_mfma_v2_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_mfma_v2(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 int quantize_symmetric(const void*, const void*, void*, int64_t, int64_t, int, int, int, hipStream_t);
+bool dense_mm_large_supported(int64_t, int64_t, int64_t, int);
+int dense_mm_large(const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, hipStream_t);
 bool qbytes_native8_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_native8(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 bool qbits_skinny_supported(int64_t, const PackedGeom&, int);
@@ -58,10 +60,17 @@ static bool prefer_gemv(int64_t M) { return M <= QUANTO_HIP_GEMV_MAX_M; }
 // qbits_mm kernel choice.  M <= 8: dot2 GEMV (x in registers, every CU busy even for N = 4096; measured 11 us at M = 8
 // vs 19 us for the streaming MFMA kernel on 4096x4096).  9..64: streaming MFMA
 // kernel (cost per weight byte independent of M); GEMV passes when it does not apply.  Above: LDS-tiled MFMA GEMM.
+// Prefill-sized M: dequantize once into the workspace (one pass over the packed weight, ~N*K*2.5 bytes of HBM traffic),
+// then a dense 256x256-tile GEMM - the dequantization cost is amortised over M rows instead of being repeated per tile.
+static bool dequant_mfma_supported(int64_t M, const PackedGeom& g, int dtype) { return dense_mm_large_supported(M, g.N, g.K, dtype); }
+static size_t dequant_mfma_workspace(const PackedGeom& g) { return (size_t)g.N * g.K * 2; }
+static bool prefer_dequant_mfma(int64_t M, const PackedGeom& g) { return ((M + 255) / 256) * ((g.N + 255) / 256) >= 32; }
+
 static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {
   if (M <= 8 && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
   if (qbits_skinny_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_SKINNY;
   if (qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
+  if (have_workspace && dequant_mfma_supported(M, g, dtype) && prefer_dequant_mfma(M, g)) return QUANTO_HIP_KERNEL_DEQUANT_MFMA;
   if (have_workspace && qbits_mfma_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MFMA;
   return QUANTO_HIP_KERNEL_NAIVE;
 }
@@ -115,6 +124,7 @@ int64_t quanto_hip_qbits_mm_workspace_size(int64_t M, int64_t N, int64_t K, int 
   if (kernel == QUANTO_HIP_KERNEL_AUTO) kernel = pick_qbits_kernel(M, g, dtype, true);
   if (kernel == QUANTO_HIP_KERNEL_SKINNY) return qbits_skinny_supported(M, g, dtype) ? (int64_t)qbits_skinny_workspace(M, g) : 0;
   if (kernel == QUANTO_HIP_KERNEL_MFMA) return qbits_mfma_supported(M, g, dtype) ? (int64_t)qbits_mfma_workspace(M, g) : 0;
+  if (kernel == QUANTO_HIP_KERNEL_DEQUANT_MFMA) return dequant_mfma_supported(M, g, dtype) ? (int64_t)dequant_mfma_workspace(g) : 0;
   return 0;
 }
 
@@ -131,6 +141,8 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
   if (kernel == QUANTO_HIP_KERNEL_AUTO) {
     kernel = pick_qbits_kernel(M, g, dtype, workspace != nullptr);
     if (kernel == QUANTO_HIP_KERNEL_SKINNY && workspace_bytes < qbits_skinny_workspace(M, g)) kernel = QUANTO_HIP_KERNEL_NAIVE;
+    if (kernel == QUANTO_HIP_KERNEL_DEQUANT_MFMA && workspace_bytes < dequant_mfma_workspace(g))
+      kernel = qbits_mfma_supported(M, g, dtype) ? QUANTO_HIP_KERNEL_MFMA : QUANTO_HIP_KERNEL_NAIVE;
     if (kernel == QUANTO_HIP_KERNEL_MFMA && workspace_bytes < qbits_mfma_workspace(M, g)) kernel = QUANTO_HIP_KERNEL_NAIVE;
   }
   int r;
@@ -146,6 +158,14 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
     case QUANTO_HIP_KERNEL_MFMA:
       r = qbits_mm_mfma(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, workspace, workspace_bytes, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("mfma");
+      return r;
+    case QUANTO_HIP_KERNEL_DEQUANT_MFMA:
+      if (!dequant_mfma_supported(M, g, dtype)) return QUANTO_HIP_ENOTSUP;
+      if (!workspace || workspace_bytes < dequant_mfma_workspace(g)) return QUANTO_HIP_EINVAL;
+      r = dequantize_qbits_dispatch(packed, scale, shift, workspace, g, dtype, int_shift, stream);
+      if (r != QUANTO_HIP_OK) return r;
+      r = dense_mm_large(x, workspace, bias, y, M, g.N, g.K, dtype, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("dequant_mfma");
       return r;
     case QUANTO_HIP_KERNEL_SKINNY:
       r = qbits_mm_skinny(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, workspace, workspace_bytes, stream);

@@ -6,14 +6,16 @@
 //                rounding to the output dtype -> bit-identical to the reference's _int_mm path;
 //   fp8  x fp8 : every product of two e4m3/e5m2 values is exact in fp32; fp32 accumulation.
 //
-// Same LDS image as qmm_mfma_large.hip (256x256 tile, 8 waves as 2x4, LDS-DMA with counted vmcnt, swizzled 64-byte rows,
-// alternating load / compute phases with waves 4-7 one phase behind waves 0-3, LDS-transposed full-line epilogue), but a
-// K-tile of 64 bytes per row for BOTH operands (4 stages of 32 KiB) and one load + one compute phase per K-tile:
-// 12 ds_read_b128 and 32 (int8) or 64 (fp8) MFMAs per wave.
+// Same structure as qmm_mfma_large.hip (256x256 tile, 8 waves as 2x4, LDS-DMA with counted vmcnt, swizzled 64-byte rows,
+// one software-pipelined instruction stream per wave, one barrier per K-tile, LDS-transposed full-line epilogue), with a
+// K-tile of 64 bytes per row for BOTH operands (4 stages of 32 KiB): 12 ds_read_b128, 4 DMA issues and 32 (int8) or
+// 64 (fp8) MFMAs per wave and K-tile.
+#include <type_traits>
+
 #include "qh_common.h"
 
 #ifndef QH_N8_ABLATE
-#define QH_N8_ABLATE 0  // experiments only: 1 = no DMA in the steady loop, 2 = no MFMA, 3 = no fragment reads
+#define QH_N8_ABLATE 0  // timing experiments only: 1 = no DMA inside the K loop
 #endif
 
 namespace qh {
@@ -43,7 +45,7 @@ __device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_
 
 __device__ __forceinline__ int swz64(int row) { return (-(row >> 2)) & 3; }  // 64-byte rows, lanes read chunk lane>>4
 
-enum { K_I8 = 0, K_F8E4M3 = 1, K_F8E5M2 = 2 };
+enum { K_I8 = 0, K_F8E4M3 = 1, K_F8E5M2 = 2, K_BF16 = 3, K_F16 = 4 };  // K_BF16 / K_F16: dense 16-bit operands, 32 elements per K-tile
 
 template <int KIND>
 struct Acc {
@@ -55,9 +57,9 @@ struct Acc<K_I8> {
 };
 
 struct Args {
-  const uint8_t* a;   // [M, K] 1 byte per element
+  const uint8_t* a;   // [M, K] 1 byte per element (2 for the dense 16-bit kinds)
   const uint8_t* w;   // [N, K]
-  const void* scale;  // [N] output dtype
+  const void* scale;  // [N] output dtype, or null (= 1)
   const void* bias;   // [N] or null
   void* y;            // [M, N]
   int M, N, K;
@@ -72,9 +74,10 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
+  const int wm = wave >> 2, wn = wave & 3;
+  constexpr int ES = (KIND == K_BF16 || KIND == K_F16) ? 2 : 1;  // operand element size; a K-tile is always 64 bytes per row
   const int M = a.M, N = a.N, K = a.K;
-  const int nk = K / BK;
+  const int nk = K * ES / BK;
 
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
   const int nwg = tiles_n * tiles_m;
@@ -96,8 +99,8 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
     int m = m0 + R, n = n0 + R;
     m = m < M ? m : M - 1;
     n = n < N ? n : N - 1;
-    asrc[j] = (uint32_t)((size_t)m * K + c * 16);
-    wsrc[j] = (uint32_t)((size_t)n * K + c * 16);
+    asrc[j] = (uint32_t)((size_t)m * K * ES + c * 16);
+    wsrc[j] = (uint32_t)((size_t)n * K * ES + c * 16);
     adst[j] = (j * 8 + wave) * 1024;
     wdst[j] = A_BYTES + (j * 8 + wave) * 1024;
   }
@@ -110,18 +113,11 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
     for (int j = 0; j < 2; ++j) glds16(a.w + (size_t)kt * BK, wsrc[j], st + wdst[j]);
   };
 
-  // ---- fragment reads: ONE ds_read_b128 per 16-row fragment and K-tile (bytes k = 16g .. 16g+15, g = lane >> 4) --------
-  int aoff[8], boff[4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int R = wm * 128 + i * 16 + (lane & 15);
-    aoff[i] = R * 64 + (((lane >> 4) ^ swz64(R)) << 4);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int R = wn * 64 + j * 16 + (lane & 15);
-    boff[j] = A_BYTES + R * 64 + (((lane >> 4) ^ swz64(R)) << 4);
-  }
+  // ---- fragment reads: ONE ds_read_b128 per 16-row fragment and K-tile (bytes k = 16g .. 16g+15, g = lane >> 4); the
+  // swizzle only depends on (row & 15) >> 2, so fragment i / j adds a compile-time multiple of 1024 bytes
+  const int ra = wm * 128 + (lane & 15), rw = wn * 64 + (lane & 15);
+  const int aoff0 = ra * 64 + (((lane >> 4) ^ swz64(ra)) << 4);
+  const int boff0 = A_BYTES + rw * 64 + (((lane >> 4) ^ swz64(rw)) << 4);
 
   // acc[j][i]: the weight fragment is the MFMA A operand (rows = output features), the activation fragment the B operand
   AV acc[4][8];
@@ -130,100 +126,105 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[j][i] = AV{0, 0, 0, 0};
 
-  uint4 xa[8], wq[4];
-  auto read_frags = [&](const uint8_t* st) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wq[j] = *reinterpret_cast<const uint4*>(st + boff[j]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) xa[i] = *reinterpret_cast<const uint4*>(st + aoff[i]);
+  // Single software-pipelined stream per wave (same scheme as qmm_mfma_large.hip): per K-tile 8 steps, step i = the
+  // MFMAs of token fragment i against the four resident weight fragments, each MFMA followed by at most one LDS read or
+  // one DMA issue.  Fragments are fetched a full K-tile ahead (with 32 MFMAs per tile a two-step distance is shorter
+  // than the LDS latency under load and the stream stalls on every fragment): the activation fragment of step i is
+  // replaced by the next tile's as soon as step i has issued its MFMAs; the weight fragments, live for the whole tile,
+  // ping-pong between two register sets.  One barrier per K-tile.
+  uint4 xf[8], wq[2][4];
+  auto read_x = [&](const uint8_t* st, int i) -> uint4 { return *reinterpret_cast<const uint4*>(st + aoff0 + i * 1024); };
+  auto read_w = [&](const uint8_t* st, int j) -> uint4 { return *reinterpret_cast<const uint4*>(st + boff0 + j * 1024); };
+  auto issue_piece = [&](int kt, int stage, int piece) {
+    const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
+    if (piece < 2)
+      glds16(a.a + (size_t)kt * BK, asrc[piece], st + adst[piece]);
+    else
+      glds16(a.w + (size_t)kt * BK, wsrc[piece - 2], st + wdst[piece - 2]);
   };
-  auto end_load_phase = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  };
-  auto end_compute_phase = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+  auto mma = [&](AV& c, const uint4& w, const uint4& x) {
+    if constexpr (KIND == K_I8) {
+      c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, w), __builtin_bit_cast(i32x4, x), c, 0, 0, 0);
+    } else if constexpr (KIND == K_BF16) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+    } else if constexpr (KIND == K_F16) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+    } else {
+      const long wlo = (long)(((unsigned long)w.y << 32) | w.x), whi = (long)(((unsigned long)w.w << 32) | w.z);
+      const long xlo = (long)(((unsigned long)x.y << 32) | x.x), xhi = (long)(((unsigned long)x.w << 32) | x.z);
+      if constexpr (KIND == K_F8E4M3) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wlo, xlo, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(whi, xhi, c, 0, 0, 0);
+      } else {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(wlo, xlo, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(whi, xhi, c, 0, 0, 0);
+      }
+    }
   };
 
-  // prologue: tiles 0, 1, 2 in flight; tile 0 must be visible before the first load phase
+  // prologue: tiles 0, 1, 2 in flight; tiles 0 and 1 visible (tile 1 feeds the prefetches issued during tile 0)
   issue(0, 0);
   if (nk > 1) issue(1, 1);
-  if (nk > 2) issue(2, 2);
-  if (nk > 2)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (nk > 1)
+  if (nk > 2) {
+    issue(2, 2);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else
+  } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if (grp == 1) end_compute_phase();  // G1 runs one phase behind G0
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wq[0][j] = read_w(smem, j);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) xf[i] = read_x(smem, i);
 
-  // Per K-tile and wave: L (DMA of tile kt+3, fragment reads of tile kt, wait for the own share of tile kt+1) then
-  // C (32 / 64 MFMAs).  Tile kt+1 is visible to everybody once all waves passed the barrier that ends their L(kt);
-  // the stage of tile kt-1 is free once all waves passed the barrier that ends their L(kt-1)... + one more slot for G1,
-  // which is why the refill (tile kt+3 -> stage of tile kt-1) is issued in L(kt), after G1's L(kt-1) completed.
-  int cur = 0;
-  auto compute = [&]() {
-#if QH_N8_ABLATE == 2
-    return;
-#endif
-    __builtin_amdgcn_s_setprio(1);
+  // tile kt (stage kt & 3): refill the stage of tile kt-1 with tile kt+3, prefetch from the stage of tile kt+1, and before
+  // the closing barrier wait for the own DMA share of tile kt+2 (tile kt+3 may stay in flight)
+  auto tile = [&](int kt, auto parity_tag, bool dma, int wait_mode /* 2: vmcnt(4), 1: vmcnt(0), 0: none */, bool barrier) {
+    constexpr int P = decltype(parity_tag)::value;
+    const uint8_t* sn = smem + ((kt + 1) & 3) * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if constexpr (KIND == K_I8) {
-          acc[j][i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, wq[j]), __builtin_bit_cast(i32x4, xa[i]),
-                                                             acc[j][i], 0, 0, 0);
-        } else {
-          const long wlo = (long)(((unsigned long)wq[j].y << 32) | wq[j].x), whi = (long)(((unsigned long)wq[j].w << 32) | wq[j].z);
-          const long xlo = (long)(((unsigned long)xa[i].y << 32) | xa[i].x), xhi = (long)(((unsigned long)xa[i].w << 32) | xa[i].z);
-          if constexpr (KIND == K_F8E4M3) {
-            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wlo, xlo, acc[j][i], 0, 0, 0);
-            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(whi, xhi, acc[j][i], 0, 0, 0);
-          } else {
-            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(wlo, xlo, acc[j][i], 0, 0, 0);
-            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(whi, xhi, acc[j][i], 0, 0, 0);
-          }
+        mma(acc[j][i], wq[P][j], xf[i]);
+        if (j == 1) {
+          if (i < 4) wq[P ^ 1][i] = read_w(sn, i);
+        } else if (j == 2) {
+#if QH_N8_ABLATE != 1
+          if (i >= 4 && dma) issue_piece(kt + 3, (kt + 3) & 3, i - 4);
+#endif
+        } else if (j == 3) {
+          xf[i] = read_x(sn, i);  // same fragment of the next tile
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __builtin_amdgcn_s_setprio(0);
-  };
-  // steady state: tiles kt+1 .. kt+3 exist; the own share of tile kt+1 has landed once at most 8 DMAs are in flight
-  int kt = 0;
-  for (; kt + 3 < nk; ++kt) {
-#if QH_N8_ABLATE != 3
-    read_frags(smem + cur * STAGE_BYTES);
-#endif
-#if QH_N8_ABLATE != 1
-    issue(kt + 3, (cur + 3) & 3);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#endif
-    end_load_phase();
-    compute();
-    end_compute_phase();
-    cur = (cur + 1) & 3;
-  }
-  // drain: 2, 1, 0 younger tiles in flight
-  for (; kt < nk; ++kt) {
-    read_frags(smem + cur * STAGE_BYTES);
-    const int younger = nk - 2 - kt;
-    if (younger >= 1)
+    if (wait_mode == 2)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else
+    else if (wait_mode == 1)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    end_load_phase();
-    compute();
-    end_compute_phase();
-    cur = (cur + 1) & 3;
+    if (barrier) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  };
+  using even = std::integral_constant<int, 0>;
+  using odd = std::integral_constant<int, 1>;
+  int kt = 0;
+  for (; kt + 4 < nk; kt += 2) {  // steady state: tiles kt+3 and kt+4 exist
+    tile(kt, even{}, true, 2, true);
+    tile(kt + 1, odd{}, true, 2, true);
   }
-  if (grp == 0) end_compute_phase();
+  // at most four tiles left (kt is even): nothing, or less, to prefetch - straight-line so the parity stays static
+#define QH_TAIL_TILE(J, PARITY)                                                                                          \
+  if (kt + (J) < nk)                                                                                                     \
+    tile(kt + (J), PARITY{}, kt + (J) + 3 < nk, kt + (J) + 3 < nk ? 2 : (kt + (J) + 2 < nk ? 1 : 0), kt + (J) + 1 < nk)
+  QH_TAIL_TILE(0, even);
+  QH_TAIL_TILE(1, odd);
+  QH_TAIL_TILE(2, even);
+  QH_TAIL_TILE(3, odd);
+#undef QH_TAIL_TILE
 
   // ---- epilogue: (int32 | fp32) accumulator * scale[n] (+ bias), parked per wave in LDS, stored as full 128-byte lines ----
   T* yg = reinterpret_cast<T*>(a.y);
@@ -246,7 +247,7 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = nb + r < N ? nb + r : N - 1;
-        sc[r] = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
+        sc[r] = a.scale ? E::to_f32(reinterpret_cast<const T*>(a.scale)[n]) : 1.f;
         bv[r] = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
       }
 #pragma unroll
@@ -305,6 +306,21 @@ static int launch(const Args& a, hipStream_t stream) {
 }
 
 }  // namespace n8
+
+// Dense 16-bit GEMM y = x @ w^T (+ bias) on the same pipeline; used by qbits_mm for prefill-sized M after the packed
+// weight has been dequantized (bit-identically to the reference's dequantize()) into the caller's workspace.
+bool dense_mm_large_supported(int64_t M, int64_t N, int64_t K, int dtype) {
+  return (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && K % 32 == 0 && K >= 32 && M >= 1 && M * K < (1ll << 30) &&
+         N * K < (1ll << 30) && M < (1 << 30) && N < (1 << 30);
+}
+
+int dense_mm_large(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int dtype, hipStream_t stream) {
+  if (!dense_mm_large_supported(M, N, K, dtype)) return QUANTO_HIP_ENOTSUP;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
+  n8::Args args{reinterpret_cast<const uint8_t*>(x), reinterpret_cast<const uint8_t*>(w), nullptr, bias, y, (int)M, (int)N, (int)K};
+  if (dtype == QUANTO_HIP_BF16) return n8::launch<QUANTO_HIP_BF16, n8::K_BF16>(args, stream);
+  return n8::launch<QUANTO_HIP_F16, n8::K_F16>(args, stream);
+}
 
 bool qbytes_native8_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
   const bool pair = (a_dtype == QUANTO_HIP_I8 && b_dtype == QUANTO_HIP_I8) ||

@@ -19,9 +19,9 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # quanto_hip_dtype (include/quanto_hip.h)
 F32, F16, BF16, I8, U8, F8_E4M3FN, F8_E5M2, F8_E4M3FNUZ = range(8)
-KERNEL_AUTO, KERNEL_NAIVE, KERNEL_GEMV, KERNEL_MFMA, KERNEL_MFMA_LARGE, KERNEL_SKINNY, KERNEL_NATIVE8 = range(7)
+KERNEL_AUTO, KERNEL_NAIVE, KERNEL_GEMV, KERNEL_MFMA, KERNEL_MFMA_LARGE, KERNEL_SKINNY, KERNEL_NATIVE8, KERNEL_DEQUANT_MFMA = range(8)
 KERNELS = {"auto": KERNEL_AUTO, "naive": KERNEL_NAIVE, "gemv": KERNEL_GEMV, "mfma": KERNEL_MFMA, "mfma_large": KERNEL_MFMA_LARGE, "skinny": KERNEL_SKINNY,
-           "mfma_native8": KERNEL_NATIVE8}
+           "mfma_native8": KERNEL_NATIVE8, "dequant_mfma": KERNEL_DEQUANT_MFMA}
 
 _DTYPES = {
     torch.float32: F32,

@@ -14,7 +14,7 @@ for (M,N,K) in shapes:
         sc = (torch.rand((N*K//128,1),generator=g)*0.01+0.005).to(torch.bfloat16).cuda(); sh = (torch.rand((N*K//128,1),generator=g)*0.05).to(torch.bfloat16).cuda()
         sets.append((packed, sc, sh))
     x = torch.randn((M,K),generator=g).to(torch.bfloat16).cuda()
-    for kern in ("skinny","gemv","mfma"):
+    for kern in ("skinny","gemv","mfma","dequant_mfma"):
         i = [0]
         def f():
             p, s, z = sets[i[0] % len(sets)]; i[0] += 1
@@ -31,4 +31,4 @@ for (M,N,K) in shapes:
         e0,e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1)/32*1000
-        print(f"M={M} N={N} K={K} {kern:7s} {us:8.1f} us  {N*K/2/us/1e6:6.2f} TB/s(weights)", flush=True)
+        print(f"M={M} N={N} K={K} {kern:12s} {us:8.1f} us  {N*K/2/us/1e6:6.2f} TB/s(weights) {2*M*N*K/us/1e6:8.1f} TFLOP/s", flush=True)

@@ -146,6 +146,27 @@ def test_qbits_mfma(dt, M, N, K, gs):
     assert_close_to_exact(_run_qbits(p, "mfma"), _exact_qbits(p), dt, f"mfma {M}x{K}x{N} g{gs}")
 
 
+def _rounded_weight_exact(p, bias=None):
+    """x @ W_dt.T in float64 with W_dt = the reference's dequantize() output (rounded to the module dtype, qbits.py:27-49)."""
+    w = O.dequantize_qbits_ref(p["packed"], p["bits"], p["scale"], p["shift"], 0, p["group_size"], (p["N"], p["K"]), p["dt"])
+    y = np.matmul(p["x"].astype(np.float64), w.astype(np.float64).T)
+    return y if bias is None else y + bias.astype(np.float64)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K,bits,gs,zp", [(256, 256, 256, 4, 128, False), (300, 700, 512, 4, 128, True), (512, 768, 1024, 4, 64, False),
+                                               (257, 64, 96, 4, 32, False), (128, 256, 192, 2, 64, False), (1024, 512, 160, 4, None, False),
+                                               (64, 48, 32, 2, None, True)])
+def test_qbits_dequant_mfma(dt, M, N, K, bits, gs, zp):
+    """Prefill path: fused dequantize (bit-identical to the reference's weights) + dense 256x256 MFMA GEMM.  The oracle for
+    this path multiplies the ROUNDED dequantized weight, exactly what tensor/function.py:41-47 does; int2, per-channel
+    (group_size None) and zero-point layouts included."""
+    p = make_qbits_problem(M, N, K, dt, bits=bits, group_size=gs, zeropoint=zp, seed=M + N + K)
+    assert_close_to_exact(_run_qbits(p, "dequant_mfma"), _rounded_weight_exact(p), dt, f"dequant_mfma {M}x{K}x{N}")
+    bias = O.round_to(np.random.default_rng(3).standard_normal(N).astype(np.float32), dt)
+    assert_close_with_bias(_run_qbits(p, "dequant_mfma", bias), _rounded_weight_exact(p), bias, dt, "dequant_mfma + bias")
+
+
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_qbits_mfma_zeropoint_and_bias(dt):
     p = make_qbits_problem(40, 256, 512, dt, zeropoint=True, seed=12)
@@ -176,6 +197,9 @@ def test_qbits_auto_picks_fast_kernels():
     p = make_qbits_problem(65, 256, 1024, "bf16")
     _run_qbits(p, "auto")
     assert quanto_hip.lib.last_kernel() == "mfma"
+    p = make_qbits_problem(2048, 1024, 256, "bf16")  # 8 x 4 tiles of 256x256: dequantize once + dense GEMM
+    _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "dequant_mfma"
 
 
 def test_qbits_golden_linear(golden):
