@@ -75,8 +75,9 @@ static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool hav
   return QUANTO_HIP_KERNEL_NAIVE;
 }
 
-// 256x256 tiles pay off once they can fill a good part of the 256 CUs; below that the 128x128 kernel has 4x the blocks
-static bool prefer_large_tile(int64_t M, int64_t N) { return ((M + 255) / 256) * ((N + 255) / 256) >= 96; }
+// The LDS-DMA pipelined kernel (256x256 or 128x128 tiles, picked inside) whenever its 128-tiles can occupy a good part of
+// the chip; the register-staged 128x128 kernel remains for what it does not support (fp32, K % 64 != 0, K < 128)
+static bool prefer_large_tile(int64_t M, int64_t N) { return ((M + 127) / 128) * ((N + 127) / 128) >= 64; }
 
 }  // namespace qh
 

@@ -31,10 +31,7 @@
 namespace qh {
 namespace lt {
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int A_BYTES = BM * BK * 2;  // 32 KiB
-constexpr int W_BYTES = BN * BK;      // 16 KiB
-constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+constexpr int BK = 64;
 constexpr int STAGES = 3;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -118,15 +115,27 @@ struct Args {
   int M, N, K;
 };
 
-// WN = waves along the feature dimension: 2 -> four waves of 128x128 (one per SIMD), 4 -> eight waves of 128x64 (two per SIMD)
-template <int DT, int FMT, int WN>
-__global__ void __launch_bounds__(128 * WN, 1) qbytes_mfma_large_kernel(const Args a) {
-  constexpr int NWAVES = 2 * WN;
-  constexpr int NJ = 16 / WN;          // 16-feature fragments per wave (8 or 4)
-  constexpr int APIECES = 32 / NWAVES;  // activation DMA pieces per wave and K-tile (8 or 4)
-  constexpr int WPIECES = 16 / NWAVES;  // weight DMA pieces per wave and K-tile (4 or 2)
+// Tile configurations (BM x BN workgroup tile, WM x WN waves, each wave (BM/WM) x (BN/WN)):
+//   256 x 256, 2 x 4 waves of 128 x 64  - the default for grids that fill the chip: two interleaving streams per SIMD
+//   256 x 256, 2 x 2 waves of 128 x 128 - one stream per SIMD, least LDS traffic (experiments: QUANTO_HIP_LARGE_WN=2)
+//   128 x 128, 1 x 4 waves of 128 x 32  - four times the workgroups for prefill shapes whose 256-tiles cannot fill 256 CUs
+//                                         (e.g. M = 512).  All waves side by side along the features: every converted
+//                                         weight fragment feeds 8 MFMAs (1.5 VALU ops per MFMA, as in the 256-tiles); a
+//                                         2 x 2 layout converts twice as much and is VALU-issue bound (measured 105 us
+//                                         vs this layout on cfg4)
+template <int DT, int FMT, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(const Args a) {
+  constexpr int NWAVES = WM * WN;
+  constexpr int MI = BM / WM / 16;              // 16-token fragments per wave
+  constexpr int NJ = BN / WN / 16;              // 16-feature fragments per wave
+  constexpr int STEPS = 2 * MI;                 // (k-half, token fragment) steps per K-tile
+  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK, STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int APIECES = BM / 8 / NWAVES;      // activation DMA pieces (8 rows x 128 B) per wave and K-tile
+  constexpr int WPIECES = BN / 16 / NWAVES;     // weight DMA pieces (16 rows x 64 B) per wave and K-tile
   constexpr int NPIECES = APIECES + WPIECES;
-  constexpr int ND = NJ / 2;           // converted dwords per step (one phase converts NJ*4 dwords in 8 steps)
+  constexpr int ND = (NJ * 4 + MI - 1) / MI;    // converted dwords per step (one phase converts NJ*4 dwords in MI steps)
+  constexpr int PPS = NPIECES / 6;              // DMA pieces per step over the first six steps
+  static_assert(NPIECES % 6 == 0 && STEPS % 4 == 0 && ND <= NJ && PPS <= NJ, "unsupported tile configuration");
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
@@ -178,21 +187,21 @@ __global__ void __launch_bounds__(128 * WN, 1) qbytes_mfma_large_kernel(const Ar
   };
 
   // ---- fragment read offsets: fragment i / j only adds a compile-time multiple of 2048 / 1024 bytes ----------------
-  const int ra = wm * 128 + (lane & 15), rw = wn * (NJ * 16) + (lane & 15);
+  const int ra = wm * (MI * 16) + (lane & 15), rw = wn * (NJ * 16) + (lane & 15);
   int aoff[2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) aoff[kk] = ra * 128 + ((((lane >> 4) * 2 + kk) ^ swz_a(ra)) << 4);
   const int boff = A_BYTES + rw * 64 + (((lane >> 4) ^ swz_w(rw)) << 4);
 
-  f32x4 acc[NJ][8];  // acc[j][i]: features j*16.., tokens i*16..
+  f32x4 acc[NJ][MI];  // acc[j][i]: features j*16.., tokens i*16..
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   uint4 raw[NJ];         // 16 weight bytes per fragment: k-half 0 in .xy, k-half 1 in .zw
   uint32_t w0[NJ][4], w1[NJ][4];
-  V8 xf[4];              // activation fragments, two steps ahead (ring of 4: 16 steps per tile keep the ring aligned)
+  V8 xf[4];              // activation fragments, two steps ahead (ring of 4: STEPS is a multiple of 4, the ring stays aligned)
   auto as_v8 = [&](const uint32_t(&w)[4]) { return __builtin_bit_cast(V8, make_uint4(w[0], w[1], w[2], w[3])); };
   auto rawword = [&](int j, int kk, int d) -> uint32_t {
     const uint32_t lo = kk == 0 ? raw[j].x : raw[j].z, hi = kk == 0 ? raw[j].y : raw[j].w;
@@ -233,15 +242,15 @@ __global__ void __launch_bounds__(128 * WN, 1) qbytes_mfma_large_kernel(const Ar
     const int nxt2 = nxt == STAGES - 1 ? 0 : nxt + 1;
     const uint8_t* sn = smem + nxt * STAGE_BYTES;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int kk = s >> 3, i = s & 7;
+    for (int s = 0; s < STEPS; ++s) {
+      const int kk = s / MI, i = s % MI;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         if (kk == 0)
           acc[j][i] = Mma<DT>::run(as_v8(w0[j]), xf[s & 3], acc[j][i]);
         else
           acc[j][i] = Mma<DT>::run(as_v8(w1[j]), xf[s & 3], acc[j][i]);
-        if (j < ND) {
+        if (j < ND && i * ND + j < NJ * 4) {
           // conversion: step i of a phase produces dwords i*ND .. i*ND+ND-1 of the phase's NJ*4 (fragment-major)
           const int c = i * ND + j, f = c >> 2, d = c & 3;
 #if QH_V3_ABLATE & 1
@@ -252,20 +261,23 @@ __global__ void __launch_bounds__(128 * WN, 1) qbytes_mfma_large_kernel(const Ar
           else
             w0[f][d] = convert_pair<DT, FMT>(rawword(f, 0, d), d & 1);  // next tile's k-half 0 (raw[f] already holds tile kt+1)
 #endif
-        } else if (j == ND) {
+        }
+        if (j == (ND < NJ ? ND : 0)) {
           // activation fragment of step s+2 (the first two of the next tile at the end; garbage, unused, on the last tile)
 #if !(QH_V3_ABLATE & 2)
-          xf[(s + 2) & 3] = s + 2 < 16 ? read_x(st, (s + 2) & 7, (s + 2) >> 3) : read_x(sn, (s + 2) & 7, 0);
-#endif
-        } else if (j == ND + 1) {
-          // next tile's raw weight bytes: fragment f is dead once its k-half 1 is converted, i.e. after phase-0 step
-          // (f+1)*(8/NJ) - 1; it is reloaded in the step after that (the last one at the first step of phase 1)
-          constexpr int SPF = 8 / NJ;  // steps per fragment (1 or 2)
-#if !(QH_V3_ABLATE & 2)
-          if (s >= SPF && s <= 8 && s % SPF == 0) raw[s / SPF - 1] = read_raw(sn, s / SPF - 1);
+          xf[(s + 2) & 3] = s + 2 < STEPS ? read_x(st, (s + 2) % MI, (s + 2) / MI) : read_x(sn, s + 2 - STEPS, 0);
 #endif
         }
-        if (DMA && !(QH_V3_ABLATE & 4) && j >= NJ - NPIECES / 6 && s < 6) issue_piece(kt + 2, nxt2, (NPIECES / 6) * s + (j - (NJ - NPIECES / 6)));
+        if (j == (ND + 1 < NJ ? ND + 1 : 1)) {
+          // next tile's raw weight bytes: fragment f is dead once the last dword of its k-half 1 is converted, i.e. after
+          // phase-0 step (4f+3)/ND; it is reloaded in the following step (phase-1 step 0 for the last fragment)
+#if !(QH_V3_ABLATE & 2)
+#pragma unroll
+          for (int f = 0; f < NJ; ++f)
+            if (s == (4 * f + 3) / ND + 1) raw[f] = read_raw(sn, f);
+#endif
+        }
+        if (DMA && !(QH_V3_ABLATE & 4) && j >= NJ - PPS && s < 6) issue_piece(kt + 2, nxt2, PPS * s + (j - (NJ - PPS)));
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -287,13 +299,13 @@ __global__ void __launch_bounds__(128 * WN, 1) qbytes_mfma_large_kernel(const Ar
   tile(kt + 1, no{}, no{});
   QH_V3_STAMP(4);
 
-  // ---- epilogue: scale (+bias) on the fp32 accumulator; each wave parks 128 tokens x 64 features (16 KiB) twice ----------
+  // ---- epilogue: scale (+bias) on the fp32 accumulator; each wave parks MI*16 tokens x 64 features per pass -------------
   T* yg = reinterpret_cast<T*>(a.y);
 #if QH_V3_ABLATE & 32
   {
     float sum = 0.f;
     for (int j = 0; j < NJ; ++j)
-      for (int i = 0; i < 8; ++i) sum += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+      for (int i = 0; i < MI; ++i) sum += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
     if (sum == 1.2345f) yg[0] = E::from_f32(sum);
     return;
   }
@@ -303,12 +315,14 @@ __global__ void __launch_bounds__(128 * WN, 1) qbytes_mfma_large_kernel(const Ar
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  uint8_t* park = smem + wave * (128 * 128);
+  constexpr int JP = NJ < 4 ? NJ : 4;  // feature fragments per pass: parked rows of JP*32 bytes
+  constexpr int ROWB = JP * 32, LPR = ROWB / 16;  // lanes per parked row on the read side
+  uint8_t* park = smem + wave * (MI * 16 * ROWB);
 #pragma unroll
-  for (int p = 0; p < NJ / 4; ++p) {
+  for (int p = 0; p < NJ / JP; ++p) {
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int j = p * 4 + jj;
+    for (int jj = 0; jj < JP; ++jj) {
+      const int j = p * JP + jj;
       const int nb = n0 + wn * (NJ * 16) + j * 16 + (lane >> 4) * 4;
       float sc[4], bv[4];
 #pragma unroll
@@ -318,7 +332,7 @@ __global__ void __launch_bounds__(128 * WN, 1) qbytes_mfma_large_kernel(const Ar
         bv[r] = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < MI; ++i) {
         T out[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -327,18 +341,18 @@ __global__ void __launch_bounds__(128 * WN, 1) qbytes_mfma_large_kernel(const Ar
           out[r] = E::from_f32(v);
         }
         const int row = i * 16 + (lane & 15);
-        const int chunk = (jj * 4 + (lane >> 4)) ^ ((row & 7) << 1);
-        *reinterpret_cast<uint2*>(park + row * 128 + chunk * 8) = *reinterpret_cast<const uint2*>(out);
+        const int chunk = (jj * 4 + (lane >> 4)) ^ ((row & (LPR - 1)) << 1);
+        *reinterpret_cast<uint2*>(park + row * ROWB + chunk * 8) = *reinterpret_cast<const uint2*>(out);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier needed
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int row = t * 8 + (lane >> 3);
-      const int c16 = lane & 7;
-      const uint4 v = *reinterpret_cast<const uint4*>(park + row * 128 + (((c16 * 2) ^ ((row & 7) << 1)) * 8));
-      const int m = m0 + wm * 128 + row;
-      const int n = n0 + wn * (NJ * 16) + p * 64 + c16 * 8;
+    for (int t = 0; t < MI * 16 * LPR / 64; ++t) {
+      const int row = t * (64 / LPR) + lane / LPR;
+      const int c16 = lane % LPR;
+      const uint4 v = *reinterpret_cast<const uint4*>(park + row * ROWB + (((c16 * 2) ^ ((row & (LPR - 1)) << 1)) * 8));
+      const int m = m0 + wm * (MI * 16) + row;
+      const int n = n0 + wn * (NJ * 16) + p * (JP * 16) + c16 * 8;
 #if QH_V3_ABLATE & 16
       if (v.x == 0x12345678u) *reinterpret_cast<uint4*>(yg + (size_t)m * N + n) = v;
       else
@@ -359,20 +373,23 @@ __global__ void __launch_bounds__(128 * WN, 1) qbytes_mfma_large_kernel(const Ar
   QH_V3_STAMP(6);
 }
 
-int g_wn = 4;  // wave layout picked at run time (QUANTO_HIP_LARGE_WN=2 selects four 128x128 waves; experiments)
+enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2 };
+
+template <int DT, int FMT, int BM, int BN, int WM, int WN>
+static int launch_cfg(const Args& a, hipStream_t stream) {
+  constexpr int lds = STAGES * (BM * BK * 2 + BN * BK);
+  const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_mfma_large_kernel<DT, FMT, BM, BN, WM, WN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((qbytes_mfma_large_kernel<DT, FMT, BM, BN, WM, WN>), dim3(tiles), dim3(WM * WN * 64), lds, stream, a);
+  return launch_status();
+}
 
 template <int DT, int FMT>
-static int launch(const Args& a, hipStream_t stream) {
-  constexpr int lds = STAGES * STAGE_BYTES;
-  const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
-  if (g_wn == 2) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_mfma_large_kernel<DT, FMT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((qbytes_mfma_large_kernel<DT, FMT, 2>), dim3(tiles), dim3(256), lds, stream, a);
-  } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_mfma_large_kernel<DT, FMT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((qbytes_mfma_large_kernel<DT, FMT, 4>), dim3(tiles), dim3(512), lds, stream, a);
-  }
-  return launch_status();
+static int launch(const Args& a, int cfg, hipStream_t stream) {
+  if (cfg == CFG_128_4W) return launch_cfg<DT, FMT, 128, 128, 1, 4>(a, stream);
+  if (cfg == CFG_256_4W) return launch_cfg<DT, FMT, 256, 256, 2, 2>(a, stream);
+  return launch_cfg<DT, FMT, 256, 256, 2, 4>(a, stream);
 }
 
 }  // namespace lt
@@ -386,13 +403,13 @@ bool qbytes_mfma_v2_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int 
 int qbytes_mm_mfma_v2(const void* x, const void* w, const void* s, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int a_dtype,
                       int b_dtype, int out_dtype, hipStream_t stream) {
   if (!qbytes_mfma_v2_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
-  {
-    static const int wn_env = [] { const char* e = getenv("QUANTO_HIP_LARGE_WN"); return e && e[0] == '2' ? 2 : 4; }();
-    lt::g_wn = wn_env;
-  }
+  // 256-tiles when they give every CU at least ~3/8 of a tile; otherwise 128-tiles (4x the workgroups)
+  static const int forced = [] { const char* e = getenv("QUANTO_HIP_LARGE_CFG"); return e ? atoi(e) : -1; }();  // experiments
+  const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+  const int cfg = forced >= 0 ? forced : (tiles256 >= 96 ? lt::CFG_256_8W : lt::CFG_128_4W);
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
   lt::Args a{x, reinterpret_cast<const uint8_t*>(w), s, bias, y, (int)M, (int)N, (int)K};
-#define QH_CASE(DT, FMT) return lt::launch<DT, FMT>(a, stream)
+#define QH_CASE(DT, FMT) return lt::launch<DT, FMT>(a, cfg, stream)
   if (out_dtype == QUANTO_HIP_BF16) {
     if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_BF16, lt::W_I8);
     if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_BF16, lt::W_F8E4M3);
