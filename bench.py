@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: QLinear GEMM throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|northstar|cfg4] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+                    [--workload cfg2|cfg3|northstar|cfg4|w8a8|fp8a8|int4_prefill]
 
 A *step* is one pass of the hot path (one ``quanto::qbytes_mm`` / ``quanto::qbits_mm`` call through the C ABI) over
 one batch of synthetic input already resident in HBM.  The default workload is BASELINE.json ``configs[1]``:
@@ -29,7 +30,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec)
-MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/fp16 MFMA peak (fp8 non-scaled MFMA runs at the bf16 rate)
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16/fp16 MFMA peak (the non-scaled fp8 MFMA used for fp8 x fp8 runs at the bf16 rate)
+MFMA_PEAK_INT8_TOPS = 5000.0  # dense int8 MFMA peak (v_mfma_i32_16x16x64_i8)
 
 WORKLOADS = {
     # name: (kind, M, K, N, description)
@@ -37,7 +39,12 @@ WORKLOADS = {
     "cfg3": ("qbits_i4", 1, 4096, 11008, "bf16 x int4 qbits_mm, group_size=128 scale+shift, (M,K,N)=(1,4096,11008)"),
     "northstar": ("qbits_i4", 1, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, (M,K,N)=(1,4096,4096)"),
     "cfg4": ("qbytes_f8", 512, 8192, 8192, "bf16 x fp8-e4m3fn qbytes_mm, per-channel scale, (M,K,N)=(512,8192,8192)"),
+    # SURVEY.md 8f rank 1 (quantized activations) and the int4 prefill shape of the same layer size as cfg2
+    "w8a8": ("qbytes_i8i8", 4096, 4096, 4096, "int8 x int8 qbytes_mm (quantized activations), int32 accumulate, (M,K,N)=(4096,4096,4096)"),
+    "fp8a8": ("qbytes_f8f8", 4096, 4096, 4096, "fp8-e4m3fn x fp8-e4m3fn qbytes_mm (quantized activations), (M,K,N)=(4096,4096,4096)"),
+    "int4_prefill": ("qbits_i4", 4096, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, prefill (M,K,N)=(4096,4096,4096)"),
 }
+ARITH_DTYPE = {"qbytes_i8": "bf16", "qbytes_f8": "bf16", "qbits_i4": "bf16", "qbytes_i8i8": "int8", "qbytes_f8f8": "fp8"}
 
 
 def algorithmic_work(kind, M, K, N):
@@ -46,6 +53,8 @@ def algorithmic_work(kind, M, K, N):
     if kind == "qbits_i4":
         G = K // 128
         nbytes = N * K // 2 + 2 * (N * G * 2) + M * K * 2 + M * N * 2
+    elif kind in ("qbytes_i8i8", "qbytes_f8f8"):
+        nbytes = N * K + N * 2 + M * K + M * N * 2
     else:
         nbytes = N * K + N * 2 + M * K * 2 + M * N * 2
     return flops, float(nbytes)
@@ -56,6 +65,10 @@ def build_inputs(kind, M, K, N, device, n_weights, seed):
     (absmax int8 / max-min int4 of a N(0, 0.02) weight); values are random - throughput does not depend on them."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     x = torch.randn((M, K), generator=g).to(torch.bfloat16).to(device)
+    if kind == "qbytes_i8i8":
+        x = torch.randint(-127, 128, (M, K), dtype=torch.int8, generator=g).to(device)
+    elif kind == "qbytes_f8f8":
+        x = (torch.randn((M, K), generator=g) * 100).clamp(-448, 448).to(torch.float8_e4m3fn).to(device)
     sets = []
     for _ in range(n_weights):
         if kind == "qbits_i4":
@@ -63,7 +76,7 @@ def build_inputs(kind, M, K, N, device, n_weights, seed):
             scale = (torch.rand((N * K // 128, 1), generator=g) * 0.01 + 0.005).to(torch.bfloat16).to(device)
             shift = (torch.rand((N * K // 128, 1), generator=g) * 0.05 + 0.05).to(torch.bfloat16).to(device)
             sets.append((packed, scale, shift))
-        elif kind == "qbytes_i8":
+        elif kind in ("qbytes_i8", "qbytes_i8i8"):
             w = torch.randint(-127, 128, (N, K), dtype=torch.int8, generator=g).to(device)
             scale = (torch.rand((N, 1), generator=g) * 1e-3 + 5e-4).to(torch.bfloat16).to(device)
             sets.append((w, scale))
@@ -107,14 +120,23 @@ def cpu_baseline(kind, M, K, N, budget_s=12.0):
         x = O.round_to(rng.standard_normal((M, K)).astype(np.float32), "bf16")
         fn = lambda: O.qbits_mm_ref(x, packed, 4, scale, shift, 128, Ns, K, "bf16")  # noqa: E731
         Ms, sample = M, f"full call (M,K,N)=({M},{K},{Ns}), generic unpack+dequantize+matmul"
+    elif kind == "qbytes_i8i8":
+        Ms = min(M, 512)
+        a8 = rng.integers(-127, 128, size=(Ms, K), dtype=np.int8)
+        b8 = rng.integers(-127, 128, size=(N, K), dtype=np.int8)
+        scale = O.round_to(rng.random((N, 1)).astype(np.float32) * 1e-5 + 5e-6, "bf16")
+        fn = lambda: O.qbytes_int_mm_ref(a8, b8, scale, "bf16")  # noqa: E731
+        Ns, sample = N, f"first {Ms} of {M} activation rows, full weight (K,N)=({K},{N}): integer matmul + rescale per call"
     else:
         Ms = min(M, 512)
-        kindf = "e4m3fn" if kind == "qbytes_f8" else None
+        kindf = "e4m3fn" if kind in ("qbytes_f8", "qbytes_f8f8") else None
         data = rng.integers(0, 256, size=(N, K), dtype=np.uint8) if kindf else rng.integers(-127, 128, size=(N, K), dtype=np.int8)
         if kindf:
             data[(data & 0x7F) == 0x7F] = 0  # avoid NaN codes
         scale = O.round_to(rng.random((N, 1)).astype(np.float32) * 1e-3 + 5e-4, "bf16")
         x = O.round_to(rng.standard_normal((Ms, K)).astype(np.float32), "bf16")
+        if kind == "qbytes_f8f8":
+            x = O.fp8_decode(O.fp8_encode(x, "e4m3fn"), "e4m3fn")  # activations on the fp8 grid
         fn = lambda: O.qbytes_mm_ref(x, data, scale, "bf16", kindf)  # noqa: E731
         Ns, sample = N, f"first {Ms} of {M} activation rows, full weight (K,N)=({K},{N}): dequantize + matmul per call"
     fn()  # warm-up
@@ -209,8 +231,9 @@ def main():
             value = flops * world / (elapsed / args.steps) / 1e12
             metric, unit = "QLinear GEMM TFLOP/s (bf16 x int8 qbytes_mm)" if kind == "qbytes_i8" else "QLinear GEMM TFLOP/s", "TFLOP/s"
             achieved = flops / (launch_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None}
+            peak = MFMA_PEAK_INT8_TOPS if kind == "qbytes_i8i8" else MFMA_PEAK_TFLOPS
+            roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": None}
         else:
             value = nbytes * world / (elapsed / args.steps) / 1e9
             metric, unit = "QLinear GEMM GB/s (bf16 x int4 qbits_mm, decode)", "GB/s"
@@ -227,7 +250,7 @@ def main():
         out = {
             "metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": ARITH_DTYPE[kind], "data": "synthetic",
             "config": {"workload": desc, "M": M, "K": K, "N": N, "weight_buffers_rotated": n_weights, "launch": "eager" if args.eager else "hipGraph replay of the K steps",
                        "parallelism": f"replicas x{world} (no data-path collective)"},
             "tflops": round(flops * world / (elapsed / args.steps) / 1e12, 3),

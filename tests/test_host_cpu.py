@@ -46,7 +46,9 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.quanto_hip_unpack(None, None, 16, 4, None) == -1  # null pointers
     lib.quanto_hip_qbits_mm_workspace_size.restype = ctypes.c_int64
     lib.quanto_hip_qbits_mm_workspace_size.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 4
-    assert lib.quanto_hip_qbits_mm_workspace_size(4096, 4096, 4096, 4, 128, 2, 0) == 32 * 4096 * 4
+    assert lib.quanto_hip_qbits_mm_workspace_size(4096, 4096, 4096, 4, 128, 2, 0) == 4096 * 4096 * 2  # prefill: dequantized weight
+    assert lib.quanto_hip_qbits_mm_workspace_size(4096, 4096, 4096, 4, 128, 2, 3) == 32 * 4096 * 4  # kernel MFMA: per-group row sums of x
+    assert lib.quanto_hip_qbits_mm_workspace_size(128, 256, 4096, 4, 128, 2, 0) == 32 * 128 * 4  # too few tiles for the dense path
     assert lib.quanto_hip_qbits_mm_workspace_size(64, 4096, 4096, 4, 128, 2, 0) == 0  # streaming MFMA kernel needs no scratch
     assert lib.quanto_hip_qbits_mm_workspace_size(4, 4096, 4096, 4, 128, 2, 0) == 0
     assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 4, 128, 2, 0) == 0  # GEMV needs none
