@@ -154,6 +154,22 @@ enum quanto_hip_scale_mode { QUANTO_HIP_SCALE_PER_TENSOR = 0, QUANTO_HIP_SCALE_A
 int quanto_hip_quantize_symmetric(const void* base, const void* scale, void* out, int64_t numel, int64_t inner,
                                   int scale_mode, int in_dtype, int out_dtype, void* stream);
 
+/*
+ * quanto::quantize_affine(Tensor base, int bits, int axis, int? group_size, Tensor scale, Tensor shift) -> Tensor, axis 0
+ *   replaces library/quantize.py:66-78 (add/div, round, clamp, cast passes) at freeze / dynamic-quantization time.
+ * base: dtype[N*K] (row-major [N, K]); scale: dtype[N*K/C]; shift: dtype[N*K/C] (float shift) or U8/I8 (zero-point), with
+ * C = group_size, or K when group_size == 0 (per-channel).  out: uint8[N*K] = the grouped matrix [N*K/C, C] of values in
+ * [0, 2^bits), bit-identical to the reference sequence in every dtype.
+ */
+int quanto_hip_quantize_affine(const void* base, const void* scale, const void* shift, uint8_t* out, int64_t N, int64_t K,
+                               int bits, int group_size, int dtype, int shift_dtype, void* stream);
+
+/*
+ * pack_weights (tensor/packed.py:24-69): packed[r, c] = OR_i unpacked[r + i*row_dim, c] << (bits*i), row_dim = ceil(rows / (8/bits)).
+ * unpacked: uint8[rows, cols]; packed: uint8[row_dim, cols].  Inverse of quanto_hip_unpack (+ the trailing-row trim).
+ */
+int quanto_hip_pack(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int64_t cols, int bits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

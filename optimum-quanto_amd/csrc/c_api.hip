@@ -24,6 +24,8 @@ int qbytes_mm_mfma(const void*, const void*, const void*, const void*, void*, in
 bool qbytes_mfma_v2_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_mfma_v2(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 int quantize_symmetric(const void*, const void*, void*, int64_t, int64_t, int, int, int, hipStream_t);
+int quantize_affine(const void*, const void*, const void*, void*, int64_t, int64_t, int, int, bool, hipStream_t);
+int pack_weights(const uint8_t*, uint8_t*, int64_t, int64_t, int, hipStream_t);
 bool dense_mm_large_supported(int64_t, int64_t, int64_t, int);
 int dense_mm_large(const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, hipStream_t);
 bool qbytes_native8_supported(int64_t, int64_t, int64_t, int, int, int);
@@ -232,6 +234,24 @@ int quanto_hip_quantize_symmetric(const void* base, const void* scale, void* out
   if (numel == 0) return QUANTO_HIP_OK;
   if (!base || !scale || !out) return QUANTO_HIP_EINVAL;
   return quantize_symmetric(base, scale, out, numel, inner, scale_mode, in_dtype, out_dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+int quanto_hip_quantize_affine(const void* base, const void* scale, const void* shift, uint8_t* out, int64_t N, int64_t K, int bits,
+                               int group_size, int dtype, int shift_dtype, void* stream) {
+  bool int_shift = false;
+  const int st = check_qbits(1, N, K, bits, group_size, dtype, shift_dtype, &int_shift);
+  if (st != QUANTO_HIP_OK) return st;
+  if (!base || !scale || !shift || !out) return QUANTO_HIP_EINVAL;
+  const int64_t C = group_size > 0 ? group_size : K;
+  return quantize_affine(base, scale, shift, out, N * K, C, bits, dtype, int_shift, reinterpret_cast<hipStream_t>(stream));
+}
+
+int quanto_hip_pack(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int64_t cols, int bits, void* stream) {
+  if (bits != 2 && bits != 4) return QUANTO_HIP_EINVAL;
+  if (rows < 0 || cols < 0) return QUANTO_HIP_EINVAL;
+  if (rows == 0 || cols == 0) return QUANTO_HIP_OK;
+  if (!unpacked || !packed) return QUANTO_HIP_EINVAL;
+  return pack_weights(unpacked, packed, rows, cols, bits, reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -140,6 +140,63 @@ int launch_out(const void* x, const void* s, void* out, int64_t numel, int64_t i
   return QUANTO_HIP_ENOTSUP;
 }
 
+// ---- quanto::quantize_affine for axis-0 weights: uint8 in [0, 2^bits) per element of the grouped matrix ---------------------
+// (library/quantize.py:66-78).  Grouping along axis 0 is a pure reshape ([N,K] -> [N*K/C, C], tensor/grouped.py:17-39), so
+// element i uses scale/shift entry i / C.  float shift: round(round_T(round_T(base + shift) / scale)); integer zero-point:
+// round(round_T(base / scale)) + zp; both clamped to [0, 2^bits - 1] - every intermediate rounded to T like the torch sequence.
+template <int IDT, bool INT_SHIFT>
+__global__ void __launch_bounds__(256) quantize_affine_kernel(const typename Elem<IDT>::T* __restrict__ x,
+                                                              const typename Elem<IDT>::T* __restrict__ scale, const void* __restrict__ shift,
+                                                              uint8_t* __restrict__ out, int64_t numel, int64_t C, float qmax) {
+  using E = Elem<IDT>;
+  using T = typename E::T;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i0 < numel; i0 += stride) {
+    uint32_t word = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = i0 + k;
+      if (i < numel) {
+        const int64_t r = i / C;
+        const float s = E::to_f32(scale[r]);
+        float q;
+        if constexpr (INT_SHIFT) {
+          const float zp = (float)(int8_t) reinterpret_cast<const uint8_t*>(shift)[r];
+          q = __builtin_rintf(E::to_f32(E::from_f32(E::to_f32(x[i]) / s))) + zp;
+          q = E::to_f32(E::from_f32(q));
+        } else {
+          const float z = E::to_f32(reinterpret_cast<const T*>(shift)[r]);
+          float t = E::to_f32(E::from_f32(E::to_f32(x[i]) + z));
+          q = __builtin_rintf(E::to_f32(E::from_f32(t / s)));
+        }
+        q = __builtin_fminf(__builtin_fmaxf(q, 0.f), qmax);
+        word |= ((uint32_t)(int)q & 0xFFu) << (8 * k);
+      }
+    }
+    if (i0 + 3 < numel && (reinterpret_cast<uintptr_t>(out + i0) & 3) == 0) {
+      *reinterpret_cast<uint32_t*>(out + i0) = word;
+    } else {
+      for (int k = 0; k < 4 && i0 + k < numel; ++k) out[i0 + k] = (uint8_t)(word >> (8 * k));
+    }
+  }
+}
+
+// ---- pack_weights (tensor/packed.py:24-69): packed[r, c] = OR_i unpacked[r + i*row_dim, c] << (bits*i) -------------------------
+__global__ void __launch_bounds__(256) pack_kernel(const uint8_t* __restrict__ u, uint8_t* __restrict__ p, int64_t rows, int64_t cols,
+                                                   int64_t row_dim, int bits) {
+  const int64_t total = row_dim * cols;
+  const int vpi = 8 / bits;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    uint32_t v = 0;
+    for (int k = 0; k < vpi; ++k) {
+      const int64_t rr = r + k * row_dim;
+      if (rr < rows) v |= (uint32_t)u[rr * cols + (i - r * cols)] << (bits * k);
+    }
+    p[i] = (uint8_t)v;
+  }
+}
+
 }  // namespace
 
 int quantize_symmetric(const void* x, const void* s, void* out, int64_t numel, int64_t inner, int mode, int in_dtype, int out_dtype,
@@ -151,6 +208,40 @@ int quantize_symmetric(const void* x, const void* s, void* out, int64_t numel, i
     case QUANTO_HIP_BF16: return launch_out<QUANTO_HIP_BF16>(x, s, out, numel, inner, mode, out_dtype, stream);
   }
   return QUANTO_HIP_ENOTSUP;
+}
+
+int quantize_affine(const void* x, const void* scale, const void* shift, void* out, int64_t numel, int64_t C, int bits, int dtype,
+                    bool int_shift, hipStream_t stream) {
+  int64_t blocks = (numel / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  const float qmax = (float)((1 << bits) - 1);
+  uint8_t* op = reinterpret_cast<uint8_t*>(out);
+#define QH_QA(DT)                                                                                                               \
+  if (int_shift)                                                                                                                \
+    hipLaunchKernelGGL((quantize_affine_kernel<DT, true>), dim3(blocks), dim3(256), 0, stream,                                  \
+                       reinterpret_cast<const Elem<DT>::T*>(x), reinterpret_cast<const Elem<DT>::T*>(scale), shift, op, numel, C, qmax); \
+  else                                                                                                                          \
+    hipLaunchKernelGGL((quantize_affine_kernel<DT, false>), dim3(blocks), dim3(256), 0, stream,                                 \
+                       reinterpret_cast<const Elem<DT>::T*>(x), reinterpret_cast<const Elem<DT>::T*>(scale), shift, op, numel, C, qmax)
+  switch (dtype) {
+    case QUANTO_HIP_F32: QH_QA(QUANTO_HIP_F32); break;
+    case QUANTO_HIP_F16: QH_QA(QUANTO_HIP_F16); break;
+    case QUANTO_HIP_BF16: QH_QA(QUANTO_HIP_BF16); break;
+    default: return QUANTO_HIP_ENOTSUP;
+  }
+#undef QH_QA
+  return launch_status();
+}
+
+int pack_weights(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int64_t cols, int bits, hipStream_t stream) {
+  const int vpi = 8 / bits;
+  const int64_t row_dim = (rows + vpi - 1) / vpi;
+  int64_t blocks = (row_dim * cols + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, stream, unpacked, packed, rows, cols, row_dim, bits);
+  return launch_status();
 }
 
 }  // namespace qh

@@ -72,6 +72,10 @@ class _Bindings:
         c.quanto_hip_qbytes_mm.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, ci, ci, vp]
         c.quanto_hip_quantize_symmetric.restype = ci
         c.quanto_hip_quantize_symmetric.argtypes = [vp, vp, vp, i64, i64, ci, ci, ci, vp]
+        c.quanto_hip_quantize_affine.restype = ci
+        c.quanto_hip_quantize_affine.argtypes = [vp, vp, vp, vp, i64, i64, ci, ci, ci, ci, vp]
+        c.quanto_hip_pack.restype = ci
+        c.quanto_hip_pack.argtypes = [vp, vp, i64, i64, ci, vp]
         self._c = c
         if c.quanto_hip_abi_version() != 1:
             raise QuantoHipError("libquanto_hip.so ABI version mismatch: rebuild with __graft_entry__.build()")
@@ -116,6 +120,34 @@ class _Bindings:
             st = self._c.quanto_hip_quantize_symmetric(_ptr(base), _ptr(scale), _ptr(out), base.numel(), inner, mode, _dt(base),
                                                        _dt(out), self._stream(base))
         self._check(st, "quantize_symmetric")
+        return out
+
+    def quantize_affine(self, base: torch.Tensor, bits: int, group_size, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+        """Axis-0 2-D weights only: uint8 grouped matrix [N*K/C, C] (C = group_size or K)."""
+        self._require_cuda(base, scale, shift)
+        N, K = base.shape
+        base = base.contiguous()
+        scale = scale.to(base.dtype).contiguous()
+        shift = shift.contiguous() if not shift.dtype.is_floating_point else shift.to(base.dtype).contiguous()
+        C = group_size or K
+        out = torch.empty((N * K // C, C), dtype=torch.uint8, device=base.device)
+        with torch.cuda.device(base.device):
+            st = self._c.quanto_hip_quantize_affine(_ptr(base), _ptr(scale), _ptr(shift), _ptr(out), N, K, bits, group_size or 0,
+                                                    _dt(base), _dt(shift), self._stream(base))
+        self._check(st, "quantize_affine")
+        return out
+
+    def pack(self, t: torch.Tensor, bits: int) -> torch.Tensor:
+        self._require_cuda(t)
+        if t.dtype not in (torch.uint8, torch.int8):
+            raise QuantoHipError("pack expects an 8-bit integer tensor")
+        t = t.contiguous().view(torch.uint8)
+        rows = t.shape[0]
+        cols = t.numel() // rows if rows else 0
+        row_dim = (rows + 8 // bits - 1) // (8 // bits)
+        out = torch.empty((row_dim,) + tuple(t.shape[1:]), dtype=torch.uint8, device=t.device)
+        with torch.cuda.device(t.device):
+            self._check(self._c.quanto_hip_pack(_ptr(t), _ptr(out), rows, cols, bits, self._stream(t)), "pack")
         return out
 
     # -- quanto::unpack ---------------------------------------------------------------------------

@@ -198,8 +198,25 @@ if _define("quantize_symmetric", "(Tensor base, ScalarType dtype, int? axis, Ten
     _impl("quantize_symmetric", "CUDA", quantize_symmetric_hip, True)
 else:
     _impl("quantize_symmetric", "CUDA", quantize_symmetric_hip, False)
+def quantize_affine_hip(base: torch.Tensor, bits: int, axis: int, group_size: Union[int, None], scale: torch.Tensor,
+                        shift: torch.Tensor) -> torch.Tensor:
+    """Device tensors: the one-pass kernel (csrc/quantize.hip) for the layout of the hot path - axis-0 2-D weights with
+    one scale/shift per group; every other case keeps the torch sequence on the device."""
+    if axis not in (0, -1):
+        raise ValueError("axis parameter must be 0 (first axis) or -1 (last axis)")
+    if (axis == 0 and base.ndim == 2 and bits in (2, 4) and base.dtype in (torch.float32, torch.float16, torch.bfloat16)
+            and (group_size is None or base.shape[1] % group_size == 0)):
+        rows = base.numel() // (group_size or base.shape[1])
+        if scale.numel() == rows and shift.numel() == rows and shift.dtype in (base.dtype, torch.uint8, torch.int8):
+            return quanto_hip.lib.quantize_affine(base, bits, group_size, scale, shift)
+    return quantize_affine(base, bits, axis, group_size, scale, shift)
+
+
 if _define("quantize_affine", "(Tensor base, int bits, int axis, int? group_size, Tensor scale, Tensor shift) -> Tensor"):
     _impl("quantize_affine", "CompositeExplicitAutograd", quantize_affine, True)
+    _impl("quantize_affine", "CUDA", quantize_affine_hip, True)
+else:
+    _impl("quantize_affine", "CUDA", quantize_affine_hip, False)
 
 
 # ------------------------------------------------------------------------------------------------

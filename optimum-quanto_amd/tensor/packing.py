@@ -18,6 +18,10 @@ def pack_weights(intweights: torch.Tensor, bits: int) -> torch.Tensor:
     """Pack 2-bit or 4-bit values stored one per byte into a ``torch.uint8`` tensor."""
     if bits not in (2, 4):
         raise ValueError("bits must be 2 or 4")
+    if intweights.is_cuda and intweights.ndim >= 1 and intweights.numel() > 0:
+        from ..library.hip import quanto_hip  # one pass on the device (csrc/quantize.hip::pack_kernel); raises if the library is missing
+
+        return quanto_hip.lib.pack(intweights, bits)
     vpi = 8 // bits
     rows = intweights.shape[0]
     row_dim = -(-rows // vpi)

@@ -294,3 +294,57 @@ def test_qactivation_qweight_linear_reference_grid(batch_size, tokens, embedding
     qout = torch.nn.functional.linear(qx, qw, bias)
     out = torch.nn.functional.linear(qx.dequantize(), qw.dequantize(), bias)
     assert_similar(out, qout)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU: fused quantize_affine / pack (freeze-time half of SURVEY.md 8f rank 2) vs the reference-pinned oracle, bit-exact
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("bits", [2, 4])
+@pytest.mark.parametrize("zeropoint", [False, True])
+@pytest.mark.parametrize("N,K,gs", [(48, 256, 128), (33, 96, 32), (256, 4096, 128), (10, 50, None), (64, 64, 64), (7, 128, 64)])
+def test_hip_quantize_affine_and_pack_bit_exact(N, K, gs, zeropoint, bits, dt):
+    rng = np.random.default_rng(N + K + bits)
+    w = O.round_to((rng.standard_normal((N, K)) * 0.05).astype(np.float32), dt)
+    scale, shift = O.max_scale_shift(w, bits, 0, gs, dt)
+    if zeropoint:
+        shift = np.clip(np.rint(O.round_to(shift / scale, dt)), 0, 2**bits - 1).astype(np.uint8)
+    want = O.quantize_affine(w, bits, 0, gs, scale, shift, dt)
+    tshift = torch.from_numpy(shift).to(DEV) if zeropoint else to_torch(shift, dt, DEV)
+    got = torch.ops.quanto.quantize_affine(to_torch(w, dt, DEV), bits, 0, gs, to_torch(scale, dt, DEV), tshift)
+    assert got.dtype == torch.uint8 and tuple(got.shape) == want.shape
+    np.testing.assert_array_equal(to_numpy(got), want)
+    from optimum_quanto_amd.tensor.packing import PackedTensor, pack_weights
+
+    packed = pack_weights(got, bits)
+    np.testing.assert_array_equal(to_numpy(packed), O.pack_weights(want, bits))
+    pt = PackedTensor.pack(got, bits)
+    np.testing.assert_array_equal(to_numpy(pt.unpack()), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [2, 4])
+@pytest.mark.parametrize("shape", [(10,), (12,), (10, 10), (12, 10), (32, 32), (7, 5), (1, 3), (256, 128)])
+def test_hip_pack_golden(golden, bits, shape):
+    """tests/tensor/test_packed_tensor.py:24-36 shapes (incl. first dims that are not a multiple of 8/bits), on the device."""
+    from optimum_quanto_amd.tensor.packing import pack_weights
+
+    key = f"pack/b{bits}/" + "x".join(map(str, shape))
+    a = torch.from_numpy(golden[key + "/a"]).to(DEV)
+    np.testing.assert_array_equal(to_numpy(pack_weights(a, bits)), golden[key + "/packed"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("wname", ["qint4", "qint2"])
+def test_device_side_freeze_matches_cpu_freeze(wname, dt):
+    """quantize_weight on the device (fused affine quantize + pack) produces the very bytes the CPU path produces."""
+    torch.manual_seed(3)
+    w = (torch.randn(96, 256) * 0.05).to(TORCH_DT[dt])
+    qt = Q.qtypes[wname]
+    scale, shift = Q.MaxOptimizer()(w, qtype=qt, axis=0, group_size=128)
+    cpu = Q.quantize_weight(w, qtype=qt, axis=0, scale=scale, shift=shift, group_size=128)
+    dev = Q.quantize_weight(w.to(DEV), qtype=qt, axis=0, scale=scale.to(DEV), shift=shift.to(DEV), group_size=128)
+    assert torch.equal(dev._data._data.cpu(), cpu._data._data)
+    assert torch.equal(dev.dequantize().cpu(), cpu.dequantize())
