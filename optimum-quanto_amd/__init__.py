@@ -12,4 +12,5 @@ from .nn import *
 from .model_api import *
 from .calibrate import *
 from .models import *
+from .checkpoint import *
 from . import parallel  # noqa: E402,F401  (column shard over RCCL / gloo)

@@ -11,6 +11,7 @@ from typing import Any, List, Optional, Union
 
 import torch
 
+from .checkpoint import load_state_dict_to_device, save_sharded_state_dict
 from .model_api import freeze, quantization_map, quantize, requantize
 from .nn import QModuleMixin
 from .tensor import Optimizer, qtype
@@ -18,7 +19,6 @@ from .tensor import Optimizer, qtype
 __all__ = ["QuantizedTransformersModel", "QuantizedModelForCausalLM"]
 
 _QMAP_NAME = "quanto_qmap.json"
-_WEIGHTS_NAME = "model.safetensors"
 
 
 class QuantizedTransformersModel:
@@ -55,8 +55,7 @@ class QuantizedTransformersModel:
         freeze(model)
         return cls(model)
 
-    def save_pretrained(self, save_directory: Union[str, os.PathLike]) -> None:
-        from safetensors.torch import save_file
+    def save_pretrained(self, save_directory: Union[str, os.PathLike], max_shard_size: Optional[int] = None) -> None:
 
         model = self._wrapped
         os.makedirs(save_directory, exist_ok=True)
@@ -67,7 +66,7 @@ class QuantizedTransformersModel:
         state = {k: v.contiguous().cpu() for k, v in model.state_dict().items()}
         if getattr(model.config, "tie_word_embeddings", False) and model.get_output_embeddings() is not None:
             state.pop("lm_head.weight", None)  # shared storage: safetensors refuses aliases
-        save_file(state, os.path.join(save_directory, _WEIGHTS_NAME), metadata={"format": "pt"})
+        save_sharded_state_dict(state, str(save_directory), max_shard_size)
         with open(os.path.join(save_directory, _QMAP_NAME), "w", encoding="utf8") as f:
             json.dump(quantization_map(model), f, indent=4)
 
@@ -76,7 +75,6 @@ class QuantizedTransformersModel:
         if cls.auto_class is None:
             raise ValueError("use a specialized class such as QuantizedModelForCausalLM to reload a quantized model")
         from accelerate import init_empty_weights
-        from safetensors.torch import load_file
         from transformers import AutoConfig
 
         path = str(pretrained_model_name_or_path)
@@ -90,10 +88,8 @@ class QuantizedTransformersModel:
         config = AutoConfig.from_pretrained(path)
         with init_empty_weights():
             model = cls.auto_class().from_config(config)
-        weights = os.path.join(path, _WEIGHTS_NAME)
-        if not os.path.exists(weights):
-            raise ValueError(f"No safetensor weights found in {path}.")
-        requantize(model, state_dict=load_file(weights), quantization_map=qmap, device=device)
+        # shards are read straight onto `device` (checkpoint.py): no CPU staging copy of the quantized weights
+        requantize(model, state_dict=load_state_dict_to_device(path, device), quantization_map=qmap, device=device)
         if getattr(model.config, "tie_word_embeddings", True):
             model.tie_weights()
         model.eval()
