@@ -28,6 +28,10 @@
                         // 16 no output stores, 32 no epilogue at all
 #endif
 
+#ifndef QH_DMA_STEPS
+#define QH_DMA_STEPS 6
+#endif
+
 namespace qh {
 namespace lt {
 
@@ -134,8 +138,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   constexpr int WPIECES = BN / 16 / NWAVES;     // weight DMA pieces (16 rows x 64 B) per wave and K-tile
   constexpr int NPIECES = APIECES + WPIECES;
   constexpr int ND = (NJ * 4 + MI - 1) / MI;    // converted dwords per step (one phase converts NJ*4 dwords in MI steps)
-  constexpr int PPS = NPIECES / 6;              // DMA pieces per step over the first six steps
-  static_assert(NPIECES % 6 == 0 && STEPS % 4 == 0 && ND <= NJ && PPS <= NJ, "unsupported tile configuration");
+  constexpr int DSTEPS = QH_DMA_STEPS;          // the DMA of tile kt+2 is issued over the first DSTEPS steps of tile kt
+  constexpr int PPS = NPIECES / DSTEPS;         // pieces per step
+  static_assert(NPIECES % DSTEPS == 0 && STEPS % 4 == 0 && ND <= NJ && PPS <= NJ, "unsupported tile configuration");
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
@@ -277,13 +282,17 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
             if (s == (4 * f + 3) / ND + 1) raw[f] = read_raw(sn, f);
 #endif
         }
-        if (DMA && !(QH_V3_ABLATE & 4) && j >= NJ - PPS && s < 6) issue_piece(kt + 2, nxt2, PPS * s + (j - (NJ - PPS)));
+        if (DMA && !(QH_V3_ABLATE & 4) && j >= NJ - PPS && s < DSTEPS) issue_piece(kt + 2, nxt2, PPS * s + (j - (NJ - PPS)));
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (BARRIER && !(QH_V3_ABLATE & 8)) {
-      // tile boundary: own DMA share of tile kt+1 landed (issued one tile ago) -> barrier -> everybody's share visible and
-      // every wave done with tile kt, whose stage the next tile refills
+      // tile boundary: the own DMA share of tile kt+2, issued in the first steps of this tile, has landed -> barrier ->
+      // everybody's share visible and every wave done with tile kt, whose stage the next tile refills.  vmcnt(0), not
+      // "all but the newest pieces": tile kt+1 prefetches its successor's weight bytes and first activation fragments
+      // out of that stage while it runs, so tile kt+2 must be complete before tile kt+1 starts.  Tried and rejected:
+      // five 24 KiB stages for the 128-tile (one workgroup per CU instead of two: 110 us vs 86 us on cfg4) and a
+      // three-step activation prefetch distance (cfg4 95 -> 119 us, 4096^3 unchanged).
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -387,6 +396,7 @@ static int launch_cfg(const Args& a, hipStream_t stream) {
 
 template <int DT, int FMT>
 static int launch(const Args& a, int cfg, hipStream_t stream) {
+  // three 24 KiB stages: two workgroups share a CU (two interleaving streams per SIMD)
   if (cfg == CFG_128_4W) return launch_cfg<DT, FMT, 128, 128, 1, 4>(a, stream);
   if (cfg == CFG_256_4W) return launch_cfg<DT, FMT, 256, 256, 2, 2>(a, stream);
   return launch_cfg<DT, FMT, 256, 256, 2, 4>(a, stream);
