@@ -18,14 +18,14 @@
 // LDS images are linear per DMA instruction; bank-conflict swizzles are applied to the DMA source address and undone on
 // the fragment reads: weights (128-byte rows, 8 chunks) chunk ^ (row & 7); activations (256-byte rows, 16 chunks)
 // chunk ^ (row & 15).
+#include <cstdlib>
+
 #include "qh_common.h"
 
 namespace qh {
 namespace skinny {
 
-constexpr int BK = 128;             // byte-columns (= k) per tile = one group
-constexpr int ROWS = 32;            // packed rows per block (64 output features)
-constexpr int W_BYTES = ROWS * BK;  // 4 KiB
+constexpr int BK = 128;  // byte-columns (= k) per tile = one group
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -86,11 +86,16 @@ struct Args {
   int M, N, K, G;
 };
 
-template <int DT, int TF, int STAGES, bool INT_SHIFT>
-__global__ void __launch_bounds__(256) qbits_skinny_kernel(const Args a) {
+// WAVES per block: 4 (64 features per block), 2 or 1 (16 features) - narrower blocks when N/64 blocks cannot occupy the chip
+// (N = 4096: 64 -> 256 blocks); every block streams the whole activation tile, so narrow blocks trade L2 traffic for CUs.
+template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) {
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
+  constexpr int ROWS = 8 * WAVES;     // packed rows per block (2*ROWS output features)
+  constexpr int W_BYTES = ROWS * BK;  // 1 KiB per wave
+  constexpr int XP = TF * 4 / WAVES;  // 1 KiB activation DMA pieces per wave and tile
   constexpr int X_BYTES = TF * 16 * BK * 2;
   constexpr int STAGE_BYTES = W_BYTES + X_BYTES;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -111,11 +116,11 @@ __global__ void __launch_bounds__(256) qbits_skinny_kernel(const Args a) {
     const int r = lane >> 3, c = (lane & 7) ^ (r & 7);
     wsrc = a.w + (size_t)(p0 + wave * 8 + r) * K + c * 16;
   }
-  // activations: TF KiB-instructions per wave; instruction u covers tile rows 4*(wave*TF+u) .. +3
-  const uint8_t* xsrc[TF];
+  // activations: XP KiB-instructions per wave; instruction u covers tile rows 4*(wave*XP+u) .. +3
+  const uint8_t* xsrc[XP];
 #pragma unroll
-  for (int u = 0; u < TF; ++u) {
-    const int row = 4 * (wave * TF + u) + (lane >> 4);
+  for (int u = 0; u < XP; ++u) {
+    const int row = 4 * (wave * XP + u) + (lane >> 4);
     const int c = (lane & 15) ^ (row & 15);
     const int m = row < M ? row : M - 1;
     xsrc[u] = reinterpret_cast<const uint8_t*>(reinterpret_cast<const T*>(a.x) + (size_t)m * K + c * 8);
@@ -125,7 +130,7 @@ __global__ void __launch_bounds__(256) qbits_skinny_kernel(const Args a) {
     const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
     glds16(wsrc + (size_t)kt * BK, st + wave * 1024);
 #pragma unroll
-    for (int u = 0; u < TF; ++u) glds16(xsrc[u] + (size_t)kt * (BK * 2), st + W_BYTES + (wave * TF + u) * 1024);
+    for (int u = 0; u < XP; ++u) glds16(xsrc[u] + (size_t)kt * (BK * 2), st + W_BYTES + (wave * XP + u) * 1024);
   };
 #pragma unroll
   for (int t = 0; t < STAGES - 2; ++t)
@@ -133,15 +138,16 @@ __global__ void __launch_bounds__(256) qbits_skinny_kernel(const Args a) {
 
   // ---- park scale / (shift + OFFSET*scale) of the block's 64 features and the XS rows in LDS ---------------------
   // sz[g][0][f] = scale, sz[g][1][f] = shift (zero-points converted to T: small integers are exact),
-  // f = plane*32 + local packed row (0..31); kept in the 16-bit storage type so that K = 14336 (112 groups) fits
-  for (int e = tid; e < 64 * G; e += 256) {
+  // f = plane*ROWS + local packed row; kept in the 16-bit storage type so that K = 14336 (112 groups) fits
+  constexpr int NF = 2 * ROWS;  // features per block
+  for (int e = tid; e < NF * G; e += WAVES * 64) {
     const int f = e / G, g = e - f * G;
-    const size_t idx = (size_t)(p0 + (f & 31) + (f >> 5) * P) * G + g;
-    sz[(g * 2 + 0) * 64 + f] = reinterpret_cast<const T*>(a.scale)[idx];
+    const size_t idx = (size_t)(p0 + (f % ROWS) + (f / ROWS) * P) * G + g;
+    sz[(g * 2 + 0) * NF + f] = reinterpret_cast<const T*>(a.scale)[idx];
     if constexpr (INT_SHIFT)
-      sz[(g * 2 + 1) * 64 + f] = E::from_f32((float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[idx]);
+      sz[(g * 2 + 1) * NF + f] = E::from_f32((float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[idx]);
     else
-      sz[(g * 2 + 1) * 64 + f] = reinterpret_cast<const T*>(a.shift)[idx];
+      sz[(g * 2 + 1) * NF + f] = reinterpret_cast<const T*>(a.shift)[idx];
   }
 
   // ---- fragment read offsets ----------------------------------------------------------------------------------------
@@ -159,7 +165,7 @@ __global__ void __launch_bounds__(256) qbits_skinny_kernel(const Args a) {
     for (int t = 0; t < 4; ++t) xoff[tf][t] = W_BYTES + row * 256 + (((8 * (t >> 1) + 2 * fg + (t & 1)) ^ (row & 15)) << 4);
   }
   // this lane's 4 consecutive features inside the block: plane (fg>>1), local packed rows wave*8 + 4*(fg&1) + r
-  const int floc = (fg >> 1) * 32 + wave * 8 + 4 * (fg & 1);
+  const int floc = (fg >> 1) * ROWS + wave * 8 + 4 * (fg & 1);
 
   f32x4 acc[TF];
 #pragma unroll
@@ -203,8 +209,8 @@ __global__ void __launch_bounds__(256) qbits_skinny_kernel(const Args a) {
     }
     // fold the group: acc += s * acc_g - zz * XS
     T s4t[4], z4t[4];
-    *reinterpret_cast<uint2*>(s4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 0) * 64 + floc);
-    *reinterpret_cast<uint2*>(z4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 1) * 64 + floc);
+    *reinterpret_cast<uint2*>(s4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 0) * NF + floc);
+    *reinterpret_cast<uint2*>(z4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 1) * NF + floc);
     float s4[4], z4[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(256) qbits_skinny_kernel(const Args a) {
     // tiles kt (and kt+1) have landed when at most the DMA of the tiles younger than them is outstanding
     const int last = pair ? kt + 1 : kt;
     const int younger = nk - 1 - last < STAGES - 4 ? nk - 1 - last : STAGES - 4;
-    wait_vmcnt<(STAGES - 4) * (1 + TF), 1 + TF>(younger);
+    wait_vmcnt<(STAGES - 4) * (1 + XP), 1 + XP>(younger);
     __builtin_amdgcn_s_barrier();  // both tiles visible to all; everybody is done with the previous pair (and the tables are written)
     asm volatile("" ::: "memory");
     const int nxt = cur + 1 == STAGES ? 0 : cur + 1;
@@ -267,40 +273,61 @@ __global__ void __launch_bounds__(256) qbits_skinny_kernel(const Args a) {
   }
 }
 
-constexpr int lds_bytes(int tf, int stages, int G) { return stages * (W_BYTES + tf * 16 * BK * 2) + G * 128 * 2; }
+constexpr int lds_bytes(int tf, int stages, int G, int waves) { return stages * (waves * 8 * BK + tf * 16 * BK * 2) + G * 2 * (16 * waves) * 2; }
 
-template <int DT, int TF, int STAGES, bool INT_SHIFT>
+template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES>
 static int launch_s(const Args& a, hipStream_t stream) {
-  const int lds = lds_bytes(TF, STAGES, a.G);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT>),
+  const int lds = lds_bytes(TF, STAGES, a.G, WAVES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT>), dim3(a.N / 2 / ROWS), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES>), dim3(a.N / (16 * WAVES)), dim3(WAVES * 64), lds, stream, a);
   return launch_status();
 }
 
-// Deepest DMA pipeline that fits: the kernel is latency-bound per block (bytes in flight = stages x tile bytes)
-template <int DT, int TF, bool INT_SHIFT>
+// Deepest DMA pipeline that fits: the kernel is latency-bound per block (bytes in flight = stages x tile bytes).  Narrow
+// blocks budget for two (or three) blocks per CU.
+template <int DT, int TF, bool INT_SHIFT, int WAVES>
 static int launch(const Args& a, hipStream_t stream) {
-  constexpr int budget = 150 * 1024;
-  if (lds_bytes(TF, 8, a.G) <= budget) return launch_s<DT, TF, 8, INT_SHIFT>(a, stream);
-  if (lds_bytes(TF, 6, a.G) <= budget) return launch_s<DT, TF, 6, INT_SHIFT>(a, stream);
-  return launch_s<DT, TF, 4, INT_SHIFT>(a, stream);
+  constexpr int budget = WAVES == 4 ? 150 * 1024 : 76 * 1024;
+  constexpr int per_tile = 1 + TF * 4 / WAVES;  // DMA instructions per wave and tile; vmcnt counts at most 63 of them
+  if constexpr ((8 - 4) * per_tile <= 60)
+    if (lds_bytes(TF, 8, a.G, WAVES) <= budget) return launch_s<DT, TF, 8, INT_SHIFT, WAVES>(a, stream);
+  if constexpr ((6 - 4) * per_tile <= 60)
+    if (lds_bytes(TF, 6, a.G, WAVES) <= budget) return launch_s<DT, TF, 6, INT_SHIFT, WAVES>(a, stream);
+  return launch_s<DT, TF, 4, INT_SHIFT, WAVES>(a, stream);
+}
+
+// waves per block: as wide as possible while the grid still covers ~3/4 of the CUs
+inline int pick_waves(int N) {
+  static const int forced = [] { const char* e = getenv("QUANTO_HIP_SKINNY_WAVES"); return e ? atoi(e) : 0; }();  // experiments
+  if (forced == 1 || forced == 2 || forced == 4) return (N % (16 * forced)) == 0 ? forced : 1;
+  if (N % 64 == 0 && N / 64 >= 192) return 4;
+  if (N % 32 == 0 && N / 32 >= 192) return 2;
+  return 1;
+}
+
+template <int DT, bool INT_SHIFT, int TF>
+static int launch_waves(const Args& a, hipStream_t stream) {
+  const int w = pick_waves(a.N);
+  if (w == 4) return launch<DT, TF, INT_SHIFT, 4>(a, stream);
+  if (w == 2) return launch<DT, TF, INT_SHIFT, 2>(a, stream);
+  return launch<DT, TF, INT_SHIFT, 1>(a, stream);
 }
 
 template <int DT, bool INT_SHIFT>
 static int launch_tf(const Args& a, hipStream_t stream) {
-  if (a.M <= 16) return launch<DT, 1, INT_SHIFT>(a, stream);
-  if (a.M <= 32) return launch<DT, 2, INT_SHIFT>(a, stream);
-  return launch<DT, 4, INT_SHIFT>(a, stream);
+  if (a.M <= 16) return launch_waves<DT, INT_SHIFT, 1>(a, stream);
+  if (a.M <= 32) return launch_waves<DT, INT_SHIFT, 2>(a, stream);
+  return launch_waves<DT, INT_SHIFT, 4>(a, stream);
 }
 
 }  // namespace skinny
 
 bool qbits_skinny_supported(int64_t M, const PackedGeom& g, int dtype) {
   const int tf = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
-  return g.bits == 4 && g.C == 128 && (g.N % 64 == 0) && (g.K % 128 == 0) && M >= 1 && M <= QUANTO_HIP_SKINNY_MAX_M &&
+  return g.bits == 4 && g.C == 128 && (g.N % 16 == 0) && (g.K % 128 == 0) && M >= 1 && M <= QUANTO_HIP_SKINNY_MAX_M &&
          (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30) && g.K < (1 << 30) &&
-         skinny::lds_bytes(tf, 4, (int)g.G) <= 160 * 1024;
+         skinny::lds_bytes(tf, 4, (int)g.G, skinny::pick_waves((int)g.N)) <= 160 * 1024;
 }
 
 size_t qbits_skinny_workspace(int64_t, const PackedGeom&) { return 0; }
