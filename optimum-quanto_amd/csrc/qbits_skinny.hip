@@ -86,8 +86,7 @@ struct Args {
   int M, N, K, G;
 };
 
-// WAVES per block: 4 (64 features per block), 2 or 1 (16 features) - narrower blocks when N/64 blocks cannot occupy the chip
-// (N = 4096: 64 -> 256 blocks); every block streams the whole activation tile, so narrow blocks trade L2 traffic for CUs.
+// WAVES per block: 4 (64 features per block), 2 or 1 (16 features) - so that any N that is a multiple of 16 is served.
 template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) {
   using E = Elem<DT>;
@@ -297,13 +296,13 @@ static int launch(const Args& a, hipStream_t stream) {
   return launch_s<DT, TF, 4, INT_SHIFT, WAVES>(a, stream);
 }
 
-// waves per block: as wide as possible while the grid still covers ~3/4 of the CUs
+// waves per block: the widest that divides N.  Narrower blocks do not help small N (measured, N = 4096, M = 32: 4 waves
+// 21.9 us, 2 waves 21.8 us, 1 wave 26.1 us): the kernel is bound by the instruction stream of the single wave each SIMD gets,
+// not by the number of occupied CUs - what it lacks for N <= 4096 is K-parallelism.
 inline int pick_waves(int N) {
   static const int forced = [] { const char* e = getenv("QUANTO_HIP_SKINNY_WAVES"); return e ? atoi(e) : 0; }();  // experiments
   if (forced == 1 || forced == 2 || forced == 4) return (N % (16 * forced)) == 0 ? forced : 1;
-  if (N % 64 == 0 && N / 64 >= 192) return 4;
-  if (N % 32 == 0 && N / 32 >= 192) return 2;
-  return 1;
+  return N % 64 == 0 ? 4 : (N % 32 == 0 ? 2 : 1);
 }
 
 template <int DT, bool INT_SHIFT, int TF>

@@ -117,7 +117,24 @@ struct Args {
   const void* bias;
   void* y;
   int M, N, K;
+  int group_m;  // tile raster: groups of group_m tile rows, column-major inside a group (see tile_coords)
 };
+
+// XCD-aware tile order.  Consecutive workgroup ids land on different XCDs (id % 8), so first give every XCD a contiguous
+// band of tile indices; inside the index space walk groups of `group_m` tile rows column by column, so that a band of
+// B = tiles/8 consecutive indices is a (group_m x B/group_m) rectangle: its activation panels (group_m) and weight panels
+// (B/group_m) are what that XCD's L2 has to fetch.  group_m ~ sqrt(B * bytes_per_weight_row / bytes_per_activation_row)
+// minimises the fetched bytes (cfg4, 128-tiles: 294 MB of fabric traffic per launch with row-major order).
+__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int per_group = group_m * tiles_n;
+  const int g = t / per_group, in_g = t - g * per_group;
+  const int rows = tiles_m - g * group_m < group_m ? tiles_m - g * group_m : group_m;
+  tn = in_g / rows;
+  tm = g * group_m + (in_g - tn * rows);
+}
 
 // Tile configurations (BM x BN workgroup tile, WM x WN waves, each wave (BM/WM) x (BN/WN)):
 //   256 x 256, 2 x 4 waves of 128 x 64  - the default for grids that fill the chip: two interleaving streams per SIMD
@@ -154,13 +171,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   const int nk = K / BK;
 
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-  const int nwg = tiles_n * tiles_m;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  int tm, tn;
+  tile_coords(blockIdx.x, tiles_m, tiles_n, a.group_m, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- DMA: per K-tile 32 activation pieces (8 rows x 128 B) + 16 weight pieces (16 rows x 64 B) of 1 KiB; 8 + 4 per wave
@@ -387,10 +399,20 @@ enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2 };
 template <int DT, int FMT, int BM, int BN, int WM, int WN>
 static int launch_cfg(const Args& a, hipStream_t stream) {
   constexpr int lds = STAGES * (BM * BK * 2 + BN * BK);
-  const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, tiles = tiles_m * tiles_n;
+  Args b = a;
+  {
+    // per-XCD band of B tiles as a (g x B/g) rectangle: fetched bytes ~ g*BM*2 + (B/g)*BN per k -> g = sqrt(B*BN/(2*BM))
+    const int band = (tiles + 7) / 8;
+    int g = 1;
+    while ((g + 1) * (g + 1) * 2 * BM <= band * BN) ++g;
+    static const int forced = [] { const char* e = getenv("QUANTO_HIP_GROUP_M"); return e ? atoi(e) : 0; }();  // experiments
+    if (forced > 0) g = forced;
+    b.group_m = g < tiles_m ? g : tiles_m;
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_mfma_large_kernel<DT, FMT, BM, BN, WM, WN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((qbytes_mfma_large_kernel<DT, FMT, BM, BN, WM, WN>), dim3(tiles), dim3(WM * WN * 64), lds, stream, a);
+  hipLaunchKernelGGL((qbytes_mfma_large_kernel<DT, FMT, BM, BN, WM, WN>), dim3(tiles), dim3(WM * WN * 64), lds, stream, b);
   return launch_status();
 }
 
@@ -418,7 +440,7 @@ int qbytes_mm_mfma_v2(const void* x, const void* w, const void* s, const void* b
   const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
   const int cfg = forced >= 0 ? forced : (tiles256 >= 96 ? lt::CFG_256_8W : lt::CFG_128_4W);
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
-  lt::Args a{x, reinterpret_cast<const uint8_t*>(w), s, bias, y, (int)M, (int)N, (int)K};
+  lt::Args a{x, reinterpret_cast<const uint8_t*>(w), s, bias, y, (int)M, (int)N, (int)K, 1};
 #define QH_CASE(DT, FMT) return lt::launch<DT, FMT>(a, cfg, stream)
   if (out_dtype == QUANTO_HIP_BF16) {
     if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_BF16, lt::W_I8);

@@ -13,11 +13,11 @@ int main() {
     hipMalloc(&x, hx.size() * 2); hipMalloc(&w, hw.size()); hipMalloc(&sc, N * 2); hipMalloc(&y, (size_t)M * N * 2);
     hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), hw.size(), hipMemcpyHostToDevice);
     hipMemcpy(sc, hs.data(), N * 2, hipMemcpyHostToDevice);
-    qh::lt::Args a{x, (const uint8_t*)w, sc, nullptr, y, M, N, K};
+    qh::lt::Args a{x, (const uint8_t*)w, sc, nullptr, y, M, N, K, 4};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) qh::lt::launch<QUANTO_HIP_BF16, qh::lt::W_I8>(a, 0);
+    for (int i = 0; i < 3; ++i) qh::lt::launch<QUANTO_HIP_BF16, qh::lt::W_I8>(a, qh::lt::CFG_256_8W, 0);
     hipEventRecord(e0, 0);
-    for (int i = 0; i < 20; ++i) qh::lt::launch<QUANTO_HIP_BF16, qh::lt::W_I8>(a, 0);
+    for (int i = 0; i < 20; ++i) qh::lt::launch<QUANTO_HIP_BF16, qh::lt::W_I8>(a, qh::lt::CFG_256_8W, 0);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[256 * 8];
