@@ -121,10 +121,16 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
  * The caller allocates it (16-byte aligned), passes it as `workspace` and may reuse it for any later
  * call on the same stream.  The MFMA kernel stores the per-group row sums of x there
  * (fp32 [K/group_size][roundup(M,128)]); the DEQUANT_MFMA path stores the dequantized weight (dtype[N, K]).
+ * The SKINNY kernel splits K across workgroups when N alone cannot occupy the chip: its workspace starts with
+ * ceil(N/16*4 / 256)*256 bytes of arrival counters that MUST BE ZERO on entry (the kernel leaves them zero), followed by
+ * fp32 partial sums; without a workspace it runs unsplit.  quanto_hip_qbits_mm_pick tells which kernel AUTO selects, so
+ * that a caller can hand the zero-initialised buffer to exactly those calls.
  * Returns a negative status on invalid arguments.
  */
 int64_t quanto_hip_qbits_mm_workspace_size(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype,
                                            int kernel);
+/* The quanto_hip_kernel that QUANTO_HIP_KERNEL_AUTO resolves to for this problem when a sufficient workspace is given. */
+int quanto_hip_qbits_mm_pick(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype);
 
 /*
  * quanto::qbytes_mm(Tensor A, Tensor B, Tensor scales) -> Tensor

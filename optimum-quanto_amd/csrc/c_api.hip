@@ -131,6 +131,13 @@ int64_t quanto_hip_qbits_mm_workspace_size(int64_t M, int64_t N, int64_t K, int 
   return 0;
 }
 
+int quanto_hip_qbits_mm_pick(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype) {
+  bool int_shift = false;
+  const int st = check_qbits(M, N, K, bits, group_size, dtype, dtype, &int_shift);
+  if (st != QUANTO_HIP_OK) return st;
+  return pick_qbits_kernel(M, make_geom(N, K, bits, group_size), dtype, true);
+}
+
 int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t M,
                         int64_t N, int64_t K, int bits, int group_size, int dtype, int shift_dtype, int kernel, void* workspace,
                         size_t workspace_bytes, void* stream_) {
@@ -143,7 +150,6 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
   const PackedGeom g = make_geom(N, K, bits, group_size);
   if (kernel == QUANTO_HIP_KERNEL_AUTO) {
     kernel = pick_qbits_kernel(M, g, dtype, workspace != nullptr);
-    if (kernel == QUANTO_HIP_KERNEL_SKINNY && workspace_bytes < qbits_skinny_workspace(M, g)) kernel = QUANTO_HIP_KERNEL_NAIVE;
     if (kernel == QUANTO_HIP_KERNEL_DEQUANT_MFMA && workspace_bytes < dequant_mfma_workspace(g))
       kernel = qbits_mfma_supported(M, g, dtype) ? QUANTO_HIP_KERNEL_MFMA : QUANTO_HIP_KERNEL_NAIVE;
     if (kernel == QUANTO_HIP_KERNEL_MFMA && workspace_bytes < qbits_mfma_workspace(M, g)) kernel = QUANTO_HIP_KERNEL_NAIVE;

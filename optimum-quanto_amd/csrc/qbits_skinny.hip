@@ -84,6 +84,11 @@ struct Args {
   const void* bias;     // [N] or null
   void* y;              // [M, N]
   int M, N, K, G;
+  // split-K (S > 1): block b handles feature block b / S and K-range b % S; partial fp32 sums go to `partials`, the last block
+  // of a feature block to arrive (atomic counter, zero on entry, reset to zero on exit) adds them up in split order and stores
+  int S;
+  int* counters;    // [N / (16*WAVES)]
+  float* partials;  // [blocks][WAVES*64 lanes][TF] float4
 };
 
 // WAVES per block: 4 (64 features per block), 2 or 1 (16 features) - so that any N that is a multiple of 16 is served.
@@ -103,17 +108,21 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int M = a.M, N = a.N, K = a.K, G = a.G;
+  const int M = a.M, N = a.N, K = a.K;
   const int P = N >> 1;
-  const int p0 = blockIdx.x * ROWS;
-  const int nk = K / BK;
+  const int S = a.S;
+  const int fb = S > 1 ? blockIdx.x / S : blockIdx.x, sp = S > 1 ? blockIdx.x - fb * S : 0;
+  const int p0 = fb * ROWS;
+  const int nk = K / BK / S;   // tiles (= groups) of this block's K-range
+  const int kt0 = sp * nk;     // first global tile / group index
+  const int G = nk;            // groups held in the LDS tables
 
   // ---- per-lane DMA sources ---------------------------------------------------------------------------
   // weights: this wave's 8 rows x 128 B = 1 KiB per tile; lane -> row lane>>3, position lane&7 holds chunk pos ^ (row & 7)
   const uint8_t* wsrc;
   {
     const int r = lane >> 3, c = (lane & 7) ^ (r & 7);
-    wsrc = a.w + (size_t)(p0 + wave * 8 + r) * K + c * 16;
+    wsrc = a.w + (size_t)(p0 + wave * 8 + r) * K + c * 16 + (size_t)kt0 * BK;
   }
   // activations: XP KiB-instructions per wave; instruction u covers tile rows 4*(wave*XP+u) .. +3
   const uint8_t* xsrc[XP];
@@ -122,7 +131,7 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
     const int row = 4 * (wave * XP + u) + (lane >> 4);
     const int c = (lane & 15) ^ (row & 15);
     const int m = row < M ? row : M - 1;
-    xsrc[u] = reinterpret_cast<const uint8_t*>(reinterpret_cast<const T*>(a.x) + (size_t)m * K + c * 8);
+    xsrc[u] = reinterpret_cast<const uint8_t*>(reinterpret_cast<const T*>(a.x) + (size_t)m * K + c * 8 + (size_t)kt0 * BK);
   }
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
   auto issue = [&](int kt, int stage) {
@@ -141,7 +150,7 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
   constexpr int NF = 2 * ROWS;  // features per block
   for (int e = tid; e < NF * G; e += WAVES * 64) {
     const int f = e / G, g = e - f * G;
-    const size_t idx = (size_t)(p0 + (f % ROWS) + (f / ROWS) * P) * G + g;
+    const size_t idx = (size_t)(p0 + (f % ROWS) + (f / ROWS) * P) * a.G + kt0 + g;
     sz[(g * 2 + 0) * NF + f] = reinterpret_cast<const T*>(a.scale)[idx];
     if constexpr (INT_SHIFT)
       sz[(g * 2 + 1) * NF + f] = E::from_f32((float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[idx]);
@@ -247,6 +256,39 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
     cur = nxt + 1 == STAGES ? 0 : nxt + 1;
   }
 
+  // ---- split-K: park the partial sums, elect the last block of this feature block, which reduces in split order -------------
+  // The blocks of one feature block may run on different XCDs, whose L2s are not coherent with each other.  An agent-scope
+  // fence would be correct but writes back / invalidates a whole L2 (measured: 23 -> 57 us); instead the few KiB of partials
+  // travel with system-coherent (sc0 sc1) 16-byte stores and loads and the only
+  // ordering needed is "my stores are acknowledged (vmcnt(0)) before my workgroup's arrival is counted".
+  if (S > 1) {
+    float* mine = a.partials + ((size_t)blockIdx.x * (WAVES * 64) + tid) * (TF * 4);
+#pragma unroll
+    for (int tf = 0; tf < TF; ++tf)  // s_nop: gfx9 hazard "VMEM store of > 64 bits, then VALU write of its data VGPRs" - hipcc cannot see into the asm
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + tf * 4), "v"(acc[tf]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) *flag = __hip_atomic_fetch_add(a.counters + fb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (*flag != S - 1) return;
+    if (tid == 0) __hip_atomic_store(a.counters + fb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // leave the workspace as found
+#pragma unroll
+    for (int tf = 0; tf < TF; ++tf) acc[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < S; ++q) {  // fixed order: the result does not depend on which block arrived last
+      const float* theirs = a.partials + ((size_t)(fb * S + q) * (WAVES * 64) + tid) * (TF * 4);
+      f32x4 v[TF];
+#pragma unroll
+      for (int tf = 0; tf < TF; ++tf) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[tf]) : "v"(theirs + tf * 4) : "memory");
+#pragma unroll
+      for (int tf = 0; tf < TF; ++tf) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[tf])::"memory");  // ties the uses below to the wait
+#pragma unroll
+      for (int tf = 0; tf < TF; ++tf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[tf][r] += v[tf][r];
+    }
+  }
+
   // ---- epilogue ----------------------------------------------------------------------------------------------------------
   T* yg = reinterpret_cast<T*>(a.y);
   const int n0 = p0 + wave * 8 + 4 * (fg & 1) + (fg >> 1) * P;  // 4 consecutive output features n0..n0+3
@@ -276,10 +318,10 @@ constexpr int lds_bytes(int tf, int stages, int G, int waves) { return stages * 
 
 template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES>
 static int launch_s(const Args& a, hipStream_t stream) {
-  const int lds = lds_bytes(TF, STAGES, a.G, WAVES);
+  const int lds = lds_bytes(TF, STAGES, a.G / a.S, WAVES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES>), dim3(a.N / (16 * WAVES)), dim3(WAVES * 64), lds, stream, a);
+  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES>), dim3(a.N / (16 * WAVES) * a.S), dim3(WAVES * 64), lds, stream, a);
   return launch_status();
 }
 
@@ -290,9 +332,9 @@ static int launch(const Args& a, hipStream_t stream) {
   constexpr int budget = WAVES == 4 ? 150 * 1024 : 76 * 1024;
   constexpr int per_tile = 1 + TF * 4 / WAVES;  // DMA instructions per wave and tile; vmcnt counts at most 63 of them
   if constexpr ((8 - 4) * per_tile <= 60)
-    if (lds_bytes(TF, 8, a.G, WAVES) <= budget) return launch_s<DT, TF, 8, INT_SHIFT, WAVES>(a, stream);
+    if (lds_bytes(TF, 8, a.G / a.S, WAVES) <= budget) return launch_s<DT, TF, 8, INT_SHIFT, WAVES>(a, stream);
   if constexpr ((6 - 4) * per_tile <= 60)
-    if (lds_bytes(TF, 6, a.G, WAVES) <= budget) return launch_s<DT, TF, 6, INT_SHIFT, WAVES>(a, stream);
+    if (lds_bytes(TF, 6, a.G / a.S, WAVES) <= budget) return launch_s<DT, TF, 6, INT_SHIFT, WAVES>(a, stream);
   return launch_s<DT, TF, 4, INT_SHIFT, WAVES>(a, stream);
 }
 
@@ -322,6 +364,18 @@ static int launch_tf(const Args& a, hipStream_t stream) {
 
 }  // namespace skinny
 
+// split factor: enough K-ranges that every SIMD of the chip gets a wave (N = 4096 alone gives 256 waves for 1024 SIMDs),
+// each range at least 4 groups long and the group count divisible by it
+static int skinny_split(const PackedGeom& g) {
+  static const int forced = [] { const char* e = getenv("QUANTO_HIP_SKINNY_SPLIT"); return e ? atoi(e) : 0; }();  // experiments
+  const int waves = (int)(g.N / 16);
+  int s = 1;
+  while (s < 8 && waves * s * 2 <= 1024 && g.G % (s * 2) == 0 && g.G / (s * 2) >= 4) s *= 2;
+  if (forced > 0 && g.G % forced == 0) s = forced;
+  return s;
+}
+static size_t skinny_counter_bytes(const PackedGeom& g) { return ((size_t)(g.N / 16) * 4 + 255) / 256 * 256; }
+
 bool qbits_skinny_supported(int64_t M, const PackedGeom& g, int dtype) {
   const int tf = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
   return g.bits == 4 && g.C == 128 && (g.N % 16 == 0) && (g.K % 128 == 0) && M >= 1 && M <= QUANTO_HIP_SKINNY_MAX_M &&
@@ -329,13 +383,23 @@ bool qbits_skinny_supported(int64_t M, const PackedGeom& g, int dtype) {
          skinny::lds_bytes(tf, 4, (int)g.G, skinny::pick_waves((int)g.N)) <= 160 * 1024;
 }
 
-size_t qbits_skinny_workspace(int64_t, const PackedGeom&) { return 0; }
+// [counters (zero on entry, zero on exit) | fp32 partial sums]; 0 when the problem is not split
+size_t qbits_skinny_workspace(int64_t M, const PackedGeom& g) {
+  const int S = skinny_split(g);
+  if (S == 1) return 0;
+  const int tf = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+  return skinny_counter_bytes(g) + (size_t)(g.N / 16) * S * 64 * tf * 16;
+}
 
 int qbits_mm_skinny(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t M,
-                    const PackedGeom& g, int dtype, bool int_shift, void*, size_t, hipStream_t stream) {
+                    const PackedGeom& g, int dtype, bool int_shift, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbits_skinny_supported(M, g, dtype)) return QUANTO_HIP_ENOTSUP;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed)) % 16) return QUANTO_HIP_EALIGN;
-  skinny::Args a{x, packed, scale, shift, bias, y, (int)M, (int)g.N, (int)g.K, (int)g.G};
+  // split-K only with a workspace (whose counter words the caller guarantees to be zero); without one: one block per feature block
+  int S = skinny_split(g);
+  if (S > 1 && (!workspace || workspace_bytes < qbits_skinny_workspace(M, g) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
+  skinny::Args a{x, packed, scale, shift, bias, y, (int)M, (int)g.N, (int)g.K, (int)g.G, S, reinterpret_cast<int*>(workspace),
+                 S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr};
   if (dtype == QUANTO_HIP_BF16)
     return int_shift ? skinny::launch_tf<QUANTO_HIP_BF16, true>(a, stream) : skinny::launch_tf<QUANTO_HIP_BF16, false>(a, stream);
   return int_shift ? skinny::launch_tf<QUANTO_HIP_F16, true>(a, stream) : skinny::launch_tf<QUANTO_HIP_F16, false>(a, stream);

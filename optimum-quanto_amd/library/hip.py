@@ -68,6 +68,8 @@ class _Bindings:
         c.quanto_hip_qbits_mm.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, ci, ci, ci, vp, sz, vp]
         c.quanto_hip_qbits_mm_workspace_size.restype = i64
         c.quanto_hip_qbits_mm_workspace_size.argtypes = [i64, i64, i64, ci, ci, ci, ci]
+        c.quanto_hip_qbits_mm_pick.restype = ci
+        c.quanto_hip_qbits_mm_pick.argtypes = [i64, i64, i64, ci, ci, ci]
         c.quanto_hip_qbytes_mm.restype = ci
         c.quanto_hip_qbytes_mm.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, ci, ci, vp]
         c.quanto_hip_quantize_symmetric.restype = ci
@@ -95,6 +97,16 @@ class _Bindings:
         for t in tensors:
             if t is not None and not t.is_cuda:
                 raise QuantoHipError("quanto_hip kernels only accept tensors on a ROCm device")
+
+    def _zeroed_workspace(self, device: torch.device, nbytes: int) -> torch.Tensor:
+        """Per-device buffer that is zero-filled once when (re)allocated and only ever handed to kernels that restore the
+        zero words they use (stream-ordered reuse; concurrent launches on several streams of one device must not share it)."""
+        cache = self.__dict__.setdefault("_zero_ws", {})
+        buf = cache.get(device)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.zeros((max(nbytes, 8 << 20),), dtype=torch.uint8, device=device)
+            cache[device] = buf
+        return buf
 
     def last_kernel(self) -> str:
         return self._c.quanto_hip_last_kernel().decode()
@@ -192,11 +204,20 @@ class _Bindings:
         y = torch.empty((M, out_features), dtype=scale.dtype, device=x.device)
         k = KERNELS[kernel]
         with torch.cuda.device(x.device):
+            if k == KERNEL_AUTO:
+                k = self._c.quanto_hip_qbits_mm_pick(M, out_features, in_features, bits, group_size or 0, _dt(scale))
+                if k < 0:
+                    self._check(k, "qbits_mm_pick")
             ws_bytes = self._c.quanto_hip_qbits_mm_workspace_size(M, out_features, in_features, bits, group_size or 0,
                                                                   _dt(scale), k)
             if ws_bytes < 0:
                 self._check(int(ws_bytes), "qbits_mm_workspace_size")
-            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
+            if ws_bytes == 0:
+                ws = None
+            elif k == KERNEL_SKINNY:
+                ws = self._zeroed_workspace(x.device, ws_bytes)  # split-K arrival counters: zero on entry, left zero by the kernel
+            else:
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
             st = self._c.quanto_hip_qbits_mm(
                 _ptr(x2), _ptr(packed), _ptr(scale), _ptr(shift), _ptr(bias), _ptr(y), M, out_features, in_features,
                 bits, group_size or 0, _dt(scale), _dt(shift), k, _ptr(ws), ws_bytes, self._stream(x))
