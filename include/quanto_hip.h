@@ -65,7 +65,7 @@ typedef enum {
 } quanto_hip_kernel;
 
 #define QUANTO_HIP_GEMV_MAX_M 8         /* qbytes_mm: rows of x the GEMV kernel accepts                    */
-#define QUANTO_HIP_SKINNY_MAX_M 64       /* qbits_mm: rows of x the streaming MFMA kernel accepts            */
+#define QUANTO_HIP_SKINNY_MAX_M 256      /* qbits_mm: rows of x the streaming MFMA kernel accepts (passes of 64) */
 #define QUANTO_HIP_GEMV_MAX_M_QBITS 64  /* qbits_mm: ditto (passes of up to 8 rows; weights re-read from MALL) */
 
 int quanto_hip_abi_version(void);

@@ -59,20 +59,21 @@ static int check_qbits(int64_t M, int64_t N, int64_t K, int bits, int group_size
 // M above which the weight-streaming GEMV stops being the better choice (it re-reads W once per 4 (int4) / 2 (int8) rows of x)
 static bool prefer_gemv(int64_t M) { return M <= QUANTO_HIP_GEMV_MAX_M; }
 
-// qbits_mm kernel choice.  M <= 8: dot2 GEMV (x in registers, every CU busy even for N = 4096; measured 11 us at M = 8
-// vs 19 us for the streaming MFMA kernel on 4096x4096).  9..64: streaming MFMA
-// kernel (cost per weight byte independent of M); GEMV passes when it does not apply.  Above: LDS-tiled MFMA GEMM.
-// Prefill-sized M: dequantize once into the workspace (one pass over the packed weight, ~N*K*2.5 bytes of HBM traffic),
-// then a dense 256x256-tile GEMM - the dequantization cost is amortised over M rows instead of being repeated per tile.
+// qbits_mm kernel choice (measured, int4 g128, N = K = 4096 unless noted):
+//   M <= 8    dot2 GEMV: x in registers, every CU busy even for N = 4096 (11 us at M = 8 vs 19 us streaming MFMA);
+//   M <= 256  streaming MFMA kernel in passes of 64 rows, K split across workgroups when N alone cannot occupy the chip
+//             (M = 32: 12 us, M = 128: 35 us, M = 256: 68 us; the dense path needs 90 us at any of these M);
+//   above     dequantize once into the workspace (one pass over the packed weight, ~N*K*2.5 bytes of HBM traffic), then a
+//             dense 256x256-tile GEMM: the dequantization cost is amortised over M rows instead of being paid per tile;
+//   the GEMV in passes / the register-staged 128x128 kernel / the naive kernel serve what those reject.
 static bool dequant_mfma_supported(int64_t M, const PackedGeom& g, int dtype) { return dense_mm_large_supported(M, g.N, g.K, dtype); }
 static size_t dequant_mfma_workspace(const PackedGeom& g) { return (size_t)g.N * g.K * 2; }
-static bool prefer_dequant_mfma(int64_t M, const PackedGeom& g) { return ((M + 255) / 256) * ((g.N + 255) / 256) >= 32; }
 
 static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {
   if (M <= 8 && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
   if (qbits_skinny_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_SKINNY;
   if (qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
-  if (have_workspace && dequant_mfma_supported(M, g, dtype) && prefer_dequant_mfma(M, g)) return QUANTO_HIP_KERNEL_DEQUANT_MFMA;
+  if (have_workspace && M > QUANTO_HIP_GEMV_MAX_M_QBITS && dequant_mfma_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_DEQUANT_MFMA;
   if (have_workspace && qbits_mfma_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MFMA;
   return QUANTO_HIP_KERNEL_NAIVE;
 }

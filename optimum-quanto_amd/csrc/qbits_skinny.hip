@@ -377,7 +377,8 @@ static int skinny_split(const PackedGeom& g) {
 static size_t skinny_counter_bytes(const PackedGeom& g) { return ((size_t)(g.N / 16) * 4 + 255) / 256 * 256; }
 
 bool qbits_skinny_supported(int64_t M, const PackedGeom& g, int dtype) {
-  const int tf = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+  const int64_t Mp = M > 64 ? 64 : M;  // rows per pass
+  const int tf = Mp <= 16 ? 1 : (Mp <= 32 ? 2 : 4);
   return g.bits == 4 && g.C == 128 && (g.N % 16 == 0) && (g.K % 128 == 0) && M >= 1 && M <= QUANTO_HIP_SKINNY_MAX_M &&
          (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30) && g.K < (1 << 30) &&
          skinny::lds_bytes(tf, 4, (int)g.G, skinny::pick_waves((int)g.N)) <= 160 * 1024;
@@ -387,7 +388,7 @@ bool qbits_skinny_supported(int64_t M, const PackedGeom& g, int dtype) {
 size_t qbits_skinny_workspace(int64_t M, const PackedGeom& g) {
   const int S = skinny_split(g);
   if (S == 1) return 0;
-  const int tf = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+  const int tf = M <= 16 ? 1 : (M <= 32 ? 2 : 4);  // M > 64 runs in passes of 64 rows, which reuse the workspace
   return skinny_counter_bytes(g) + (size_t)(g.N / 16) * S * 64 * tf * 16;
 }
 
@@ -398,11 +399,21 @@ int qbits_mm_skinny(const void* x, const uint8_t* packed, const void* scale, con
   // split-K only with a workspace (whose counter words the caller guarantees to be zero); without one: one block per feature block
   int S = skinny_split(g);
   if (S > 1 && (!workspace || workspace_bytes < qbits_skinny_workspace(M, g) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
-  skinny::Args a{x, packed, scale, shift, bias, y, (int)M, (int)g.N, (int)g.K, (int)g.G, S, reinterpret_cast<int*>(workspace),
-                 S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr};
-  if (dtype == QUANTO_HIP_BF16)
-    return int_shift ? skinny::launch_tf<QUANTO_HIP_BF16, true>(a, stream) : skinny::launch_tf<QUANTO_HIP_BF16, false>(a, stream);
-  return int_shift ? skinny::launch_tf<QUANTO_HIP_F16, true>(a, stream) : skinny::launch_tf<QUANTO_HIP_F16, false>(a, stream);
+  const size_t esize = 2;  // bf16 / fp16
+  for (int64_t m0 = 0; m0 < M; m0 += 64) {  // passes of up to 64 rows (stream-ordered: each pass leaves the counters zero)
+    const int64_t rows = M - m0 < 64 ? M - m0 : 64;
+    skinny::Args a{reinterpret_cast<const uint8_t*>(x) + (size_t)m0 * g.K * esize, packed, scale, shift, bias,
+                   reinterpret_cast<uint8_t*>(y) + (size_t)m0 * g.N * esize, (int)rows, (int)g.N, (int)g.K, (int)g.G, S,
+                   reinterpret_cast<int*>(workspace),
+                   S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr};
+    int r;
+    if (dtype == QUANTO_HIP_BF16)
+      r = int_shift ? skinny::launch_tf<QUANTO_HIP_BF16, true>(a, stream) : skinny::launch_tf<QUANTO_HIP_BF16, false>(a, stream);
+    else
+      r = int_shift ? skinny::launch_tf<QUANTO_HIP_F16, true>(a, stream) : skinny::launch_tf<QUANTO_HIP_F16, false>(a, stream);
+    if (r != QUANTO_HIP_OK) return r;
+  }
+  return QUANTO_HIP_OK;
 }
 
 }  // namespace qh

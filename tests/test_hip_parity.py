@@ -123,10 +123,12 @@ def test_qbits_gemv_zeropoint_and_bias(dt):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
-@pytest.mark.parametrize("M", [1, 5, 16, 17, 32, 33, 64])
-@pytest.mark.parametrize("N,K", [(64, 128), (256, 256), (128, 384), (512, 4096), (192, 14336), (1024, 1024)])
+@pytest.mark.parametrize("M", [1, 5, 16, 17, 32, 33, 64, 65, 130, 256])
+@pytest.mark.parametrize("N,K", [(64, 128), (256, 256), (128, 384), (512, 4096), (192, 14336), (1024, 1024), (48, 512)])
 def test_qbits_skinny(dt, M, N, K):
-    """Streaming MFMA kernel: 1..4 token fragments, 1..112 K-tiles (pipeline prologue/epilogue paths), ragged M."""
+    """Streaming MFMA kernel: 1..4 token fragments, 1..112 K-tiles (pipeline prologue/epilogue paths), ragged M, passes of
+    64 rows above M = 64, K split over 1..8 workgroups (N = 512, K = 4096 -> 8; arrival counters reused across passes),
+    1-, 2- and 4-wave blocks (N = 48, 192/128, 64...)."""
     p = make_qbits_problem(M, N, K, dt, seed=M * 3 + N + K)
     assert_close_to_exact(_run_qbits(p, "skinny"), _exact_qbits(p), dt, f"skinny {M}x{K}x{N}")
 
@@ -194,7 +196,10 @@ def test_qbits_auto_picks_fast_kernels():
     p = make_qbits_problem(32, 34, 1024, "bf16")  # N not a multiple of 64: GEMV passes
     _run_qbits(p, "auto")
     assert quanto_hip.lib.last_kernel() == "gemv"
-    p = make_qbits_problem(65, 256, 1024, "bf16")
+    p = make_qbits_problem(65, 256, 1024, "bf16")  # two passes of the streaming kernel
+    _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "skinny"
+    p = make_qbits_problem(40, 256, 512, "bf16", group_size=64)  # group size 64, small M: register-staged 128x128 kernel
     _run_qbits(p, "auto")
     assert quanto_hip.lib.last_kernel() == "mfma"
     p = make_qbits_problem(2048, 1024, 256, "bf16")  # 8 x 4 tiles of 256x256: dequantize once + dense GEMM

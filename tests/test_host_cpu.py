@@ -48,7 +48,8 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     lib.quanto_hip_qbits_mm_workspace_size.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 4
     assert lib.quanto_hip_qbits_mm_workspace_size(4096, 4096, 4096, 4, 128, 2, 0) == 4096 * 4096 * 2  # prefill: dequantized weight
     assert lib.quanto_hip_qbits_mm_workspace_size(4096, 4096, 4096, 4, 128, 2, 3) == 32 * 4096 * 4  # kernel MFMA: per-group row sums of x
-    assert lib.quanto_hip_qbits_mm_workspace_size(128, 256, 4096, 4, 128, 2, 0) == 32 * 128 * 4  # too few tiles for the dense path
+    assert lib.quanto_hip_qbits_mm_workspace_size(300, 256, 4096, 4, 128, 2, 0) == 256 * 4096 * 2  # above the streaming kernel's range
+    assert lib.quanto_hip_qbits_mm_workspace_size(40, 256, 512, 4, 64, 2, 0) == 8 * 128 * 4  # group size 64, small M: 128x128 kernel (row sums of x)
     # streaming MFMA kernel, N = 4096: 256 waves -> K split 4 ways; 1 KiB of arrival counters + fp32 partials (TF = 4)
     assert lib.quanto_hip_qbits_mm_workspace_size(64, 4096, 4096, 4, 128, 2, 0) == 1024 + 256 * 4 * 64 * 4 * 16
     assert lib.quanto_hip_qbits_mm_workspace_size(64, 14336, 4096, 4, 128, 2, 0) == 0  # wide enough: not split
