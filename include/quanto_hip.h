@@ -146,6 +146,18 @@ int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const
                          void* stream);
 
 /*
+ * Same, with a caller-provided scratch buffer.  Only the SKINNY kernel (float activations, 8 < M <= QUANTO_HIP_SKINNY_MAX_M)
+ * uses it, to split K across workgroups when N alone cannot occupy the chip: the buffer starts with arrival counters that MUST
+ * BE ZERO on entry (the kernel leaves them zero), followed by fp32 partial sums - the contract of quanto_hip_qbits_mm's SKINNY
+ * kernel.  With workspace == NULL the call is quanto_hip_qbytes_mm.  quanto_hip_qbytes_mm_pick returns the kernel AUTO selects.
+ */
+int quanto_hip_qbytes_mm_ws(const void* a, const void* b, const void* scales, const void* bias, void* y,
+                            int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype, int kernel,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int64_t quanto_hip_qbytes_mm_workspace_size(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype, int kernel);
+int quanto_hip_qbytes_mm_pick(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype);
+
+/*
  * quanto::quantize_symmetric(Tensor base, ScalarType dtype, int? axis, Tensor scale) -> Tensor
  *   replaces library/quantize.py:26-55 (div, round, clamp, cast = four elementwise passes) with one pass; it is the
  *   per-forward step of quantized activations (tensor/activations/qbytes.py:31-39, nn/qmodule.py:281-291).

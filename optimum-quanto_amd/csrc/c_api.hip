@@ -26,6 +26,9 @@ int qbytes_mm_mfma_v2(const void*, const void*, const void*, const void*, void*,
 int quantize_symmetric(const void*, const void*, void*, int64_t, int64_t, int, int, int, hipStream_t);
 int quantize_affine(const void*, const void*, const void*, void*, int64_t, int64_t, int, int, bool, hipStream_t);
 int pack_weights(const uint8_t*, uint8_t*, int64_t, int64_t, int, hipStream_t);
+bool qbytes_skinny_supported(int64_t, int64_t, int64_t, int, int, int);
+size_t qbytes_skinny_workspace(int64_t, int64_t, int64_t);
+int qbytes_mm_skinny(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, void*, size_t, hipStream_t);
 bool dense_mm_large_supported(int64_t, int64_t, int64_t, int);
 int dense_mm_large(const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, hipStream_t);
 bool qbytes_native8_supported(int64_t, int64_t, int64_t, int, int, int);
@@ -60,7 +63,8 @@ static int check_qbits(int64_t M, int64_t N, int64_t K, int bits, int group_size
 static bool prefer_gemv(int64_t M) { return M <= QUANTO_HIP_GEMV_MAX_M; }
 
 // qbits_mm kernel choice (measured, int4 g128, N = K = 4096 unless noted):
-//   M <= 8    dot2 GEMV: x in registers, every CU busy even for N = 4096 (11 us at M = 8 vs 19 us streaming MFMA);
+//   M <= 4    dot2 GEMV: x in registers, every CU busy even for N = 4096 (4.4 / 5.4 / 7.1 us at M = 1 / 2 / 4; 11.3 at M = 8,
+//             where the split-K streaming kernel needs 10.1 - and 21 vs 44 us for K = 14336);
 //   M <= 256  streaming MFMA kernel in passes of 64 rows, K split across workgroups when N alone cannot occupy the chip
 //             (M = 32: 12 us, M = 128: 35 us, M = 256: 68 us; the dense path needs 90 us at any of these M);
 //   above     dequantize once into the workspace (one pass over the packed weight, ~N*K*2.5 bytes of HBM traffic), then a
@@ -70,7 +74,7 @@ static bool dequant_mfma_supported(int64_t M, const PackedGeom& g, int dtype) { 
 static size_t dequant_mfma_workspace(const PackedGeom& g) { return (size_t)g.N * g.K * 2; }
 
 static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {
-  if (M <= 8 && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
+  if (M <= 4 && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
   if (qbits_skinny_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_SKINNY;
   if (qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
   if (have_workspace && M > QUANTO_HIP_GEMV_MAX_M_QBITS && dequant_mfma_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_DEQUANT_MFMA;
@@ -185,25 +189,50 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
   return QUANTO_HIP_EINVAL;
 }
 
-int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const void* bias, void* y, int64_t M, int64_t N, int64_t K,
-                         int a_dtype, int b_dtype, int out_dtype, int kernel, void* stream_) {
+// qbytes_mm kernel choice (measured with bf16 x int8, hipGraph replay, N = K = 4096 unless noted):
+//   M <= 2    GEMV (7.4 us at M = 1; it re-reads the weights per pair of rows: 38 us at M = 8);
+//   quantized activations -> native8 (int8 x int8 / fp8 x fp8 MFMA);
+//   M <= 64   streaming MFMA kernel, K split across workgroups (8.8 us at M = 8, 17 us at M = 64; the tiled kernels need 30);
+//   enough 128-tiles to occupy the chip -> pipelined large-tile kernel (M = 256: 35 us vs 68 us streaming);
+//   M <= 256  streaming kernel in passes of 64 rows (few, long tiles: (256, 4096, 14336) 107 us vs 127 us tiled);
+//   else the large-tile kernel whenever it applies, the register-staged 128x128 kernel, the naive kernel.
+static int pick_qbytes_kernel(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
+  if (M <= 2 && qbytes_gemv_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_KERNEL_GEMV;
+  if (qbytes_native8_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_KERNEL_NATIVE8;
+  const bool skinny = qbytes_skinny_supported(M, N, K, a_dtype, b_dtype, out_dtype);
+  const bool large = qbytes_mfma_v2_supported(M, N, K, a_dtype, b_dtype, out_dtype);
+  if (skinny && M <= 64) return QUANTO_HIP_KERNEL_SKINNY;
+  if (large && prefer_large_tile(M, N)) return QUANTO_HIP_KERNEL_MFMA_LARGE;
+  if (skinny) return QUANTO_HIP_KERNEL_SKINNY;
+  if (prefer_gemv(M) && qbytes_gemv_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_KERNEL_GEMV;
+  if (large) return QUANTO_HIP_KERNEL_MFMA_LARGE;
+  if (qbytes_mfma_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_KERNEL_MFMA;
+  return QUANTO_HIP_KERNEL_NAIVE;
+}
+
+int quanto_hip_qbytes_mm_pick(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
+  if (M < 0 || N <= 0 || K <= 0) return QUANTO_HIP_EINVAL;
+  if (!is_float_dtype(out_dtype)) return QUANTO_HIP_ENOTSUP;
+  return pick_qbytes_kernel(M, N, K, a_dtype, b_dtype, out_dtype);
+}
+
+int64_t quanto_hip_qbytes_mm_workspace_size(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype, int kernel) {
+  if (M < 0 || N <= 0 || K <= 0) return QUANTO_HIP_EINVAL;
+  if (!is_float_dtype(out_dtype)) return QUANTO_HIP_ENOTSUP;
+  if (kernel == QUANTO_HIP_KERNEL_AUTO) kernel = pick_qbytes_kernel(M, N, K, a_dtype, b_dtype, out_dtype);
+  if (kernel == QUANTO_HIP_KERNEL_SKINNY && qbytes_skinny_supported(M, N, K, a_dtype, b_dtype, out_dtype))
+    return (int64_t)qbytes_skinny_workspace(M, N, K);
+  return 0;
+}
+
+int quanto_hip_qbytes_mm_ws(const void* a, const void* b, const void* scales, const void* bias, void* y, int64_t M, int64_t N, int64_t K,
+                            int a_dtype, int b_dtype, int out_dtype, int kernel, void* workspace, size_t workspace_bytes, void* stream_) {
   if (M < 0 || N <= 0 || K <= 0) return QUANTO_HIP_EINVAL;
   if (!is_float_dtype(out_dtype)) return QUANTO_HIP_ENOTSUP;
   if (M == 0) return QUANTO_HIP_OK;
   if (!a || !b || !scales || !y) return QUANTO_HIP_EINVAL;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (kernel == QUANTO_HIP_KERNEL_AUTO) {
-    if (prefer_gemv(M) && qbytes_gemv_supported(M, N, K, a_dtype, b_dtype, out_dtype))
-      kernel = QUANTO_HIP_KERNEL_GEMV;
-    else if (qbytes_native8_supported(M, N, K, a_dtype, b_dtype, out_dtype))
-      kernel = QUANTO_HIP_KERNEL_NATIVE8;
-    else if (qbytes_mfma_v2_supported(M, N, K, a_dtype, b_dtype, out_dtype) && prefer_large_tile(M, N))
-      kernel = QUANTO_HIP_KERNEL_MFMA_LARGE;
-    else if (qbytes_mfma_supported(M, N, K, a_dtype, b_dtype, out_dtype))
-      kernel = QUANTO_HIP_KERNEL_MFMA;
-    else
-      kernel = QUANTO_HIP_KERNEL_NAIVE;
-  }
+  if (kernel == QUANTO_HIP_KERNEL_AUTO) kernel = pick_qbytes_kernel(M, N, K, a_dtype, b_dtype, out_dtype);
   int r;
   switch (kernel) {
     case QUANTO_HIP_KERNEL_NAIVE:
@@ -213,6 +242,10 @@ int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const
     case QUANTO_HIP_KERNEL_GEMV:
       r = qbytes_mm_gemv(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("gemv");
+      return r;
+    case QUANTO_HIP_KERNEL_SKINNY:
+      r = qbytes_mm_skinny(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, workspace, workspace_bytes, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("skinny");
       return r;
     case QUANTO_HIP_KERNEL_MFMA:
       r = qbytes_mm_mfma(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
@@ -228,6 +261,11 @@ int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const
       return r;
   }
   return QUANTO_HIP_EINVAL;
+}
+
+int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const void* bias, void* y, int64_t M, int64_t N, int64_t K,
+                         int a_dtype, int b_dtype, int out_dtype, int kernel, void* stream) {
+  return quanto_hip_qbytes_mm_ws(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, kernel, nullptr, 0, stream);
 }
 
 int quanto_hip_quantize_symmetric(const void* base, const void* scale, void* out, int64_t numel, int64_t inner, int scale_mode,

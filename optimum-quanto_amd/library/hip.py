@@ -72,6 +72,12 @@ class _Bindings:
         c.quanto_hip_qbits_mm_pick.argtypes = [i64, i64, i64, ci, ci, ci]
         c.quanto_hip_qbytes_mm.restype = ci
         c.quanto_hip_qbytes_mm.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, ci, ci, vp]
+        c.quanto_hip_qbytes_mm_ws.restype = ci
+        c.quanto_hip_qbytes_mm_ws.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, ci, ci, vp, sz, vp]
+        c.quanto_hip_qbytes_mm_workspace_size.restype = i64
+        c.quanto_hip_qbytes_mm_workspace_size.argtypes = [i64, i64, i64, ci, ci, ci, ci]
+        c.quanto_hip_qbytes_mm_pick.restype = ci
+        c.quanto_hip_qbytes_mm_pick.argtypes = [i64, i64, i64, ci, ci, ci]
         c.quanto_hip_quantize_symmetric.restype = ci
         c.quanto_hip_quantize_symmetric.argtypes = [vp, vp, vp, i64, i64, ci, ci, ci, vp]
         c.quanto_hip_quantize_affine.restype = ci
@@ -239,9 +245,19 @@ class _Bindings:
             bias = bias.to(scales.dtype).contiguous()
         M = a2.shape[0]
         y = torch.empty((M, N), dtype=scales.dtype, device=a.device)
+        k = KERNELS[kernel]
         with torch.cuda.device(a.device):
-            st = self._c.quanto_hip_qbytes_mm(_ptr(a2), _ptr(b), _ptr(s), _ptr(bias), _ptr(y), M, N, K, _dt(a2), _dt(b),
-                                              _dt(s), KERNELS[kernel], self._stream(a))
+            if k == KERNEL_AUTO:
+                k = self._c.quanto_hip_qbytes_mm_pick(M, N, K, _dt(a2), _dt(b), _dt(s))
+                if k < 0:
+                    self._check(k, "qbytes_mm_pick")
+            ws, ws_bytes = None, 0
+            if k == KERNEL_SKINNY:
+                ws_bytes = self._c.quanto_hip_qbytes_mm_workspace_size(M, N, K, _dt(a2), _dt(b), _dt(s), k)
+                if ws_bytes > 0:
+                    ws = self._zeroed_workspace(a.device, ws_bytes)  # split-K arrival counters: zero on entry, left zero
+            st = self._c.quanto_hip_qbytes_mm_ws(_ptr(a2), _ptr(b), _ptr(s), _ptr(bias), _ptr(y), M, N, K, _dt(a2), _dt(b),
+                                                 _dt(s), k, _ptr(ws), max(ws_bytes, 0), self._stream(a))
         self._check(st, "qbytes_mm")
         return y.reshape(*lead, N)
 
@@ -255,7 +271,7 @@ class QuantoHipExtension(NativeLibrary):
             "quanto_hip",
             root_dir=csrc,
             lib_path=os.path.join(_PKG_DIR, "lib", "libquanto_hip.so"),
-            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qmm_mfma_large.hip", "qbits_skinny.hip", "qmm_native8.hip", "quantize.hip",
+            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qmm_mfma_large.hip", "qbits_skinny.hip", "qbytes_skinny.hip", "qmm_native8.hip", "quantize.hip",
                      "qh_common.h", os.path.join("..", "..", "include", "quanto_hip.h")],
         )
         self._bindings = None

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--pairs", nargs="+", default=["i8:i8", "f8:f8", "bf16:i8", "bf16:f8"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--kernel", default="auto")
+    ap.add_argument("--graph", action="store_true")
     args = ap.parse_args()
     from optimum_quanto_amd.library.hip import quanto_hip
 
@@ -43,10 +44,21 @@ def main():
             kern = lib.last_kernel()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.iters):
-                lib.qbytes_mm(a, b, s, kernel=args.kernel)
-            e1.record()
+            if args.graph:  # replay: a call of a few microseconds is shorter than its Python issue time
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(args.iters):
+                        lib.qbytes_mm(a, b, s, kernel=args.kernel)
+                g.replay()
+                torch.cuda.synchronize()
+                e0.record()
+                g.replay()
+                e1.record()
+            else:
+                e0.record()
+                for _ in range(args.iters):
+                    lib.qbytes_mm(a, b, s, kernel=args.kernel)
+                e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / args.iters
             print(json.dumps({"M": M, "N": N, "K": K, "a": ak, "b": bk, "kernel": kern, "us": round(us, 1),

@@ -252,6 +252,22 @@ def test_qbytes_gemv(dt, kind, M, N, K):
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("kind", [None, "e4m3fn", "e5m2"])
+@pytest.mark.parametrize("M,N,K", [(9, 64, 128), (16, 256, 256), (17, 130, 384), (32, 512, 4096), (33, 17, 1024), (64, 192, 14336),
+                                   (65, 1024, 1024), (130, 48, 512), (256, 256, 2048)])
+def test_qbytes_skinny(dt, kind, M, N, K):
+    """8-bit streaming MFMA kernel: 1..4 token fragments, 1..112 K-tiles, ragged M and N (clamped loads, masked stores), passes
+    of 64 rows, K split over 1..8 workgroups (N = 512, K = 4096 -> 8), with and without bias."""
+    p = make_qbytes_problem(M, N, K, dt, kind, seed=M + N + K)
+    want = O.qbytes_mm_exact(p["x"], p["data"], p["scale"], kind)
+    assert_close_to_exact(_run_qbytes(p, "skinny"), want, dt, "qbytes skinny")
+    assert_close_to_exact(_run_qbytes(p, "auto"), want, dt, "qbytes auto")
+    assert quanto_hip.lib.last_kernel() == "skinny"
+    bias = O.round_to(np.random.default_rng(5).standard_normal(N).astype(np.float32), dt)
+    assert_close_with_bias(_run_qbytes(p, "skinny", bias), want, bias, dt, "qbytes skinny + bias")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("kind", [None, "e4m3fn", "e5m2"])
 @pytest.mark.parametrize("M,N,K", [(16, 128, 64), (128, 128, 512), (100, 200, 1024), (9, 130, 256), (512, 512, 2048), (257, 48, 128)])
 def test_qbytes_mfma(dt, kind, M, N, K):
     p = make_qbytes_problem(M, N, K, dt, kind, seed=M + K)
