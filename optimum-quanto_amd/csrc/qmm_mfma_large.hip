@@ -379,7 +379,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
       else
 #endif
       if (full) {
-        *reinterpret_cast<uint4*>(yg + (size_t)m * N + n) = v;
+        // non-temporal: the 2*M*N output bytes are not re-read by this kernel; streaming them past the L2 shortens the
+        // end-of-kernel write-back (measured: 19.4 -> 13.3 us at K = 128, -3 us at K = 4096)
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + (size_t)m * N + n));
       } else if (m < M) {
         const T* e = reinterpret_cast<const T*>(&v);
 #pragma unroll

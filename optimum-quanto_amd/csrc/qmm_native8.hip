@@ -283,7 +283,8 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
       const int m = m0 + wm * 128 + row;
       const int n = n0 + wn * 64 + p * (64 / PASSES) + c16 * (16 / (int)sizeof(T));
       if (full) {
-        *reinterpret_cast<uint4*>(yg + (size_t)m * N + n) = v;
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // non-temporal: see qmm_mfma_large.hip
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + (size_t)m * N + n));
       } else if (m < M) {
         const T* e = reinterpret_cast<const T*>(&v);
 #pragma unroll
