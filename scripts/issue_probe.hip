@@ -12,7 +12,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
-enum { F_NONE, F_CVT_SDWA, F_CVT_PK, F_AND_OR, F_PERM, F_DSREAD, F_SNOP, F_CVT_UBYTE, F_MIX3, F_I8MFMA, F_CVT_FP8 };
+enum { F_NONE, F_CVT_SDWA, F_CVT_PK, F_AND_OR, F_PERM, F_DSREAD, F_SNOP, F_CVT_UBYTE, F_MIX3, F_I8MFMA, F_CVT_FP8, F_MFMA32, F_MFMA32_MIX };
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 template <int KIND, int K, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) probe(unsigned long long* out, int iters, float seed) {
@@ -21,6 +22,9 @@ __global__ void __launch_bounds__(WAVES * 64) probe(unsigned long long* out, int
   for (int i = threadIdx.x; i < 4096; i += blockDim.x) reinterpret_cast<unsigned*>(lds)[i] = i * 2654435761u;
   __syncthreads();
   f32x4 acc[8];
+  f32x16 acc32[4];
+  for (int j = 0; j < 4; ++j)
+    for (int e = 0; e < 16; ++e) acc32[j][e] = seed;
   i32x4 iacc[8];
   for (int j = 0; j < 8; ++j) acc[j] = f32x4{seed, 0.f, 0.f, 0.f}, iacc[j] = i32x4{0, 0, 0, 0};
   bf16x8 a, b;
@@ -32,7 +36,11 @@ __global__ void __launch_bounds__(WAVES * 64) probe(unsigned long long* out, int
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      if constexpr (KIND == F_I8MFMA)
+      if constexpr (KIND == F_MFMA32 || KIND == F_MFMA32_MIX) {
+        // same flops per loop iteration: four 32x32x16 MFMAs instead of eight 16x16x32
+        if (j < 4) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc32[j]) : "v"(a), "v"(b));
+        if (j >= 4 && KIND == F_MFMA32) continue;
+      } else if constexpr (KIND == F_I8MFMA)
         asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(iacc[j]) : "v"(__builtin_bit_cast(i32x4, a)), "v"(__builtin_bit_cast(i32x4, b)));
       else
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(a), "v"(b));
@@ -55,7 +63,7 @@ __global__ void __launch_bounds__(WAVES * 64) probe(unsigned long long* out, int
           asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(f2) : "v"(r0));
         else if constexpr (KIND == F_CVT_FP8)
           asm volatile("v_cvt_pk_f32_fp8 %0, %1" : "=v"(*reinterpret_cast<double*>(&f2)) : "v"(r0));
-        else if constexpr (KIND == F_MIX3) {  // the real conversion recipe: 2 sdwa cvt + 1 pk per output dword
+        else if constexpr (KIND == F_MIX3 || KIND == F_MFMA32_MIX) {  // the real conversion recipe: 2 sdwa cvt + 1 pk per output dword
           if (k % 3 == 2)
             asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r1) : "v"(f2), "v"(f3));
           else if (k % 3 == 1)
@@ -70,6 +78,7 @@ __global__ void __launch_bounds__(WAVES * 64) probe(unsigned long long* out, int
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   float s = f2 + f3 + __builtin_bit_cast(float, r1 ^ r2);
   for (int j = 0; j < 8; ++j) s += acc[j][0] + (float)iacc[j][0];
+  for (int j = 0; j < 4; ++j) s += acc32[j][0];
   if (lane == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = t1 - t0;
   if (s == 12345.678f) out[1] = 1;
 }
@@ -108,6 +117,11 @@ int main() {
   const int blocks = 256;
   run<F_NONE, 0, 4>("mfma only", dbg, blocks);
   run<F_NONE, 0, 8>("mfma only", dbg, blocks);
+  run<F_MFMA32, 0, 4>("32x32x16 (x0.5)", dbg, blocks);  // reported per 16x16x32-equivalent: 8 per iteration
+  run<F_MFMA32, 0, 8>("32x32x16 (x0.5)", dbg, blocks);
+  run<F_MFMA32_MIX, 1, 8>("32x32 + mix", dbg, blocks);   // K fillers behind each of 8 slots (4 of them hold an MFMA): 2K VALU per 32x32 MFMA
+  run<F_MFMA32_MIX, 2, 8>("32x32 + mix", dbg, blocks);
+  run<F_MFMA32_MIX, 3, 8>("32x32 + mix", dbg, blocks);
   run<F_I8MFMA, 0, 4>("i8 mfma", dbg, blocks);
   run<F_I8MFMA, 0, 8>("i8 mfma", dbg, blocks);
   RUN_K(F_SNOP, "s_nop", 4);
