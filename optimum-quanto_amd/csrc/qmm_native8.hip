@@ -10,6 +10,7 @@
 // one software-pipelined instruction stream per wave, one barrier per K-tile, LDS-transposed full-line epilogue), with a
 // K-tile of 64 bytes per row for BOTH operands (4 stages of 32 KiB): 12 ds_read_b128, 4 DMA issues and 32 (int8) or
 // 64 (fp8) MFMAs per wave and K-tile.
+#include <cstdlib>
 #include <type_traits>
 
 #include "qh_common.h"
@@ -65,7 +66,9 @@ struct Args {
   int M, N, K;
 };
 
-template <int ODT, int KIND>
+// PAIRED (fp8 kinds, K % 128 == 0): K-tiles are consumed two at a time by the K = 128 MX-format MFMA (unit scales), which runs
+// at twice the rate of the 16x16x32 fp8 MFMA - see the paired loop below.
+template <int ODT, int KIND, bool PAIRED = false>
 __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
   using E = Elem<ODT>;
   using T = typename E::T;
@@ -162,69 +165,140 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
     }
   };
 
-  // prologue: tiles 0, 1, 2 in flight; tiles 0 and 1 visible (tile 1 feeds the prefetches issued during tile 0)
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
-  if (nk > 2) {
-    issue(2, 2);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  if constexpr (PAIRED) {
+    // ---- fp8 x fp8 on v_mfma_scale_f32_16x16x128_f8f6f4 --------------------------------------------------------------------
+    // An operand is 32 bytes per lane: the lane's 16 bytes of tile 2p (k = 16g..16g+15 of that tile) followed by its 16 bytes
+    // of tile 2p+1 - the same k assignment in both operands.  Pair p = 32 MFMAs per wave in two halves:
+    //   half A: token fragments 0..3 x weight fragments 0..3, while X[4..7] of THIS pair are fetched;
+    //   (own DMA share of tiles 2p+2, 2p+3 landed -> barrier -> refill the stages of tiles 2p, 2p+1 with tiles 2p+4, 2p+5)
+    //   half B: weight-fragment-major over token fragments 4..7; X[0..3] and each W[j], dead after its last MFMA, are
+    //           refetched for pair p+1.
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    constexpr int FMTSEL = KIND == K_F8E4M3 ? 0 : 1;  // cbsz / blgp: 0 = fp8 (e4m3), 1 = bf8 (e5m2)
+    i32x8 X[8], W[4];
+    auto load_pair = [&](i32x8& dst, const uint8_t* s0, const uint8_t* s1, int off) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(s0 + off), hi = *reinterpret_cast<const uint4*>(s1 + off);
+      dst = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    };
+    auto mma128 = [&](AV& c, const i32x8& w, const i32x8& x) {
+      c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, x, c, FMTSEL, FMTSEL, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);  // scales 2^0
+    };
+    const int np = nk >> 1;
+    // prologue: tiles 0..3 in flight, pair 0 visible, its W and X[0..3] in registers
 #pragma unroll
-  for (int j = 0; j < 4; ++j) wq[0][j] = read_w(smem, j);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) xf[i] = read_x(smem, i);
-
-  // tile kt (stage kt & 3): refill the stage of tile kt-1 with tile kt+3, prefetch from the stage of tile kt+1, and before
-  // the closing barrier wait for the own DMA share of tile kt+2 (tile kt+3 may stay in flight)
-  auto tile = [&](int kt, auto parity_tag, bool dma, int wait_mode /* 2: vmcnt(4), 1: vmcnt(0), 0: none */, bool barrier) {
-    constexpr int P = decltype(parity_tag)::value;
-    const uint8_t* sn = smem + ((kt + 1) & 3) * STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        mma(acc[j][i], wq[P][j], xf[i]);
-        if (j == 1) {
-          if (i < 4) wq[P ^ 1][i] = read_w(sn, i);
-        } else if (j == 2) {
-#if QH_N8_ABLATE != 1
-          if (i >= 4 && dma) issue_piece(kt + 3, (kt + 3) & 3, i - 4);
-#endif
-        } else if (j == 3) {
-          xf[i] = read_x(sn, i);  // same fragment of the next tile
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (wait_mode == 2)
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (wait_mode == 1)
+    for (int t = 0; t < 4; ++t)
+      if (t < nk) issue(t, t);
+    if (nk > 2)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (barrier) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_pair(W[j], smem, smem + STAGE_BYTES, boff0 + j * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_pair(X[i], smem, smem + STAGE_BYTES, aoff0 + i * 1024);
+    for (int p = 0; p < np; ++p) {
+      const uint8_t* c0 = smem + ((2 * p) & 3) * STAGE_BYTES;
+      const uint8_t* c1 = smem + ((2 * p + 1) & 3) * STAGE_BYTES;
+      const uint8_t* n0s = smem + ((2 * p + 2) & 3) * STAGE_BYTES;
+      const uint8_t* n1s = smem + ((2 * p + 3) & 3) * STAGE_BYTES;
+      // ---- half A ----
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          mma128(acc[j][i], W[j], X[i]);
+          if (j == 1) load_pair(X[4 + i], c0, c1, aoff0 + (4 + i) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (p + 1 < np) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tiles 2p+2, 2p+3 (issued one pair ago; nothing younger is in flight)
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // X[4..7] returned: this wave is done reading tiles 2p, 2p+1
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if (2 * p + 4 < nk) issue(2 * p + 4, (2 * p) & 3);
+      if (2 * p + 5 < nk) issue(2 * p + 5, (2 * p + 1) & 3);
+      // ---- half B ----
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 4; i < 8; ++i) {
+          mma128(acc[j][i], W[j], X[i]);
+          if (i == 5) load_pair(X[j], n0s, n1s, aoff0 + j * 1024);            // X[0..3] of the next pair (dead since half A)
+          if (i == 7) load_pair(W[j], n0s, n1s, boff0 + j * 1024);            // W[j] of the next pair: its last MFMA was just issued
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
-  };
-  using even = std::integral_constant<int, 0>;
-  using odd = std::integral_constant<int, 1>;
-  int kt = 0;
-  for (; kt + 4 < nk; kt += 2) {  // steady state: tiles kt+3 and kt+4 exist
-    tile(kt, even{}, true, 2, true);
-    tile(kt + 1, odd{}, true, 2, true);
-  }
-  // at most four tiles left (kt is even): nothing, or less, to prefetch - straight-line so the parity stays static
+  } else {
+  // prologue: tiles 0, 1, 2 in flight; tiles 0 and 1 visible (tile 1 feeds the prefetches issued during tile 0)
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 2) {
+      issue(2, 2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wq[0][j] = read_w(smem, j);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xf[i] = read_x(smem, i);
+
+    // tile kt (stage kt & 3): refill the stage of tile kt-1 with tile kt+3, prefetch from the stage of tile kt+1, and before
+    // the closing barrier wait for the own DMA share of tile kt+2 (tile kt+3 may stay in flight)
+    auto tile = [&](int kt, auto parity_tag, bool dma, int wait_mode /* 2: vmcnt(4), 1: vmcnt(0), 0: none */, bool barrier) {
+      constexpr int P = decltype(parity_tag)::value;
+      const uint8_t* sn = smem + ((kt + 1) & 3) * STAGE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          mma(acc[j][i], wq[P][j], xf[i]);
+          if (j == 1) {
+            if (i < 4) wq[P ^ 1][i] = read_w(sn, i);
+          } else if (j == 2) {
+#if QH_N8_ABLATE != 1
+            if (i >= 4 && dma) issue_piece(kt + 3, (kt + 3) & 3, i - 4);
+#endif
+          } else if (j == 3) {
+            xf[i] = read_x(sn, i);  // same fragment of the next tile
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (wait_mode == 2)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (wait_mode == 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (barrier) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    };
+    using even = std::integral_constant<int, 0>;
+    using odd = std::integral_constant<int, 1>;
+    int kt = 0;
+    for (; kt + 4 < nk; kt += 2) {  // steady state: tiles kt+3 and kt+4 exist
+      tile(kt, even{}, true, 2, true);
+      tile(kt + 1, odd{}, true, 2, true);
+    }
+    // at most four tiles left (kt is even): nothing, or less, to prefetch - straight-line so the parity stays static
 #define QH_TAIL_TILE(J, PARITY)                                                                                          \
-  if (kt + (J) < nk)                                                                                                     \
-    tile(kt + (J), PARITY{}, kt + (J) + 3 < nk, kt + (J) + 3 < nk ? 2 : (kt + (J) + 2 < nk ? 1 : 0), kt + (J) + 1 < nk)
-  QH_TAIL_TILE(0, even);
-  QH_TAIL_TILE(1, odd);
-  QH_TAIL_TILE(2, even);
-  QH_TAIL_TILE(3, odd);
+    if (kt + (J) < nk)                                                                                                     \
+      tile(kt + (J), PARITY{}, kt + (J) + 3 < nk, kt + (J) + 3 < nk ? 2 : (kt + (J) + 2 < nk ? 1 : 0), kt + (J) + 1 < nk)
+    QH_TAIL_TILE(0, even);
+    QH_TAIL_TILE(1, odd);
+    QH_TAIL_TILE(2, even);
+    QH_TAIL_TILE(3, odd);
 #undef QH_TAIL_TILE
+
+  }
 
   // ---- epilogue: (int32 | fp32) accumulator * scale[n] (+ bias), parked per wave in LDS, stored as full 128-byte lines ----
   T* yg = reinterpret_cast<T*>(a.y);
@@ -299,9 +373,18 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
 template <int ODT, int KIND>
 static int launch(const Args& a, hipStream_t stream) {
   constexpr int need = STAGES * STAGE_BYTES;  // 128 KiB; the epilogue parks 8 x 16 KiB in the same space
+  const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
+  if constexpr (KIND == K_F8E4M3 || KIND == K_F8E5M2) {
+    static const bool paired_ok = [] { const char* e = getenv("QUANTO_HIP_FP8_K128"); return !(e && e[0] == '0'); }();  // experiments
+    if (paired_ok && a.K % 128 == 0) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_kernel<ODT, KIND, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, need);
+      hipLaunchKernelGGL((qbytes_native8_kernel<ODT, KIND, true>), dim3(tiles), dim3(512), need, stream, a);
+      return launch_status();
+    }
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_kernel<ODT, KIND>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, need);
-  const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
   hipLaunchKernelGGL((qbytes_native8_kernel<ODT, KIND>), dim3(tiles), dim3(512), need, stream, a);
   return launch_status();
 }
