@@ -174,14 +174,21 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
     //   half B: weight-fragment-major over token fragments 4..7; X[0..3] and each W[j], dead after its last MFMA, are
     //           refetched for pair p+1.
     typedef __attribute__((ext_vector_type(8))) int i32x8;
-    constexpr int FMTSEL = KIND == K_F8E4M3 ? 0 : 1;  // cbsz / blgp: 0 = fp8 (e4m3), 1 = bf8 (e5m2)
+    constexpr int FMTSEL = KIND == K_F8E5M2 ? 1 : 0;  // cbsz / blgp: 0 = fp8 (e4m3), 1 = bf8 (e5m2)
     i32x8 X[8], W[4];
     auto load_pair = [&](i32x8& dst, const uint8_t* s0, const uint8_t* s1, int off) {
       const uint4 lo = *reinterpret_cast<const uint4*>(s0 + off), hi = *reinterpret_cast<const uint4*>(s1 + off);
       dst = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
     };
     auto mma128 = [&](AV& c, const i32x8& w, const i32x8& x) {
-      c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, x, c, FMTSEL, FMTSEL, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);  // scales 2^0
+      if constexpr (KIND == K_F8E4M3 || KIND == K_F8E5M2) {
+        c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, x, c, FMTSEL, FMTSEL, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);  // scales 2^0
+      } else {  // other kinds: the two tiles of the pair as two MFMAs (same schedule, half as many barriers as the per-tile loop)
+        const uint4 wl = make_uint4(w[0], w[1], w[2], w[3]), wh = make_uint4(w[4], w[5], w[6], w[7]);
+        const uint4 xl = make_uint4(x[0], x[1], x[2], x[3]), xh = make_uint4(x[4], x[5], x[6], x[7]);
+        mma(c, wl, xl);
+        mma(c, wh, xh);
+      }
     };
     const int np = nk >> 1;
     // prologue: tiles 0..3 in flight, pair 0 visible, its W and X[0..3] in registers
@@ -374,9 +381,13 @@ template <int ODT, int KIND>
 static int launch(const Args& a, hipStream_t stream) {
   constexpr int need = STAGES * STAGE_BYTES;  // 128 KiB; the epilogue parks 8 x 16 KiB in the same space
   const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
-  if constexpr (KIND == K_F8E4M3 || KIND == K_F8E5M2) {
-    static const bool paired_ok = [] { const char* e = getenv("QUANTO_HIP_FP8_K128"); return !(e && e[0] == '0'); }();  // experiments
-    if (paired_ok && a.K % 128 == 0) {
+  // the paired loop pays off only where one instruction consumes both tiles (fp8); as two MFMAs per pair it measured
+  // slower than the per-tile loop (int8 4096^3: 72 vs 66 us; dense bf16: 135 vs 127 us) - QUANTO_HIP_PAIRED=1 forces it
+  {
+    constexpr int ES = (KIND == K_BF16 || KIND == K_F16) ? 2 : 1;
+    constexpr bool FP8 = KIND == K_F8E4M3 || KIND == K_F8E5M2;
+    static const int paired_env = [] { const char* e = getenv("QUANTO_HIP_PAIRED"); return e ? atoi(e) : -1; }();  // experiments
+    if ((paired_env == 1 || (FP8 && paired_env != 0)) && (a.K * ES) % 128 == 0) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_kernel<ODT, KIND, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, need);
       hipLaunchKernelGGL((qbytes_native8_kernel<ODT, KIND, true>), dim3(tiles), dim3(512), need, stream, a);
