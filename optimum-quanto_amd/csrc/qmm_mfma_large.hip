@@ -118,6 +118,11 @@ struct Args {
   void* y;
   int M, N, K;
   int group_m;  // tile raster: groups of group_m tile rows, column-major inside a group (see tile_coords)
+  // split-K (S > 1): workgroup b computes K-range b % S of tile b / S; fp32 partial sums go to `partials` and the last
+  // workgroup of a tile to arrive adds them in split order (same protocol and workspace contract as qbits_skinny.hip)
+  int S;
+  int* counters;    // [tiles], zero on entry, zero on exit
+  float* partials;  // [tiles * S][threads][NJ * MI] float4
 };
 
 // XCD-aware tile order.  Consecutive workgroup ids land on different XCDs (id % 8), so first give every XCD a contiguous
@@ -168,11 +173,14 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int M = a.M, N = a.N, K = a.K;
-  const int nk = K / BK;
+  const int S = a.S;
+  const int tile_id = S > 1 ? blockIdx.x / S : blockIdx.x, sp = S > 1 ? blockIdx.x - tile_id * S : 0;
+  const int nk = K / BK / S;  // K-tiles of this workgroup's K-range
+  const int kt0 = sp * nk;
 
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
   int tm, tn;
-  tile_coords(blockIdx.x, tiles_m, tiles_n, a.group_m, tm, tn);
+  tile_coords(tile_id, tiles_m, tiles_n, a.group_m, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- DMA: per K-tile 32 activation pieces (8 rows x 128 B) + 16 weight pieces (16 rows x 64 B) of 1 KiB; 8 + 4 per wave
@@ -183,7 +191,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
     const int c = (lane & 7) ^ swz_a(R);
     int m = m0 + R;
     m = m < M ? m : M - 1;
-    asrc[j] = (uint32_t)(((size_t)m * K + c * 8) * 2);
+    asrc[j] = (uint32_t)(((size_t)m * K + c * 8 + (size_t)kt0 * BK) * 2);
   }
 #pragma unroll
   for (int j = 0; j < WPIECES; ++j) {
@@ -191,7 +199,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
     const int c = (lane & 3) ^ swz_w(R);
     int n = n0 + R;
     n = n < N ? n : N - 1;
-    wsrc[j] = (uint32_t)((size_t)n * K + c * 16);
+    wsrc[j] = (uint32_t)((size_t)n * K + c * 16 + (size_t)kt0 * BK);
   }
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
   const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.x);
@@ -336,6 +344,43 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if (S > 1) {
+    // split-K reduction: system-coherent 16-byte stores / loads of the partial sums (no L2-wide fence), one arrival counter
+    // per tile, the last workgroup to arrive sums in split order - see qbits_skinny.hip for the coherence argument
+    float* mine = a.partials + ((size_t)blockIdx.x * (NWAVES * 64) + tid) * (NJ * MI * 4);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + (j * MI + i) * 4), "v"(acc[j][i]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) *flag = __hip_atomic_fetch_add(a.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (*flag != S - 1) return;
+    if (tid == 0) __hip_atomic_store(a.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();  // the flag word is part of the parking area used below
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < S; ++q) {
+      const float* theirs = a.partials + ((size_t)(tile_id * S + q) * (NWAVES * 64) + tid) * (NJ * MI * 4);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        f32x4 v[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[i]) : "v"(theirs + (j * MI + i) * 4) : "memory");
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[i])::"memory");
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[j][i][r] += v[i][r];
+      }
+    }
+  }
   constexpr int JP = NJ < 4 ? NJ : 4;  // feature fragments per pass: parked rows of JP*32 bytes
   constexpr int ROWB = JP * 32, LPR = ROWB / 16;  // lanes per parked row on the read side
   uint8_t* park = smem + wave * (MI * 16 * ROWB);
@@ -415,7 +460,7 @@ static int launch_cfg(const Args& a, hipStream_t stream) {
   }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_mfma_large_kernel<DT, FMT, BM, BN, WM, WN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((qbytes_mfma_large_kernel<DT, FMT, BM, BN, WM, WN>), dim3(tiles), dim3(WM * WN * 64), lds, stream, b);
+  hipLaunchKernelGGL((qbytes_mfma_large_kernel<DT, FMT, BM, BN, WM, WN>), dim3(tiles * b.S), dim3(WM * WN * 64), lds, stream, b);
   return launch_status();
 }
 
@@ -435,15 +480,37 @@ bool qbytes_mfma_v2_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int 
          K >= 2 * lt::BK && M >= 1 && M * K < (1ll << 30) && N * K < (1ll << 31) && M < (1 << 30) && N < (1 << 30);
 }
 
+// split-K for the 128-tile configuration, only when its tiles cover at most half of the CUs and K is long: the partial
+// sums cost 64 KiB of system-coherent traffic per workgroup each way.  Measured (bf16 x int8, split 1 -> 2):
+// (512, 4096, 14336) 129 -> 95 us, but cfg4 (512, 8192, 8192; 256 tiles) 84 -> 105 us and (1024, 4096, 4096) 44 -> 76 us.
+static int large_split(int64_t M, int64_t N, int64_t K) {
+  static const int forced = [] { const char* e = getenv("QUANTO_HIP_LARGE_SPLIT"); return e ? atoi(e) : 0; }();  // experiments
+  const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256), tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+  int s = 1;
+  if (tiles256 < 96 && tiles128 <= 128 && K >= 4096 && (K / lt::BK) % 2 == 0) s = 2;
+  if (forced > 0 && tiles256 < 96 && (K / lt::BK) % forced == 0 && K / lt::BK / forced >= 2) s = forced;
+  return s;
+}
+static size_t large_counter_bytes(int64_t M, int64_t N) { return ((size_t)(((M + 127) / 128) * ((N + 127) / 128)) * 4 + 255) / 256 * 256; }
+size_t qbytes_mfma_large_workspace(int64_t M, int64_t N, int64_t K) {
+  const int S = large_split(M, N, K);
+  if (S == 1) return 0;
+  return large_counter_bytes(M, N) + (size_t)(((M + 127) / 128) * ((N + 127) / 128)) * S * (128 * 128 * 4);
+}
+
 int qbytes_mm_mfma_v2(const void* x, const void* w, const void* s, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int a_dtype,
-                      int b_dtype, int out_dtype, hipStream_t stream) {
+                      int b_dtype, int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbytes_mfma_v2_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
+  int split = large_split(M, N, K);
+  if (split > 1 && (!workspace || workspace_bytes < qbytes_mfma_large_workspace(M, N, K) || reinterpret_cast<uintptr_t>(workspace) % 16)) split = 1;
   // 256-tiles when they give every CU at least ~3/8 of a tile; otherwise 128-tiles (4x the workgroups)
   static const int forced = [] { const char* e = getenv("QUANTO_HIP_LARGE_CFG"); return e ? atoi(e) : -1; }();  // experiments
   const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
   const int cfg = forced >= 0 ? forced : (tiles256 >= 96 ? lt::CFG_256_8W : lt::CFG_128_4W);
+  if (cfg != lt::CFG_128_4W) split = 1;  // the workspace is sized for 128-tiles
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
-  lt::Args a{x, reinterpret_cast<const uint8_t*>(w), s, bias, y, (int)M, (int)N, (int)K, 1};
+  lt::Args a{x, reinterpret_cast<const uint8_t*>(w), s, bias, y, (int)M, (int)N, (int)K, 1, split, reinterpret_cast<int*>(workspace),
+             split > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + large_counter_bytes(M, N)) : nullptr};
 #define QH_CASE(DT, FMT) return lt::launch<DT, FMT>(a, cfg, stream)
   if (out_dtype == QUANTO_HIP_BF16) {
     if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_BF16, lt::W_I8);

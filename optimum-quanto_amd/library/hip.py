@@ -252,7 +252,7 @@ class _Bindings:
                 if k < 0:
                     self._check(k, "qbytes_mm_pick")
             ws, ws_bytes = None, 0
-            if k == KERNEL_SKINNY:
+            if k in (KERNEL_SKINNY, KERNEL_MFMA_LARGE):
                 ws_bytes = self._c.quanto_hip_qbytes_mm_workspace_size(M, N, K, _dt(a2), _dt(b), _dt(s), k)
                 if ws_bytes > 0:
                     ws = self._zeroed_workspace(a.device, ws_bytes)  # split-K arrival counters: zero on entry, left zero

@@ -284,6 +284,19 @@ def test_qbytes_mfma_large_tile(dt, kind, M, N, K):
     assert_close_to_exact(_run_qbytes(p, "mfma_large"), O.qbytes_mm_exact(p["x"], p["data"], p["scale"], kind), dt, "qbytes mfma_large")
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("kind", [None, "e4m3fn"])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 4096), (300, 700, 8192), (128, 256, 4096)])
+def test_qbytes_mfma_large_tile_split_k(dt, kind, M, N, K):
+    """128-tiles with the K-range halved across two workgroups per tile (few tiles, long K): partial sums through the
+    workspace, last-arriver reduction, ragged edges; called twice to check that the arrival counters were left zero."""
+    p = make_qbytes_problem(M, N, K, dt, kind, seed=M + K + 3)
+    want = O.qbytes_mm_exact(p["x"], p["data"], p["scale"], kind)
+    assert_close_to_exact(_run_qbytes(p, "mfma_large"), want, dt, "qbytes mfma_large split-K")
+    bias = O.round_to(np.random.default_rng(7).standard_normal(N).astype(np.float32), dt)
+    assert_close_with_bias(_run_qbytes(p, "mfma_large", bias), want, bias, dt, "qbytes mfma_large split-K + bias")
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("kind", [None, "e4m3fn", "e4m3fnuz", "e5m2"])
 @pytest.mark.parametrize("M,N,K", [(1, 48, 32), (10, 50, 50), (32, 64, 50), (7, 3, 5)])
