@@ -28,10 +28,6 @@
                         // 16 no output stores, 32 no epilogue at all
 #endif
 
-#ifndef QH_DMA_STEPS
-#define QH_DMA_STEPS 6
-#endif
-
 namespace qh {
 namespace lt {
 
@@ -160,7 +156,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   constexpr int WPIECES = BN / 16 / NWAVES;     // weight DMA pieces (16 rows x 64 B) per wave and K-tile
   constexpr int NPIECES = APIECES + WPIECES;
   constexpr int ND = (NJ * 4 + MI - 1) / MI;    // converted dwords per step (one phase converts NJ*4 dwords in MI steps)
-  constexpr int DSTEPS = QH_DMA_STEPS;          // the DMA of tile kt+2 is issued over the first DSTEPS steps of tile kt
+  constexpr int DSTEPS = NPIECES % 6 == 0 ? 6 : 3;  // the DMA of tile kt+2 is issued over the first DSTEPS steps of tile kt
   constexpr int PPS = NPIECES / DSTEPS;         // pieces per step
   static_assert(NPIECES % DSTEPS == 0 && STEPS % 4 == 0 && ND <= NJ && PPS <= NJ, "unsupported tile configuration");
   using E = Elem<DT>;
@@ -293,7 +289,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
           xf[(s + 2) & 3] = s + 2 < STEPS ? read_x(st, (s + 2) % MI, (s + 2) / MI) : read_x(sn, s + 2 - STEPS, 0);
 #endif
         }
-        if (j == (ND + 1 < NJ ? ND + 1 : 1)) {
+        if (j == (ND + 1 < NJ ? ND + 1 : NJ - 1)) {
           // next tile's raw weight bytes: fragment f is dead once the last dword of its k-half 1 is converted, i.e. after
           // phase-0 step (4f+3)/ND; it is reloaded in the following step (phase-1 step 0 for the last fragment)
 #if !(QH_V3_ABLATE & 2)
@@ -468,6 +464,7 @@ template <int DT, int FMT>
 static int launch(const Args& a, int cfg, hipStream_t stream) {
   // three 24 KiB stages: two workgroups share a CU (two interleaving streams per SIMD)
   if (cfg == CFG_128_4W) return launch_cfg<DT, FMT, 128, 128, 1, 4>(a, stream);
+  // (tried: 128-tiles as eight waves of 128 x 16 with one workgroup per CU - LDS-bound, cfg4 90-98 us vs 86-90 us)
   if (cfg == CFG_256_4W) return launch_cfg<DT, FMT, 256, 256, 2, 2>(a, stream);
   return launch_cfg<DT, FMT, 256, 256, 2, 4>(a, stream);
 }
