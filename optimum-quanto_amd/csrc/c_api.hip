@@ -21,8 +21,8 @@ bool qbytes_gemv_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_gemv(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 bool qbytes_mfma_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_mfma(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
-bool qbytes_mfma_v2_supported(int64_t, int64_t, int64_t, int, int, int);
-int qbytes_mm_mfma_v2(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, void*, size_t, hipStream_t);
+bool qbytes_mfma_large_supported(int64_t, int64_t, int64_t, int, int, int);
+int qbytes_mm_mfma_large(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, void*, size_t, hipStream_t);
 size_t qbytes_mfma_large_workspace(int64_t, int64_t, int64_t);
 int quantize_symmetric(const void*, const void*, void*, int64_t, int64_t, int, int, int, hipStream_t);
 int quantize_affine(const void*, const void*, const void*, void*, int64_t, int64_t, int, int, bool, hipStream_t);
@@ -201,7 +201,7 @@ static int pick_qbytes_kernel(int64_t M, int64_t N, int64_t K, int a_dtype, int 
   if (M <= 2 && qbytes_gemv_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_KERNEL_GEMV;
   if (qbytes_native8_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_KERNEL_NATIVE8;
   const bool skinny = qbytes_skinny_supported(M, N, K, a_dtype, b_dtype, out_dtype);
-  const bool large = qbytes_mfma_v2_supported(M, N, K, a_dtype, b_dtype, out_dtype);
+  const bool large = qbytes_mfma_large_supported(M, N, K, a_dtype, b_dtype, out_dtype);
   if (skinny && M <= 64) return QUANTO_HIP_KERNEL_SKINNY;
   if (large && prefer_large_tile(M, N)) return QUANTO_HIP_KERNEL_MFMA_LARGE;
   if (skinny) return QUANTO_HIP_KERNEL_SKINNY;
@@ -223,7 +223,7 @@ int64_t quanto_hip_qbytes_mm_workspace_size(int64_t M, int64_t N, int64_t K, int
   if (kernel == QUANTO_HIP_KERNEL_AUTO) kernel = pick_qbytes_kernel(M, N, K, a_dtype, b_dtype, out_dtype);
   if (kernel == QUANTO_HIP_KERNEL_SKINNY && qbytes_skinny_supported(M, N, K, a_dtype, b_dtype, out_dtype))
     return (int64_t)qbytes_skinny_workspace(M, N, K);
-  if (kernel == QUANTO_HIP_KERNEL_MFMA_LARGE && qbytes_mfma_v2_supported(M, N, K, a_dtype, b_dtype, out_dtype))
+  if (kernel == QUANTO_HIP_KERNEL_MFMA_LARGE && qbytes_mfma_large_supported(M, N, K, a_dtype, b_dtype, out_dtype))
     return (int64_t)qbytes_mfma_large_workspace(M, N, K);
   return 0;
 }
@@ -255,7 +255,7 @@ int quanto_hip_qbytes_mm_ws(const void* a, const void* b, const void* scales, co
       if (r == QUANTO_HIP_OK) set_last_kernel("mfma");
       return r;
     case QUANTO_HIP_KERNEL_MFMA_LARGE:
-      r = qbytes_mm_mfma_v2(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, workspace, workspace_bytes, stream);
+      r = qbytes_mm_mfma_large(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, workspace, workspace_bytes, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("mfma_large");
       return r;
     case QUANTO_HIP_KERNEL_NATIVE8:

@@ -23,10 +23,6 @@
 
 #include "qh_common.h"
 
-#ifndef QH_V3_ABLATE
-#define QH_V3_ABLATE 0  // timing experiments only (wrong results): 1 no conversion, 2 no fragment reads, 4 no DMA, 8 no barrier,
-                        // 16 no output stores, 32 no epilogue at all
-#endif
 
 namespace qh {
 namespace lt {
@@ -99,11 +95,11 @@ __device__ __forceinline__ uint32_t convert_pair(uint32_t word, int p) {
   return Mma<DT>::pack(f0, f1);
 }
 
-#ifdef QH_V3_STAMPS
+#ifdef QH_LT_STAMPS
 __device__ unsigned long long g_stamps[256 * 8];  // per workgroup: s_memrealtime (100 MHz) at entry / loop start / loop end / exit
-#define QH_V3_STAMP(i) do { if (threadIdx.x == 0) g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define QH_LT_STAMP(i) do { if (threadIdx.x == 0) g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
-#define QH_V3_STAMP(i) do { } while (0)
+#define QH_LT_STAMP(i) do { } while (0)
 #endif
 
 struct Args {
@@ -164,7 +160,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   using V8 = typename Mma<DT>::V8;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
-  QH_V3_STAMP(0);
+  QH_LT_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -239,10 +235,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
     for (int p = 0; p < NPIECES; ++p) issue_piece(1, 1, p);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile 1 too: its weight bytes are fetched during tile 0
-  QH_V3_STAMP(1);
+  QH_LT_STAMP(1);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  QH_V3_STAMP(2);
+  QH_LT_STAMP(2);
 #pragma unroll
   for (int j = 0; j < NJ; ++j) raw[j] = read_raw(smem, j);
 #pragma unroll
@@ -274,35 +270,27 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
         if (j < ND && i * ND + j < NJ * 4) {
           // conversion: step i of a phase produces dwords i*ND .. i*ND+ND-1 of the phase's NJ*4 (fragment-major)
           const int c = i * ND + j, f = c >> 2, d = c & 3;
-#if QH_V3_ABLATE & 1
-          if (kk == 0) w1[f][d] = rawword(f, 1, d); else w0[f][d] = rawword(f, 0, d);
-#else
           if (kk == 0)
             w1[f][d] = convert_pair<DT, FMT>(rawword(f, 1, d), d & 1);  // this tile's k-half 1
           else
             w0[f][d] = convert_pair<DT, FMT>(rawword(f, 0, d), d & 1);  // next tile's k-half 0 (raw[f] already holds tile kt+1)
-#endif
         }
         if (j == (ND < NJ ? ND : 0)) {
           // activation fragment of step s+2 (the first two of the next tile at the end; garbage, unused, on the last tile)
-#if !(QH_V3_ABLATE & 2)
           xf[(s + 2) & 3] = s + 2 < STEPS ? read_x(st, (s + 2) % MI, (s + 2) / MI) : read_x(sn, s + 2 - STEPS, 0);
-#endif
         }
         if (j == (ND + 1 < NJ ? ND + 1 : NJ - 1)) {
           // next tile's raw weight bytes: fragment f is dead once the last dword of its k-half 1 is converted, i.e. after
           // phase-0 step (4f+3)/ND; it is reloaded in the following step (phase-1 step 0 for the last fragment)
-#if !(QH_V3_ABLATE & 2)
 #pragma unroll
           for (int f = 0; f < NJ; ++f)
             if (s == (4 * f + 3) / ND + 1) raw[f] = read_raw(sn, f);
-#endif
         }
-        if (DMA && !(QH_V3_ABLATE & 4) && j >= NJ - PPS && s < DSTEPS) issue_piece(kt + 2, nxt2, PPS * s + (j - (NJ - PPS)));
+        if (DMA && j >= NJ - PPS && s < DSTEPS) issue_piece(kt + 2, nxt2, PPS * s + (j - (NJ - PPS)));
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (BARRIER && !(QH_V3_ABLATE & 8)) {
+    if (BARRIER) {
       // tile boundary: the own DMA share of tile kt+2, issued in the first steps of this tile, has landed -> barrier ->
       // everybody's share visible and every wave done with tile kt, whose stage the next tile refills.  vmcnt(0), not
       // "all but the newest pieces": tile kt+1 prefetches its successor's weight bytes and first activation fragments
@@ -317,24 +305,15 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
-  QH_V3_STAMP(3);
+  QH_LT_STAMP(3);
   int kt = 0;
   for (; kt + 2 < nk; ++kt) tile(kt, yes{}, yes{});
   tile(kt, no{}, yes{});  // nk >= 2: tiles nk-2 and nk-1 have nothing left to prefetch
   tile(kt + 1, no{}, no{});
-  QH_V3_STAMP(4);
+  QH_LT_STAMP(4);
 
   // ---- epilogue: scale (+bias) on the fp32 accumulator; each wave parks MI*16 tokens x 64 features per pass -------------
   T* yg = reinterpret_cast<T*>(a.y);
-#if QH_V3_ABLATE & 32
-  {
-    float sum = 0.f;
-    for (int j = 0; j < NJ; ++j)
-      for (int i = 0; i < MI; ++i) sum += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
-    if (sum == 1.2345f) yg[0] = E::from_f32(sum);
-    return;
-  }
-#endif
   const bool has_bias = a.bias != nullptr;
   const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (N % 8 == 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -415,10 +394,6 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
       const uint4 v = *reinterpret_cast<const uint4*>(park + row * ROWB + (((c16 * 2) ^ ((row & (LPR - 1)) << 1)) * 8));
       const int m = m0 + wm * (MI * 16) + row;
       const int n = n0 + wn * (NJ * 16) + p * (JP * 16) + c16 * 8;
-#if QH_V3_ABLATE & 16
-      if (v.x == 0x12345678u) *reinterpret_cast<uint4*>(yg + (size_t)m * N + n) = v;
-      else
-#endif
       if (full) {
         // non-temporal: the 2*M*N output bytes are not re-read by this kernel; streaming them past the L2 shortens the
         // end-of-kernel write-back (measured: 19.4 -> 13.3 us at K = 128, -3 us at K = 4096)
@@ -433,9 +408,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  QH_V3_STAMP(5);
+  QH_LT_STAMP(5);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  QH_V3_STAMP(6);
+  QH_LT_STAMP(6);
 }
 
 enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2 };
@@ -471,7 +446,7 @@ static int launch(const Args& a, int cfg, hipStream_t stream) {
 
 }  // namespace lt
 
-bool qbytes_mfma_v2_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
+bool qbytes_mfma_large_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
   const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2;
   return bd && a_dtype == out_dtype && (out_dtype == QUANTO_HIP_BF16 || out_dtype == QUANTO_HIP_F16) && K % lt::BK == 0 &&
          K >= 2 * lt::BK && M >= 1 && M * K < (1ll << 30) && N * K < (1ll << 31) && M < (1 << 30) && N < (1 << 30);
@@ -495,9 +470,9 @@ size_t qbytes_mfma_large_workspace(int64_t M, int64_t N, int64_t K) {
   return large_counter_bytes(M, N) + (size_t)(((M + 127) / 128) * ((N + 127) / 128)) * S * (128 * 128 * 4);
 }
 
-int qbytes_mm_mfma_v2(const void* x, const void* w, const void* s, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int a_dtype,
+int qbytes_mm_mfma_large(const void* x, const void* w, const void* s, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int a_dtype,
                       int b_dtype, int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  if (!qbytes_mfma_v2_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
+  if (!qbytes_mfma_large_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
   int split = large_split(M, N, K);
   if (split > 1 && (!workspace || workspace_bytes < qbytes_mfma_large_workspace(M, N, K) || reinterpret_cast<uintptr_t>(workspace) % 16)) split = 1;
   // 256-tiles when they give every CU at least ~3/8 of a tile; otherwise 128-tiles (4x the workgroups)

@@ -1,5 +1,5 @@
 // Debug harness (not part of the library): where the time of one qbytes_mfma_large launch goes (prologue / K loop / epilogue).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -DQH_V3_STAMPS scripts/large_tile_timing.hip -o scripts/large_tile_timing.bin
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -DQH_LT_STAMPS scripts/large_tile_timing.hip -o scripts/large_tile_timing.bin
 #include <cstdio>
 #include <vector>
 #include <algorithm>
@@ -13,7 +13,7 @@ int main() {
     hipMalloc(&x, hx.size() * 2); hipMalloc(&w, hw.size()); hipMalloc(&sc, N * 2); hipMalloc(&y, (size_t)M * N * 2);
     hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), hw.size(), hipMemcpyHostToDevice);
     hipMemcpy(sc, hs.data(), N * 2, hipMemcpyHostToDevice);
-    qh::lt::Args a{x, (const uint8_t*)w, sc, nullptr, y, M, N, K, 4};
+    qh::lt::Args a{x, (const uint8_t*)w, sc, nullptr, y, M, N, K, 4, 1, nullptr, nullptr};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) qh::lt::launch<QUANTO_HIP_BF16, qh::lt::W_I8>(a, qh::lt::CFG_256_8W, 0);
     hipEventRecord(e0, 0);
