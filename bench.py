@@ -2,7 +2,7 @@
 """Headline benchmark: QLinear GEMM throughput on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
-                    [--workload cfg2|cfg3|northstar|cfg4|w8a8|fp8a8|int4_prefill]
+                    [--workload cfg2|cfg3|northstar|cfg4|w8a8|fp8a8|int4_prefill|int8_decode|int4_decode32]
 
 A *step* is one pass of the hot path (one ``quanto::qbytes_mm`` / ``quanto::qbits_mm`` call through the C ABI) over
 one batch of synthetic input already resident in HBM.  The default workload is BASELINE.json ``configs[1]``:
@@ -44,6 +44,8 @@ WORKLOADS = {
     "w8a8": ("qbytes_i8i8", 4096, 4096, 4096, "int8 x int8 qbytes_mm (quantized activations), int32 accumulate, (M,K,N)=(4096,4096,4096)"),
     "fp8a8": ("qbytes_f8f8", 4096, 4096, 4096, "fp8-e4m3fn x fp8-e4m3fn qbytes_mm (quantized activations), (M,K,N)=(4096,4096,4096)"),
     "int4_prefill": ("qbits_i4", 4096, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, prefill (M,K,N)=(4096,4096,4096)"),
+    "int8_decode": ("qbytes_i8", 1, 4096, 4096, "bf16 x int8 qbytes_mm, per-channel scale, decode (M,K,N)=(1,4096,4096)"),
+    "int4_decode32": ("qbits_i4", 32, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,4096)"),
 }
 ARITH_DTYPE = {"qbytes_i8": "bf16", "qbytes_f8": "bf16", "qbits_i4": "bf16", "qbytes_i8i8": "int8", "qbytes_f8f8": "fp8"}
 
@@ -180,7 +182,7 @@ def main():
     flops, nbytes = algorithmic_work(kind, M, K, N)
     weight_bytes = N * K // 2 if kind == "qbits_i4" else N * K
     # decode workloads: rotate over > 512 MB of weights so each launch reads HBM (SURVEY.md 8d "cache hygiene")
-    n_weights = max(1, -(-(512 << 20) // weight_bytes)) if M <= 8 else 1
+    n_weights = max(1, -(-(512 << 20) // weight_bytes)) if M <= 64 else 1
     x, sets = build_inputs(kind, M, K, N, device, n_weights, seed=1234 + rank)
     step, lib = make_step(kind, x, sets, K, N)
 
@@ -237,7 +239,7 @@ def main():
                     "frac": round(achieved / peak, 4), "traffic": None}
         else:
             value = nbytes * world / (elapsed / args.steps) / 1e9
-            metric, unit = "QLinear GEMM GB/s (bf16 x int4 qbits_mm, decode)", "GB/s"
+            metric, unit = f"QLinear GEMM GB/s ({'bf16 x int4 qbits_mm' if kind == 'qbits_i4' else 'bf16 x int8 qbytes_mm'}, decode)", "GB/s"
             achieved = nbytes / (launch_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}

@@ -1,8 +1,8 @@
 // qbytes_mm for decode shapes (M <= 8): weight-streaming GEMV for int8 / fp8 weights [N, K].
 //
-// HBM-bound: one wave streams one weight row (K bytes, coalesced 16-byte loads), x stays in
-// registers as fp32, products are accumulated in fp32 (int8 -> fp32 by v_cvt_f32_i32 with SDWA byte
-// select, fp8 -> fp32 by v_cvt_pk_f32_fp8) and the per-channel scale is applied once in the epilogue:
+// HBM-bound: coalesced 16-byte loads of the weight rows, x stays in registers as fp32, products are
+// accumulated in fp32 (int8 -> fp32 by v_cvt_f32_i32 with SDWA byte select, fp8 -> fp32 by
+// v_cvt_pk_f32_fp8) and the per-channel scale is applied once in the epilogue:
 // y[m,n] = scale[n] * sum_k x[m,k] * q[n,k]   (library/qbytes_mm.py:25-33 without materialising scale*W).
 #include "qh_common.h"
 
@@ -30,34 +30,64 @@ __device__ __forceinline__ void decode_word<QUANTO_HIP_F8_E5M2>(uint32_t w, floa
   f[0] = lo.x; f[1] = lo.y; f[2] = hi.x; f[3] = hi.y;
 }
 
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over the 64 lanes; only lane 63 holds the total
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v += dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);       // row_half_mirror
+  v += dpp_f<0x140>(v);       // row_mirror
+  v += dpp_f<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+  v += dpp_f<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3 -> lane 63 holds the total
+  return v;
+}
+
+constexpr int RR8 = 4;  // weight rows per wave pass
+
+// Latency-first layout (same as qbits_gemv.hip): a decode call lasts a few microseconds, so every byte a wave needs is
+// requested in its first instructions.  A wave owns K-slabs of 1024 k (slab = wave % wpr, stride wpr, at most ITERS of
+// them), keeps that slice of x in registers as fp32 and streams RR8 weight rows at a time: RR8 * ITERS 16-byte loads per
+// lane in flight.  Per-slab partial sums are reduced with DPP adds and combined across the wpr waves through LDS.
 template <int DT, int BDT, int MT, int ITERS>
 __global__ void __launch_bounds__(256)
     qbytes_gemv_kernel(const uint16_t* __restrict__ x, const uint8_t* __restrict__ w, const uint16_t* __restrict__ scales,
                        const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int N, int K, int wpr) {
   using E = Elem<DT>;
   using T = typename E::T;
-  __shared__ float red[2][4][MT];
+  __shared__ float red[4][RR8][MT];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int slab = wave % wpr;
-  const int row_in_block = wave / wpr;
-  const int rpb = 4 / wpr;
+  const int slab0 = wave % wpr;
+  const int rgroup = wave / wpr;
+  const int n0 = (blockIdx.x * (4 / wpr) + rgroup) * RR8;
 
-  float X[ITERS][MT][16];
+  // ---- 1. request everything: weights first, then the x slice ----------------------------------------------------------
+  int k0[ITERS];
   bool valid[ITERS];
+  uint4 W[RR8][ITERS];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int k0 = ((slab * ITERS + it) * 64 + lane) * 16;
-    valid[it] = k0 < K;
+    k0[it] = ((slab0 + it * wpr) * 64 + lane) * 16;
+    valid[it] = k0[it] < K;
+    k0[it] = valid[it] ? k0[it] : 0;  // out-of-range slabs read (and then ignore) the start of the row
+#pragma unroll
+    for (int r = 0; r < RR8; ++r) {
+      const int n = n0 + r < N ? n0 + r : N - 1;  // clamped, unconditional: rows beyond N are computed on duplicates, never stored
+      W[r][it] = *reinterpret_cast<const uint4*>(w + (size_t)n * K + k0[it]);
+    }
+  }
+  float X[ITERS][MT][16];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
-      if (valid[it]) {
-        const uint4* px = reinterpret_cast<const uint4*>(x + (size_t)m * K + k0);
-        a = px[0];
-        b = px[1];
-      }
-      const uint32_t pr[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      const uint4* px = reinterpret_cast<const uint4*>(x + (size_t)m * K + k0[it]);
+      const uint4 a = px[0], b = px[1];
+      const uint32_t keep = valid[it] ? 0xFFFFFFFFu : 0u;  // x = 0 beyond K: such a slab contributes exactly 0
+      const uint32_t pr[8] = {a.x & keep, a.y & keep, a.z & keep, a.w & keep, b.x & keep, b.y & keep, b.z & keep, b.w & keep};
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         X[it][m][2 * q] = E::to_f32(__builtin_bit_cast(T, (uint16_t)(pr[q] & 0xFFFFu)));
@@ -65,83 +95,63 @@ __global__ void __launch_bounds__(256)
       }
     }
   }
-  const uint8_t* wbase = w + (size_t)(slab * ITERS) * 1024 + lane * 16;
-  auto load_row = [&](int n, uint4 (&W)[ITERS]) {
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      W[it] = make_uint4(0, 0, 0, 0);
-      if (valid[it]) W[it] = *reinterpret_cast<const uint4*>(wbase + (size_t)n * K + it * 1024);
-    }
-  };
 
-  uint4 Wcur[ITERS], Wnxt[ITERS];
-  const int stride = gridDim.x * rpb;
-  int n = blockIdx.x * rpb + row_in_block;
-  if (n < N) load_row(n, Wcur);
-  int parity = 0;
-  for (int nbase = blockIdx.x * rpb; nbase < N; nbase += stride, n += stride, parity ^= 1) {
-    const bool active = n < N;
-    if (n + stride < N) load_row(n + stride, Wnxt);
-    float acc[MT];
+  // ---- 2. products: exact value of every int8 / fp8 weight in fp32, fp32 fma --------------------------------------------------
+  float acc[RR8][MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-    if (active) {
+  for (int r = 0; r < RR8; ++r)
 #pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
-        const uint32_t w4[4] = {Wcur[it].x, Wcur[it].y, Wcur[it].z, Wcur[it].w};
+    for (int m = 0; m < MT; ++m) acc[r][m] = 0.f;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          float f[4];
-          decode_word<BDT>(w4[d], f);
+  for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
+    for (int r = 0; r < RR8; ++r) {
+      const uint32_t w4[4] = {W[r][it].x, W[r][it].y, W[r][it].z, W[r][it].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[m] = __builtin_fmaf(f[e], X[it][m][4 * d + e], acc[m]);
-        }
-      }
+      for (int d = 0; d < 4; ++d) {
+        float f[4];
+        decode_word<BDT>(w4[d], f);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = wave_sum(acc[m]);
-    }
-    if (wpr == 1) {
-      if (active && lane < MT) {
-        float r = 0.f;
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) r = lane == m ? acc[m] : r;
-        r *= E::to_f32(__builtin_bit_cast(T, scales[n]));
-        if (bias) r = E::to_f32(E::from_f32(r)) + E::to_f32(__builtin_bit_cast(T, bias[n]));
-        y[(size_t)lane * N + n] = __builtin_bit_cast(uint16_t, E::from_f32(r));
-      }
-    } else {
-      if (lane == 0) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) red[parity][wave][m] = acc[m];
-      }
-      __syncthreads();
-      if (active && slab == 0 && lane < MT) {
-        float r = 0.f;
-        for (int s = 0; s < wpr; ++s) r += red[parity][wave + s][lane];
-        r *= E::to_f32(__builtin_bit_cast(T, scales[n]));
-        if (bias) r = E::to_f32(E::from_f32(r)) + E::to_f32(__builtin_bit_cast(T, bias[n]));
-        y[(size_t)lane * N + n] = __builtin_bit_cast(uint16_t, E::from_f32(r));
+          for (int e = 0; e < 4; ++e) acc[r][m] = __builtin_fmaf(f[e], X[it][m][4 * d + e], acc[r][m]);
       }
     }
+  }
+
+  // ---- 3. reduce over lanes (DPP), over the wpr waves (LDS), scale, store --------------------------------------------------------
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) Wcur[it] = Wnxt[it];
+  for (int r = 0; r < RR8; ++r)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[r][m] = wave_sum_lane63(acc[r][m]);
+  if (lane == 63) {
+#pragma unroll
+    for (int r = 0; r < RR8; ++r)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) red[wave][r][m] = acc[r][m];
+  }
+  __syncthreads();
+  if (slab0 == 0 && lane < RR8 * MT) {
+    const int r = lane / MT, m = lane % MT;
+    const int n = n0 + r;
+    if (n < N) {
+      float v = 0.f;
+      for (int s = 0; s < wpr; ++s) v += red[wave + s][r][m];
+      v *= E::to_f32(__builtin_bit_cast(T, scales[n]));
+      if (bias) v = E::to_f32(E::from_f32(v)) + E::to_f32(__builtin_bit_cast(T, bias[n]));
+      y[(size_t)m * N + n] = __builtin_bit_cast(uint16_t, E::from_f32(v));
+    }
   }
 }
 
 template <int DT, int BDT, int MT>
 static int launch_iters(const void* x, const void* w, const void* s, const void* bias, void* y, int N, int K, hipStream_t stream) {
-  const int its_total = (K + 1023) / 1024;
-  int wpr = 1, iters = its_total;
-  if (its_total > 4) {
-    wpr = its_total > 8 ? 4 : 2;
-    iters = (its_total + wpr - 1) / wpr;
-  }
+  const int nslab = (K + 1023) / 1024;
+  const int wpr = nslab >= 3 ? 4 : nslab;  // 1, 2 or 4 waves per row group
+  const int iters = (nslab + wpr - 1) / wpr;
   if (iters > 4) return QUANTO_HIP_ENOTSUP;
-  const int rpb = 4 / wpr;
-  int grid = (N + rpb - 1) / rpb;
-  if (grid > 2048) grid = 2048;
+  const int rows_per_block = RR8 * (4 / wpr);
+  const int grid = (N + rows_per_block - 1) / rows_per_block;
   auto xs = reinterpret_cast<const uint16_t*>(x);
   auto ws = reinterpret_cast<const uint8_t*>(w);
   auto ss = reinterpret_cast<const uint16_t*>(s);
@@ -162,7 +172,7 @@ static int launch_iters(const void* x, const void* w, const void* s, const void*
 template <int DT, int BDT>
 static int launch_m(const void* x, const void* w, const void* s, const void* bias, void* y, int M, int N, int K, hipStream_t stream) {
   int m0 = 0;
-  while (m0 < M) {
+  while (m0 < M) {  // x lives in registers as fp32 (16 VGPRs per slab and row): two rows per pass, later passes hit the MALL
     const int mt = (M - m0) >= 2 ? 2 : 1;
     const void* xp = reinterpret_cast<const uint16_t*>(x) + (size_t)m0 * K;
     void* yp = reinterpret_cast<uint16_t*>(y) + (size_t)m0 * N;
