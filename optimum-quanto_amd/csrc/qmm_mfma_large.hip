@@ -296,7 +296,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
       // "all but the newest pieces": tile kt+1 prefetches its successor's weight bytes and first activation fragments
       // out of that stage while it runs, so tile kt+2 must be complete before tile kt+1 starts.  Tried and rejected:
       // five 24 KiB stages for the 128-tile (one workgroup per CU instead of two: 110 us vs 86 us on cfg4) and a
-      // three-step activation prefetch distance (cfg4 95 -> 119 us, 4096^3 unchanged).
+      // three-step activation prefetch distance (cfg4 95 -> 119 us, 4096^3 unchanged); touching the lines of tile kt+4 with one
+      // un-waited 4-byte load per lane so that the DMA hits in L2 (4096^3 127 -> 136 us).
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
