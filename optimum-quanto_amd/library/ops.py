@@ -114,7 +114,7 @@ def qbytes_mm_cpu(activations, weights, output_scales):
     return _qbytes_mm_dense(activations, weights, output_scales)
 
 
-def qbytes_mm_hip(activations, weights, output_scales):
+def qbytes_mm_hip(activations, weights, output_scales, bias=None):
     """ROCm: one fused kernel, scales applied to the fp32 accumulator (csrc/qbytes_gemv.hip, csrc/qmm_mfma.hip)."""
     assert activations.ndim >= 1 and weights.ndim == 2
     n = weights.shape[0]
@@ -123,7 +123,17 @@ def qbytes_mm_hip(activations, weights, output_scales):
         output_scales = (output_scales * torch.ones((1, n), dtype=output_scales.dtype, device=output_scales.device))
         if output_scales.numel() != n:
             raise ValueError(f"qbytes_mm: cannot broadcast scales of shape {tuple(output_scales.shape)} to {n} features")
-    return quanto_hip.lib.qbytes_mm(activations, weights, output_scales)
+    return quanto_hip.lib.qbytes_mm(activations, weights, output_scales, bias)
+
+
+def qbytes_mm_bias_default(activations, weights, output_scales, bias):
+    """What tensor/weights/qbytes.py:73-81 computes: the product in the output dtype, then the bias added."""
+    out = torch.ops.quanto.qbytes_mm(activations, weights, output_scales)
+    return out if bias is None else out + bias
+
+
+def qbytes_mm_bias_hip(activations, weights, output_scales, bias):
+    return qbytes_mm_hip(activations, weights, output_scales, bias)
 
 
 _owned = _define("qbytes_mm", "(Tensor A, Tensor B, Tensor scales) -> Tensor")
@@ -131,6 +141,11 @@ if _owned:
     _impl("qbytes_mm", "CompositeExplicitAutograd", qbytes_mm_default, True)
     _impl("qbytes_mm", "CPU", qbytes_mm_cpu, True)
 _impl("qbytes_mm", "CUDA", qbytes_mm_hip, _owned)
+# new op: the same product with the bias of the Linear fused into the kernel epilogue (rounded product + bias, rounded again:
+# bit-identical to the two-op sequence) - saves one elementwise kernel per biased Linear
+if _define("qbytes_mm_bias", "(Tensor A, Tensor B, Tensor scales, Tensor? bias) -> Tensor"):
+    _impl("qbytes_mm_bias", "CompositeExplicitAutograd", qbytes_mm_bias_default, True)
+    _impl("qbytes_mm_bias", "CUDA", qbytes_mm_bias_hip, True)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -54,14 +54,10 @@ class WeightQBytesLinearFunction(QuantizedLinearFunction):
         ctx.save_for_backward(input, other)
         if isinstance(input, QBytesTensor):
             # quantized activations: integer/fp8 product, rescaled by the product of both scales
-            output = torch.ops.quanto.qbytes_mm(input._data, other._data, input._scale * other._scale)
-        else:
-            k, n = input.shape[-1], other.shape[0]
-            output = torch.ops.quanto.qbytes_mm(input.reshape(-1, k), other._data, other._scale)
-            output = output.reshape(input.shape[:-1] + (n,))
-        if bias is not None:
-            output = output + bias
-        return output
+            return torch.ops.quanto.qbytes_mm_bias(input._data, other._data, input._scale * other._scale, bias)
+        k, n = input.shape[-1], other.shape[0]
+        output = torch.ops.quanto.qbytes_mm_bias(input.reshape(-1, k), other._data, other._scale, bias)
+        return output.reshape(input.shape[:-1] + (n,))
 
 
 class WeightQBytesTensor(QBytesTensor):
