@@ -22,10 +22,7 @@
 namespace qh {
 namespace n8 {
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int A_BYTES = BM * BK;  // 16 KiB
-constexpr int W_BYTES = BN * BK;  // 16 KiB
-constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+constexpr int BK = 64;  // bytes per row and K-tile, both operands
 constexpr int STAGES = 4;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -68,16 +65,22 @@ struct Args {
 
 // PAIRED (fp8 kinds, K % 128 == 0): K-tiles are consumed two at a time by the K = 128 MX-format MFMA (unit scales), which runs
 // at twice the rate of the 16x16x32 fp8 MFMA - see the paired loop below.
-template <int ODT, int KIND, bool PAIRED = false>
-__global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
+// SMALL: 128x128 tile with four waves of 128 x 32 (16 KiB stages: two workgroups share a CU) for shapes whose 256-tiles cannot
+// occupy the chip; otherwise 256x256 with eight waves of 128 x 64.
+template <int ODT, int KIND, bool PAIRED = false, bool SMALL = false>
+__global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(const Args a) {
   using E = Elem<ODT>;
   using T = typename E::T;
   using AV = typename Acc<KIND>::V;
+  constexpr int BM = SMALL ? 128 : 256, BN = BM;
+  constexpr int NWAVES = SMALL ? 4 : 8;
+  constexpr int NJ = SMALL ? 2 : 4;  // 16-feature fragments per wave; 8 token fragments per wave in both layouts
+  constexpr int A_BYTES = BM * BK, W_BYTES = BN * BK, STAGE_BYTES = A_BYTES + W_BYTES;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = SMALL ? 0 : wave >> 2, wn = wave & 3;
   constexpr int ES = (KIND == K_BF16 || KIND == K_F16) ? 2 : 1;  // operand element size; a K-tile is always 64 bytes per row
   const int M = a.M, N = a.N, K = a.K;
   const int nk = K * ES / BK;
@@ -97,15 +100,15 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
   int adst[2], wdst[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int R = (j * 8 + wave) * 16 + (lane >> 2);
+    const int R = (j * NWAVES + wave) * 16 + (lane >> 2);
     const int c = (lane & 3) ^ swz64(R);
     int m = m0 + R, n = n0 + R;
     m = m < M ? m : M - 1;
     n = n < N ? n : N - 1;
     asrc[j] = (uint32_t)((size_t)m * K * ES + c * 16);
     wsrc[j] = (uint32_t)((size_t)n * K * ES + c * 16);
-    adst[j] = (j * 8 + wave) * 1024;
-    wdst[j] = A_BYTES + (j * 8 + wave) * 1024;
+    adst[j] = (j * NWAVES + wave) * 1024;
+    wdst[j] = A_BYTES + (j * NWAVES + wave) * 1024;
   }
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
   auto issue = [&](int kt, int stage) {
@@ -118,14 +121,14 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
 
   // ---- fragment reads: ONE ds_read_b128 per 16-row fragment and K-tile (bytes k = 16g .. 16g+15, g = lane >> 4); the
   // swizzle only depends on (row & 15) >> 2, so fragment i / j adds a compile-time multiple of 1024 bytes
-  const int ra = wm * 128 + (lane & 15), rw = wn * 64 + (lane & 15);
+  const int ra = wm * 128 + (lane & 15), rw = wn * (NJ * 16) + (lane & 15);
   const int aoff0 = ra * 64 + (((lane >> 4) ^ swz64(ra)) << 4);
   const int boff0 = A_BYTES + rw * 64 + (((lane >> 4) ^ swz64(rw)) << 4);
 
   // acc[j][i]: the weight fragment is the MFMA A operand (rows = output features), the activation fragment the B operand
-  AV acc[4][8];
+  AV acc[NJ][8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[j][i] = AV{0, 0, 0, 0};
 
@@ -135,7 +138,7 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
   // than the LDS latency under load and the stream stalls on every fragment): the activation fragment of step i is
   // replaced by the next tile's as soon as step i has issued its MFMAs; the weight fragments, live for the whole tile,
   // ping-pong between two register sets.  One barrier per K-tile.
-  uint4 xf[8], wq[2][4];
+  uint4 xf[8], wq[2][NJ];
   auto read_x = [&](const uint8_t* st, int i) -> uint4 { return *reinterpret_cast<const uint4*>(st + aoff0 + i * 1024); };
   auto read_w = [&](const uint8_t* st, int j) -> uint4 { return *reinterpret_cast<const uint4*>(st + boff0 + j * 1024); };
   auto issue_piece = [&](int kt, int stage, int piece) {
@@ -175,7 +178,7 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
     //           refetched for pair p+1.
     typedef __attribute__((ext_vector_type(8))) int i32x8;
     constexpr int FMTSEL = KIND == K_F8E5M2 ? 1 : 0;  // cbsz / blgp: 0 = fp8 (e4m3), 1 = bf8 (e5m2)
-    i32x8 X[8], W[4];
+    i32x8 X[8], W[NJ];
     auto load_pair = [&](i32x8& dst, const uint8_t* s0, const uint8_t* s1, int off) {
       const uint4 lo = *reinterpret_cast<const uint4*>(s0 + off), hi = *reinterpret_cast<const uint4*>(s1 + off);
       dst = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
@@ -202,7 +205,7 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < 4; ++j) load_pair(W[j], smem, smem + STAGE_BYTES, boff0 + j * 1024);
+    for (int j = 0; j < NJ; ++j) load_pair(W[j], smem, smem + STAGE_BYTES, boff0 + j * 1024);
 #pragma unroll
     for (int i = 0; i < 4; ++i) load_pair(X[i], smem, smem + STAGE_BYTES, aoff0 + i * 1024);
     for (int p = 0; p < np; ++p) {
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           mma128(acc[j][i], W[j], X[i]);
           if (j == 1) load_pair(X[4 + i], c0, c1, aoff0 + (4 + i) * 1024);
           __builtin_amdgcn_sched_barrier(0);
@@ -230,11 +233,12 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
       if (2 * p + 5 < nk) issue(2 * p + 5, (2 * p + 1) & 3);
       // ---- half B ----
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
 #pragma unroll
         for (int i = 4; i < 8; ++i) {
           mma128(acc[j][i], W[j], X[i]);
-          if (i == 5) load_pair(X[j], n0s, n1s, aoff0 + j * 1024);            // X[0..3] of the next pair (dead since half A)
+          // X[0..3] of the next pair (dead since half A): 4 / NJ of them behind each weight fragment's MFMAs
+          if (i - 4 < 4 / NJ) load_pair(X[j * (4 / NJ) + (i - 4)], n0s, n1s, aoff0 + (j * (4 / NJ) + (i - 4)) * 1024);
           if (i == 7) load_pair(W[j], n0s, n1s, boff0 + j * 1024);            // W[j] of the next pair: its last MFMA was just issued
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wq[0][j] = read_w(smem, j);
+    for (int j = 0; j < NJ; ++j) wq[0][j] = read_w(smem, j);
 #pragma unroll
     for (int i = 0; i < 8; ++i) xf[i] = read_x(smem, i);
 
@@ -265,17 +269,17 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           mma(acc[j][i], wq[P][j], xf[i]);
-          if (j == 1) {
-            if (i < 4) wq[P ^ 1][i] = read_w(sn, i);
-          } else if (j == 2) {
+          if (j == 1 % NJ) {
+            if (i < NJ) wq[P ^ 1][i] = read_w(sn, i);
+          }
+          if (j == 2 % NJ) {
 #if QH_N8_ABLATE != 1
             if (i >= 4 && dma) issue_piece(kt + 3, (kt + 3) & 3, i - 4);
 #endif
-          } else if (j == 3) {
-            xf[i] = read_x(sn, i);  // same fragment of the next tile
           }
+          if (j == NJ - 1) xf[i] = read_x(sn, i);  // same fragment of the next tile
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -314,16 +318,16 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  constexpr int ROWB = 128;                    // bytes per parked row: 64 features (16-bit) or 32 features (fp32, two passes)
-  constexpr int PASSES = sizeof(T) / 2;        // 1 or 2
-  constexpr int JP = 4 / PASSES;               // feature fragments per pass
-  uint8_t* park = smem + wave * (128 * ROWB);  // 16 KiB per wave
+  constexpr int FP = NJ * 16 < 128 / (int)sizeof(T) ? NJ * 16 : 128 / (int)sizeof(T);  // features per pass (rows of <= 128 bytes)
+  constexpr int JP = FP / 16, PASSES = NJ / JP;  // feature fragments per pass
+  constexpr int ROWB = FP * (int)sizeof(T), LPR = ROWB / 16;  // bytes per parked row, lanes per row on the read side
+  uint8_t* park = smem + wave * (128 * ROWB);     // <= 16 KiB per wave
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
 #pragma unroll
     for (int jj = 0; jj < JP; ++jj) {
       const int j = p * JP + jj;
-      const int nb = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      const int nb = n0 + wn * (NJ * 16) + j * 16 + (lane >> 4) * 4;
       float sc[4], bv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -343,26 +347,26 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
         }
         const int row = i * 16 + (lane & 15);
         if constexpr (sizeof(T) == 2) {
-          const int chunk = (jj * 4 + (lane >> 4)) ^ ((row & 7) << 1);  // 8-byte chunks
+          const int chunk = (jj * 4 + (lane >> 4)) ^ ((row & (LPR - 1)) << 1);  // 8-byte chunks
           *reinterpret_cast<uint2*>(park + row * ROWB + chunk * 8) = *reinterpret_cast<const uint2*>(out);
         } else {
-          const int chunk = (jj * 4 + (lane >> 4)) ^ (row & 7);  // 16-byte chunks
+          const int chunk = (jj * 4 + (lane >> 4)) ^ (row & (LPR - 1));  // 16-byte chunks
           *reinterpret_cast<uint4*>(park + row * ROWB + chunk * 16) = *reinterpret_cast<const uint4*>(out);
         }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int row = t * 8 + (lane >> 3);
-      const int c16 = lane & 7;
+    for (int t = 0; t < 2 * LPR; ++t) {
+      const int row = t * (64 / LPR) + lane / LPR;
+      const int c16 = lane % LPR;
       uint4 v;
       if constexpr (sizeof(T) == 2)
-        v = *reinterpret_cast<const uint4*>(park + row * ROWB + (((c16 * 2) ^ ((row & 7) << 1)) * 8));
+        v = *reinterpret_cast<const uint4*>(park + row * ROWB + (((c16 * 2) ^ ((row & (LPR - 1)) << 1)) * 8));
       else
-        v = *reinterpret_cast<const uint4*>(park + row * ROWB + ((c16 ^ (row & 7)) * 16));
+        v = *reinterpret_cast<const uint4*>(park + row * ROWB + ((c16 ^ (row & (LPR - 1))) * 16));
       const int m = m0 + wm * 128 + row;
-      const int n = n0 + wn * 64 + p * (64 / PASSES) + c16 * (16 / (int)sizeof(T));
+      const int n = n0 + wn * (NJ * 16) + p * FP + c16 * (16 / (int)sizeof(T));
       if (full) {
         typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // non-temporal: see qmm_mfma_large.hip
         __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + (size_t)m * N + n));
@@ -377,27 +381,31 @@ __global__ void __launch_bounds__(512, 1) qbytes_native8_kernel(const Args a) {
   }
 }
 
+template <int ODT, int KIND, bool PAIRED, bool SMALL>
+static int launch_cfg(const Args& a, hipStream_t stream) {
+  constexpr int T = SMALL ? 128 : 256;
+  constexpr int need = STAGES * 2 * T * BK;  // 128 KiB (64 KiB for the 128-tile: two workgroups per CU); the epilogue parks in it
+  const int tiles = ((a.N + T - 1) / T) * ((a.M + T - 1) / T);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_kernel<ODT, KIND, PAIRED, SMALL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, need);
+  hipLaunchKernelGGL((qbytes_native8_kernel<ODT, KIND, PAIRED, SMALL>), dim3(tiles), dim3(SMALL ? 256 : 512), need, stream, a);
+  return launch_status();
+}
+
 template <int ODT, int KIND>
 static int launch(const Args& a, hipStream_t stream) {
-  constexpr int need = STAGES * STAGE_BYTES;  // 128 KiB; the epilogue parks 8 x 16 KiB in the same space
-  const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
+  // 256-tiles when they give every CU at least ~3/8 of a tile, otherwise 128-tiles (same rule as qmm_mfma_large.hip)
+  static const int small_env = [] { const char* e = getenv("QUANTO_HIP_NATIVE8_SMALL"); return e ? atoi(e) : -1; }();  // experiments
+  const int64_t tiles256 = (int64_t)((a.N + 255) / 256) * ((a.M + 255) / 256);
+  const bool small = small_env >= 0 ? small_env != 0 : tiles256 < 96;
   // the paired loop pays off only where one instruction consumes both tiles (fp8); as two MFMAs per pair it measured
   // slower than the per-tile loop (int8 4096^3: 72 vs 66 us; dense bf16: 135 vs 127 us) - QUANTO_HIP_PAIRED=1 forces it
-  {
-    constexpr int ES = (KIND == K_BF16 || KIND == K_F16) ? 2 : 1;
-    constexpr bool FP8 = KIND == K_F8E4M3 || KIND == K_F8E5M2;
-    static const int paired_env = [] { const char* e = getenv("QUANTO_HIP_PAIRED"); return e ? atoi(e) : -1; }();  // experiments
-    if ((paired_env == 1 || (FP8 && paired_env != 0)) && (a.K * ES) % 128 == 0) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_kernel<ODT, KIND, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, need);
-      hipLaunchKernelGGL((qbytes_native8_kernel<ODT, KIND, true>), dim3(tiles), dim3(512), need, stream, a);
-      return launch_status();
-    }
-  }
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_kernel<ODT, KIND>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, need);
-  hipLaunchKernelGGL((qbytes_native8_kernel<ODT, KIND>), dim3(tiles), dim3(512), need, stream, a);
-  return launch_status();
+  constexpr int ES = (KIND == K_BF16 || KIND == K_F16) ? 2 : 1;
+  constexpr bool FP8 = KIND == K_F8E4M3 || KIND == K_F8E5M2;
+  static const int paired_env = [] { const char* e = getenv("QUANTO_HIP_PAIRED"); return e ? atoi(e) : -1; }();  // experiments
+  const bool paired = (paired_env == 1 || (FP8 && paired_env != 0)) && (a.K * ES) % 128 == 0;
+  if (paired) return small ? launch_cfg<ODT, KIND, true, true>(a, stream) : launch_cfg<ODT, KIND, true, false>(a, stream);
+  return small ? launch_cfg<ODT, KIND, false, true>(a, stream) : launch_cfg<ODT, KIND, false, false>(a, stream);
 }
 
 }  // namespace n8
