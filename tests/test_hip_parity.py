@@ -435,6 +435,58 @@ def test_cfg4_fp8_512x8192x8192():
     _sample_rows_check(y, p["x"], lambda xr: O.qbytes_mm_exact(xr, p["data"], p["scale"], "e4m3fn"), rows, "bf16", "cfg4")
 
 
+def test_w8a8_int8_4096_cubed_bit_exact():
+    """bench workload w8a8 at full size: the i32 MFMA kernel is bit-identical to the exact integer reference on sampled rows
+    and, over the whole output, to the one-thread-per-output kernel of the same library."""
+    rng = np.random.default_rng(8)
+    a = rng.integers(-128, 128, size=(4096, 4096), dtype=np.int8)
+    b = rng.integers(-128, 128, size=(4096, 4096), dtype=np.int8)
+    s = O.round_to(((rng.random((4096, 1)) + 0.5) / 1e5).astype(np.float32), "bf16")
+    ta, tb, ts = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), to_torch(s, "bf16", DEV)
+    y = quanto_hip.lib.qbytes_mm(ta, tb, ts)
+    assert quanto_hip.lib.last_kernel() == "mfma_native8"
+    rows = rng.choice(4096, 24, replace=False)
+    np.testing.assert_array_equal(to_numpy(y)[rows], O.qbytes_int_mm_ref(a[rows], b, s, "bf16"))
+    assert torch.equal(y, quanto_hip.lib.qbytes_mm(ta, tb, ts, kernel="naive"))
+
+
+def test_fp8a8_4096_cubed():
+    """bench workload fp8a8 at full size (K = 128 MX-format MFMA path): sampled rows against float64 math."""
+    rng = np.random.default_rng(9)
+    a = O.fp8_encode(rng.standard_normal((4096, 4096)).astype(np.float32), "e4m3fn")
+    b = O.fp8_encode(rng.standard_normal((4096, 4096)).astype(np.float32), "e4m3fn")
+    s = O.round_to(((rng.random((4096, 1)) + 0.5) / 1e2).astype(np.float32), "bf16")
+    y = to_numpy(quanto_hip.lib.qbytes_mm(fp8_tensor(a, "e4m3fn", DEV), fp8_tensor(b, "e4m3fn", DEV), to_torch(s, "bf16", DEV)))
+    rows = rng.choice(4096, 24, replace=False)
+    want = np.matmul(O.fp8_decode(a[rows], "e4m3fn").astype(np.float64), O.fp8_decode(b, "e4m3fn").astype(np.float64).T)
+    assert_close_to_exact(y[rows], want * s.astype(np.float64).reshape(1, -1), "bf16", "fp8a8 4096^3")
+
+
+def test_int4_prefill_4096_cubed():
+    """bench workload int4_prefill at full size: dequantize + dense GEMM vs float64 math on the reference's rounded weight
+    (sampled rows), plus the power-of-two linearity property over the whole output."""
+    p = make_qbits_problem(4096, 4096, 4096, "bf16", seed=10)
+    y = _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "dequant_mfma"
+    rows = np.random.default_rng(2).choice(4096, 24, replace=False)
+    w = O.dequantize_qbits_ref(p["packed"], 4, p["scale"], p["shift"], 0, 128, (4096, 4096), "bf16").astype(np.float64)
+    assert_close_to_exact(y[rows], np.matmul(p["x"][rows].astype(np.float64), w.T), "bf16", "int4 prefill 4096^3")
+    np.testing.assert_array_equal(_run_qbits(dict(p, x=p["x"] * 2), "auto"), y * 2)
+
+
+@pytest.mark.parametrize("M", [32, 200])
+def test_batched_decode_llama_shapes(M):
+    """Streaming kernels (split-K, passes) on the Llama-3-8B layer shapes with the long K: sampled rows vs float64 math."""
+    for (N, K) in [(4096, 14336), (1024, 4096)]:
+        p = make_qbits_problem(M, N, K, "bf16", seed=M + N)
+        y = _run_qbits(p, "auto")
+        assert quanto_hip.lib.last_kernel() == "skinny"
+        assert_close_to_exact(y, _exact_qbits(p), "bf16", f"int4 skinny {M}x{K}x{N}")
+        q = make_qbytes_problem(M, N, K, "bf16", None, seed=M + K)
+        assert_close_to_exact(_run_qbytes(q, "auto"), O.qbytes_mm_exact(q["x"], q["data"], q["scale"]), "bf16", f"int8 {M}x{K}x{N}")
+        assert quanto_hip.lib.last_kernel() in (("skinny",) if M <= 64 else ("skinny", "mfma_large"))
+
+
 # ------------------------------------------------------------------------------------------------ QLinear end to end
 @pytest.mark.parametrize("weights", ["qint4", "qint8", "qfloat8"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
