@@ -59,6 +59,31 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.quanto_hip_qbits_mm_workspace_size(4, 4096, 4096, 4, 128, 2, 0) == 0
     assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 4, 128, 2, 0) == 0  # GEMV needs none
     assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 3, 128, 2, 0) == -1
+    # entry points added for the "next" rows: argument validation happens before any device call
+    vp, i64, ci, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+    lib.quanto_hip_quantize_symmetric.argtypes = [vp, vp, vp, i64, i64, ci, ci, ci, vp]
+    assert lib.quanto_hip_quantize_symmetric(None, None, None, 16, 1, 0, 2, 3, None) == -1   # null pointers
+    assert lib.quanto_hip_quantize_symmetric(None, None, None, 16, 1, 7, 2, 3, None) == -1   # unknown scale mode
+    assert lib.quanto_hip_quantize_symmetric(None, None, None, 16, 5, 1, 2, 3, None) == -1   # numel not a multiple of inner
+    assert lib.quanto_hip_quantize_symmetric(None, None, None, 16, 1, 0, 2, 7, None) == -2   # e4m3fnuz target: not supported
+    assert lib.quanto_hip_quantize_symmetric(None, None, None, 0, 1, 0, 2, 3, None) == 0     # empty tensor
+    lib.quanto_hip_quantize_affine.argtypes = [vp, vp, vp, vp, i64, i64, ci, ci, ci, ci, vp]
+    assert lib.quanto_hip_quantize_affine(None, None, None, None, 8, 128, 4, 128, 2, 2, None) == -1
+    assert lib.quanto_hip_quantize_affine(None, None, None, None, 8, 100, 4, 128, 2, 2, None) == -1  # K % group_size
+    lib.quanto_hip_pack.argtypes = [vp, vp, i64, i64, ci, vp]
+    assert lib.quanto_hip_pack(None, None, 8, 8, 3, None) == -1 and lib.quanto_hip_pack(None, None, 0, 8, 4, None) == 0
+    lib.quanto_hip_qbytes_mm_ws.argtypes = [vp] * 5 + [i64] * 3 + [ci] * 4 + [vp, sz, vp]
+    assert lib.quanto_hip_qbytes_mm_ws(None, None, None, None, None, 4, 4, 64, 2, 3, 2, 0, None, 0, None) == -1
+    assert lib.quanto_hip_qbytes_mm_ws(None, None, None, None, None, 0, 4, 64, 2, 3, 2, 0, None, 0, None) == 0   # M == 0
+    lib.quanto_hip_qbytes_mm_workspace_size.restype = i64
+    lib.quanto_hip_qbytes_mm_workspace_size.argtypes = [i64] * 3 + [ci] * 4
+    assert lib.quanto_hip_qbytes_mm_workspace_size(32, 14336, 4096, 2, 3, 2, 0) == 0           # wide N: not split
+    assert lib.quanto_hip_qbytes_mm_workspace_size(32, 4096, 4096, 2, 3, 2, 0) == 256 + 64 * 4 * 256 * 2 * 16  # 64 counters, split 4, TF = 2
+    assert lib.quanto_hip_qbytes_mm_workspace_size(4096, 4096, 4096, 2, 3, 2, 0) == 0          # 256-tiles: no workspace
+    lib.quanto_hip_qbytes_mm_pick.argtypes = [i64] * 3 + [ci] * 3
+    picks = {m: lib.quanto_hip_qbytes_mm_pick(m, 4096, 4096, 2, 3, 2) for m in (1, 8, 64, 256, 4096)}
+    assert picks == {1: 2, 8: 5, 64: 5, 256: 4, 4096: 4}, picks                                  # gemv, skinny, skinny, large, large
+    assert lib.quanto_hip_qbytes_mm_pick(4096, 4096, 4096, 3, 3, 2) == 6                         # int8 activations: native8
 
 
 def test_extension_registry_matches_reference_contract():
