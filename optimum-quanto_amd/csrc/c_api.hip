@@ -80,6 +80,9 @@ static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool hav
   if (qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
   if (have_workspace && M > QUANTO_HIP_GEMV_MAX_M_QBITS && dequant_mfma_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_DEQUANT_MFMA;
   if (have_workspace && qbits_mfma_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MFMA;
+  // int2, per-channel and group sizes other than 64 / 128 at small M: still one fused dequantize + one dense GEMM rather than
+  // the one-thread-per-output kernel
+  if (have_workspace && dequant_mfma_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_DEQUANT_MFMA;
   return QUANTO_HIP_KERNEL_NAIVE;
 }
 

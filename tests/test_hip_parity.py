@@ -183,7 +183,10 @@ def test_qbits_mfma_zeropoint_and_bias(dt):
 def test_qbits_naive_any_shape(dt, bits, gs, M, N, K, zp):
     p = make_qbits_problem(M, N, K, dt, bits=bits, group_size=gs, zeropoint=zp, seed=21, wscale=1.0)
     assert_close_to_exact(_run_qbits(p, "naive"), _exact_qbits(p), dt, "naive")
-    assert_close_to_exact(_run_qbits(p, "auto"), _exact_qbits(p), dt, "auto")
+    y = _run_qbits(p, "auto")
+    # AUTO may take the dequantize + dense GEMM path (int2, odd group sizes), whose oracle is the reference's rounded weight
+    want = _rounded_weight_exact(p) if quanto_hip.lib.last_kernel() == "dequant_mfma" else _exact_qbits(p)
+    assert_close_to_exact(y, want, dt, "auto")
 
 
 def test_qbits_auto_picks_fast_kernels():
