@@ -141,20 +141,30 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
 //                                         weight fragment feeds 8 MFMAs (1.5 VALU ops per MFMA, as in the 256-tiles); a
 //                                         2 x 2 layout converts twice as much and is VALU-issue bound (measured 105 us
 //                                         vs this layout on cfg4)
-template <int DT, int FMT, int BM, int BN, int WM, int WN>
+//
+// WD ("weights direct"): the weight bytes never touch the LDS.  Every lane loads the 16 bytes of its own fragment row
+// from global memory into a register ring of four K-tiles, three tiles ahead of their use, and the LDS holds FOUR
+// activation-only stages instead of three mixed ones in less space (128-tile: 4 x 16 KiB instead of 3 x 24 KiB, still
+// two workgroups per CU).  Activation DMA and weight loads are then in flight for two whole tiles instead of one.
+// It pays only where a workgroup has its CU to itself (one wave per SIMD, nobody to hide the DMA latency): see the
+// launcher for the numbers.  Tried and rejected for the 256-tile (two waves per SIMD; a ring of two weight tiles, loaded in
+// the second phase of tile t-2 and waited for in the middle of tile t-1, because 128 accumulators leave no room for four):
+// 4096^3 121 -> 126 us, 8192^3 783 -> 811 us.
+template <int DT, int FMT, int BM, int BN, int WM, int WN, bool WD = false>
 __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(const Args a) {
   constexpr int NWAVES = WM * WN;
   constexpr int MI = BM / WM / 16;              // 16-token fragments per wave
   constexpr int NJ = BN / WN / 16;              // 16-feature fragments per wave
   constexpr int STEPS = 2 * MI;                 // (k-half, token fragment) steps per K-tile
-  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK, STAGE_BYTES = A_BYTES + W_BYTES;
+  constexpr int A_BYTES = BM * BK * 2, W_BYTES = WD ? 0 : BN * BK, STAGE_BYTES = A_BYTES + W_BYTES;
   constexpr int APIECES = BM / 8 / NWAVES;      // activation DMA pieces (8 rows x 128 B) per wave and K-tile
-  constexpr int WPIECES = BN / 16 / NWAVES;     // weight DMA pieces (16 rows x 64 B) per wave and K-tile
+  constexpr int WPIECES = WD ? 0 : BN / 16 / NWAVES;  // weight DMA pieces (16 rows x 64 B) per wave and K-tile
   constexpr int NPIECES = APIECES + WPIECES;
   constexpr int ND = (NJ * 4 + MI - 1) / MI;    // converted dwords per step (one phase converts NJ*4 dwords in MI steps)
-  constexpr int DSTEPS = NPIECES % 6 == 0 ? 6 : 3;  // the DMA of tile kt+2 is issued over the first DSTEPS steps of tile kt
+  constexpr int DSTEPS = WD ? 1 : NPIECES % 6 == 0 ? 6 : 3;  // the DMA of tile kt+2 is issued over the first DSTEPS steps of tile kt
   constexpr int PPS = NPIECES / DSTEPS;         // pieces per step
-  static_assert(NPIECES % DSTEPS == 0 && STEPS % 4 == 0 && ND <= NJ && PPS <= NJ, "unsupported tile configuration");
+  static_assert(WD || (NPIECES % DSTEPS == 0 && PPS <= NJ), "unsupported tile configuration");
+  static_assert(STEPS % 4 == 0 && ND <= NJ && APIECES + NJ <= STEPS, "unsupported tile configuration");
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
@@ -176,7 +186,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- DMA: per K-tile 32 activation pieces (8 rows x 128 B) + 16 weight pieces (16 rows x 64 B) of 1 KiB; 8 + 4 per wave
-  uint32_t asrc[APIECES], wsrc[WPIECES];
+  uint32_t asrc[APIECES], wsrc[WPIECES > 0 ? WPIECES : 1];
 #pragma unroll
   for (int j = 0; j < APIECES; ++j) {
     const int R = (j * NWAVES + wave) * 8 + (lane >> 3);
@@ -216,101 +226,204 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 raw[NJ];         // 16 weight bytes per fragment: k-half 0 in .xy, k-half 1 in .zw
   uint32_t w0[NJ][4], w1[NJ][4];
   V8 xf[4];              // activation fragments, two steps ahead (ring of 4: STEPS is a multiple of 4, the ring stays aligned)
   auto as_v8 = [&](const uint32_t(&w)[4]) { return __builtin_bit_cast(V8, make_uint4(w[0], w[1], w[2], w[3])); };
-  auto rawword = [&](int j, int kk, int d) -> uint32_t {
-    const uint32_t lo = kk == 0 ? raw[j].x : raw[j].z, hi = kk == 0 ? raw[j].y : raw[j].w;
-    return d < 2 ? lo : hi;
-  };
   auto read_x = [&](const uint8_t* st, int i, int kk) -> V8 { return *reinterpret_cast<const V8*>(st + aoff[kk] + i * 2048); };
-  auto read_raw = [&](const uint8_t* st, int j) -> uint4 { return *reinterpret_cast<const uint4*>(st + boff + j * 1024); };
-
-  // ---- prologue: tiles 0 and 1 in flight, tile 0 visible, W0(0) converted, x(0..1, kk0) of tile 0 in registers -----------
-#pragma unroll
-  for (int p = 0; p < NPIECES; ++p) issue_piece(0, 0, p);
-  if (nk > 1) {
-#pragma unroll
-    for (int p = 0; p < NPIECES; ++p) issue_piece(1, 1, p);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile 1 too: its weight bytes are fetched during tile 0
-  QH_LT_STAMP(1);
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  QH_LT_STAMP(2);
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) raw[j] = read_raw(smem, j);
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int d = 0; d < 4; ++d) w0[j][d] = convert_pair<DT, FMT>(rawword(j, 0, d), d & 1);
-  xf[0] = read_x(smem, 0, 0);
-  xf[1] = read_x(smem, 1, 0);
-
-  // One K-tile.  The source order below IS the schedule: a sched_barrier after every MFMA group keeps hipcc from
-  // clustering the conversions (it otherwise hoists ~50 VALU ops in front of the first MFMA of a tile, which leaves the
-  // matrix pipe idle for their whole issue time).
-  int cur = 0;
-  auto tile = [&](int kt, auto dma_tag, auto barrier_tag) {
-    constexpr bool DMA = decltype(dma_tag)::value, BARRIER = decltype(barrier_tag)::value;
-    const uint8_t* st = smem + cur * STAGE_BYTES;
-    const int nxt = cur == STAGES - 1 ? 0 : cur + 1;
-    const int nxt2 = nxt == STAGES - 1 ? 0 : nxt + 1;
-    const uint8_t* sn = smem + nxt * STAGE_BYTES;
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      const int kk = s / MI, i = s % MI;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        if (kk == 0)
-          acc[j][i] = Mma<DT>::run(as_v8(w0[j]), xf[s & 3], acc[j][i]);
-        else
-          acc[j][i] = Mma<DT>::run(as_v8(w1[j]), xf[s & 3], acc[j][i]);
-        if (j < ND && i * ND + j < NJ * 4) {
-          // conversion: step i of a phase produces dwords i*ND .. i*ND+ND-1 of the phase's NJ*4 (fragment-major)
-          const int c = i * ND + j, f = c >> 2, d = c & 3;
-          if (kk == 0)
-            w1[f][d] = convert_pair<DT, FMT>(rawword(f, 1, d), d & 1);  // this tile's k-half 1
-          else
-            w0[f][d] = convert_pair<DT, FMT>(rawword(f, 0, d), d & 1);  // next tile's k-half 0 (raw[f] already holds tile kt+1)
-        }
-        if (j == (ND < NJ ? ND : 0)) {
-          // activation fragment of step s+2 (the first two of the next tile at the end; garbage, unused, on the last tile)
-          xf[(s + 2) & 3] = s + 2 < STEPS ? read_x(st, (s + 2) % MI, (s + 2) / MI) : read_x(sn, s + 2 - STEPS, 0);
-        }
-        if (j == (ND + 1 < NJ ? ND + 1 : NJ - 1)) {
-          // next tile's raw weight bytes: fragment f is dead once the last dword of its k-half 1 is converted, i.e. after
-          // phase-0 step (4f+3)/ND; it is reloaded in the following step (phase-1 step 0 for the last fragment)
-#pragma unroll
-          for (int f = 0; f < NJ; ++f)
-            if (s == (4 * f + 3) / ND + 1) raw[f] = read_raw(sn, f);
-        }
-        if (DMA && j >= NJ - PPS && s < DSTEPS) issue_piece(kt + 2, nxt2, PPS * s + (j - (NJ - PPS)));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (BARRIER) {
-      // tile boundary: the own DMA share of tile kt+2, issued in the first steps of this tile, has landed -> barrier ->
-      // everybody's share visible and every wave done with tile kt, whose stage the next tile refills.  vmcnt(0), not
-      // "all but the newest pieces": tile kt+1 prefetches its successor's weight bytes and first activation fragments
-      // out of that stage while it runs, so tile kt+2 must be complete before tile kt+1 starts.  Tried and rejected:
-      // five 24 KiB stages for the 128-tile (one workgroup per CU instead of two: 110 us vs 86 us on cfg4) and a
-      // three-step activation prefetch distance (cfg4 95 -> 119 us, 4096^3 unchanged); touching the lines of tile kt+4 with one
-      // un-waited 4-byte load per lane so that the DMA hits in L2 (4096^3 127 -> 136 us).
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    }
-    cur = nxt;
-  };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
-  QH_LT_STAMP(3);
-  int kt = 0;
-  for (; kt + 2 < nk; ++kt) tile(kt, yes{}, yes{});
-  tile(kt, no{}, yes{});  // nk >= 2: tiles nk-2 and nk-1 have nothing left to prefetch
-  tile(kt + 1, no{}, no{});
+  if constexpr (WD) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    // ---- weights: lane (r = lane & 15, g = lane >> 4) of fragment j owns bytes 16g..16g+15 of feature row j*16 + r of the
+    // K-tile: k-half 0 operand in .xy, k-half 1 in .zw (the same 16 bytes the LDS path reads back from its weight image)
+    uint32_t wofs[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      int n = n0 + wn * (NJ * 16) + j * 16 + (lane & 15);
+      n = n < N ? n : N - 1;
+      wofs[j] = (uint32_t)((size_t)n * K + (lane >> 4) * 16 + (size_t)kt0 * BK);
+    }
+    u32x4 rg[4][NJ];  // rg[t & 3]: weight bytes of tile t, loaded during tile t-3, complete at the end of tile t-2
+    auto load_w = [&](int kt, u32x4& dst, int j) {
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(wofs[j]), "s"(a.w + (size_t)kt * BK) : "memory");
+    };
+    auto word = [&](const u32x4& r, int kk, int d) -> uint32_t { return kk == 0 ? (d < 2 ? r.x : r.y) : (d < 2 ? r.z : r.w); };
+
+    // ---- prologue: tiles 0..2 in flight and complete, W0(0) converted, x(0..1, kk0) of tile 0 in registers ----------------
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+      for (int p = 0; p < APIECES; ++p) issue_piece(t, t, p);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) load_w(t, rg[t][j], j);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(rg[t][j]));
+    QH_LT_STAMP(1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    QH_LT_STAMP(2);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) w0[j][d] = convert_pair<DT, FMT>(word(rg[0][j], 0, d), d & 1);
+    xf[0] = read_x(smem, 0, 0);
+    xf[1] = read_x(smem, 1, 0);
+
+    // K-tile kt with kt % 4 == P: same step schedule as the LDS-weight loop below; the activation pieces and weight loads
+    // of tile kt+3 take one issue slot each in the first APIECES + NJ steps
+    auto tile = [&](auto p_tag, int kt, auto dma_tag, auto barrier_tag) {
+      constexpr int P = decltype(p_tag)::value;
+      constexpr bool DMA = decltype(dma_tag)::value, BARRIER = decltype(barrier_tag)::value;
+      const uint8_t* st = smem + P * STAGE_BYTES;
+      const uint8_t* sn = smem + ((P + 1) & 3) * STAGE_BYTES;
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        const int kk = s / MI, i = s % MI;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (kk == 0)
+            acc[j][i] = Mma<DT>::run(as_v8(w0[j]), xf[s & 3], acc[j][i]);
+          else
+            acc[j][i] = Mma<DT>::run(as_v8(w1[j]), xf[s & 3], acc[j][i]);
+          if (j < ND && i * ND + j < NJ * 4) {
+            const int c = i * ND + j, f = c >> 2, d = c & 3;
+            if (kk == 0)
+              w1[f][d] = convert_pair<DT, FMT>(word(rg[P][f], 1, d), d & 1);            // this tile's k-half 1
+            else
+              w0[f][d] = convert_pair<DT, FMT>(word(rg[(P + 1) & 3][f], 0, d), d & 1);  // next tile's k-half 0
+          }
+          if (j == (ND < NJ ? ND : 0))
+            xf[(s + 2) & 3] = s + 2 < STEPS ? read_x(st, (s + 2) % MI, (s + 2) / MI) : read_x(sn, s + 2 - STEPS, 0);
+          if (DMA && j == NJ - 1 && s < APIECES + NJ) {
+            if (s < APIECES)
+              issue_piece(kt + 3, (P + 3) & 3, s);
+            else
+              load_w(kt + 3, rg[(P + 3) & 3][s - APIECES], s - APIECES);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (BARRIER) {
+        // the activation rows of tile kt+2 (issued during tile kt-1) feed the fragment prefetch at the end of tile kt+1,
+        // its weight registers the conversions of tile kt+1's second phase.  What this tile issued stays in flight.
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA ? APIECES + NJ : 0) : "memory");
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(rg[(P + 2) & 3][j]));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using P2 = std::integral_constant<int, 2>;
+    using P3 = std::integral_constant<int, 3>;
+    QH_LT_STAMP(3);
+    int kt = 0;
+    for (; kt + 4 < nk; kt += 4) {  // nk % 4 == 0, nk >= 8 (checked by the launcher)
+      tile(P0{}, kt, yes{}, yes{});
+      tile(P1{}, kt + 1, yes{}, yes{});
+      tile(P2{}, kt + 2, yes{}, yes{});
+      tile(P3{}, kt + 3, yes{}, yes{});
+    }
+    tile(P0{}, kt, yes{}, yes{});  // fetches tile nk-1
+    tile(P1{}, kt + 1, no{}, yes{});
+    tile(P2{}, kt + 2, no{}, yes{});
+    tile(P3{}, kt + 3, no{}, no{});
+  } else {
+    uint4 raw[NJ];         // 16 weight bytes per fragment: k-half 0 in .xy, k-half 1 in .zw
+    auto rawword = [&](int j, int kk, int d) -> uint32_t {
+      const uint32_t lo = kk == 0 ? raw[j].x : raw[j].z, hi = kk == 0 ? raw[j].y : raw[j].w;
+      return d < 2 ? lo : hi;
+    };
+    auto read_raw = [&](const uint8_t* st, int j) -> uint4 { return *reinterpret_cast<const uint4*>(st + boff + j * 1024); };
+
+    // ---- prologue: tiles 0 and 1 in flight, tile 0 visible, W0(0) converted, x(0..1, kk0) of tile 0 in registers -----------
+  #pragma unroll
+    for (int p = 0; p < NPIECES; ++p) issue_piece(0, 0, p);
+    if (nk > 1) {
+  #pragma unroll
+      for (int p = 0; p < NPIECES; ++p) issue_piece(1, 1, p);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile 1 too: its weight bytes are fetched during tile 0
+    QH_LT_STAMP(1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    QH_LT_STAMP(2);
+  #pragma unroll
+    for (int j = 0; j < NJ; ++j) raw[j] = read_raw(smem, j);
+  #pragma unroll
+    for (int j = 0; j < NJ; ++j)
+  #pragma unroll
+      for (int d = 0; d < 4; ++d) w0[j][d] = convert_pair<DT, FMT>(rawword(j, 0, d), d & 1);
+    xf[0] = read_x(smem, 0, 0);
+    xf[1] = read_x(smem, 1, 0);
+
+    // One K-tile.  The source order below IS the schedule: a sched_barrier after every MFMA group keeps hipcc from
+    // clustering the conversions (it otherwise hoists ~50 VALU ops in front of the first MFMA of a tile, which leaves the
+    // matrix pipe idle for their whole issue time).
+    int cur = 0;
+    auto tile = [&](int kt, auto dma_tag, auto barrier_tag) {
+      constexpr bool DMA = decltype(dma_tag)::value, BARRIER = decltype(barrier_tag)::value;
+      const uint8_t* st = smem + cur * STAGE_BYTES;
+      const int nxt = cur == STAGES - 1 ? 0 : cur + 1;
+      const int nxt2 = nxt == STAGES - 1 ? 0 : nxt + 1;
+      const uint8_t* sn = smem + nxt * STAGE_BYTES;
+  #pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        const int kk = s / MI, i = s % MI;
+  #pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (kk == 0)
+            acc[j][i] = Mma<DT>::run(as_v8(w0[j]), xf[s & 3], acc[j][i]);
+          else
+            acc[j][i] = Mma<DT>::run(as_v8(w1[j]), xf[s & 3], acc[j][i]);
+          if (j < ND && i * ND + j < NJ * 4) {
+            // conversion: step i of a phase produces dwords i*ND .. i*ND+ND-1 of the phase's NJ*4 (fragment-major)
+            const int c = i * ND + j, f = c >> 2, d = c & 3;
+            if (kk == 0)
+              w1[f][d] = convert_pair<DT, FMT>(rawword(f, 1, d), d & 1);  // this tile's k-half 1
+            else
+              w0[f][d] = convert_pair<DT, FMT>(rawword(f, 0, d), d & 1);  // next tile's k-half 0 (raw[f] already holds tile kt+1)
+          }
+          if (j == (ND < NJ ? ND : 0)) {
+            // activation fragment of step s+2 (the first two of the next tile at the end; garbage, unused, on the last tile)
+            xf[(s + 2) & 3] = s + 2 < STEPS ? read_x(st, (s + 2) % MI, (s + 2) / MI) : read_x(sn, s + 2 - STEPS, 0);
+          }
+          if (j == (ND + 1 < NJ ? ND + 1 : NJ - 1)) {
+            // next tile's raw weight bytes: fragment f is dead once the last dword of its k-half 1 is converted, i.e. after
+            // phase-0 step (4f+3)/ND; it is reloaded in the following step (phase-1 step 0 for the last fragment)
+  #pragma unroll
+            for (int f = 0; f < NJ; ++f)
+              if (s == (4 * f + 3) / ND + 1) raw[f] = read_raw(sn, f);
+          }
+          if (DMA && j >= NJ - PPS && s < DSTEPS) issue_piece(kt + 2, nxt2, PPS * s + (j - (NJ - PPS)));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (BARRIER) {
+        // tile boundary: the own DMA share of tile kt+2, issued in the first steps of this tile, has landed -> barrier ->
+        // everybody's share visible and every wave done with tile kt, whose stage the next tile refills.  vmcnt(0), not
+        // "all but the newest pieces": tile kt+1 prefetches its successor's weight bytes and first activation fragments
+        // out of that stage while it runs, so tile kt+2 must be complete before tile kt+1 starts.  Tried and rejected:
+        // five 24 KiB stages for the 128-tile (one workgroup per CU instead of two: 110 us vs 86 us on cfg4) and a
+        // three-step activation prefetch distance (cfg4 95 -> 119 us, 4096^3 unchanged); touching the lines of tile kt+4 with one
+        // un-waited 4-byte load per lane so that the DMA hits in L2 (4096^3 127 -> 136 us).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      cur = nxt;
+    };
+    QH_LT_STAMP(3);
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) tile(kt, yes{}, yes{});
+    tile(kt, no{}, yes{});  // nk >= 2: tiles nk-2 and nk-1 have nothing left to prefetch
+    tile(kt + 1, no{}, no{});
+  }
   QH_LT_STAMP(4);
 
   // ---- epilogue: scale (+bias) on the fp32 accumulator; each wave parks MI*16 tokens x 64 features per pass -------------
@@ -416,9 +529,12 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
 
 enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2 };
 
-template <int DT, int FMT, int BM, int BN, int WM, int WN>
+template <int DT, int FMT, int BM, int BN, int WM, int WN, bool WD = false>
 static int launch_cfg(const Args& a, hipStream_t stream) {
-  constexpr int lds = STAGES * (BM * BK * 2 + BN * BK);
+  constexpr int lds0 = WD ? 4 * (BM * BK * 2) : STAGES * (BM * BK * 2 + BN * BK);
+  static const int pad = [] { const char* e = getenv("QUANTO_HIP_LARGE_LDS_PAD"); return e ? atoi(e) : 0; }();  // experiments
+  const int lds = lds0 + pad;
+  static_assert(lds0 >= BM * BN * 2, "the epilogue parks the output tile in the stage memory");
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, tiles = tiles_m * tiles_n;
   Args b = a;
   {
@@ -430,16 +546,26 @@ static int launch_cfg(const Args& a, hipStream_t stream) {
     if (forced > 0) g = forced;
     b.group_m = g < tiles_m ? g : tiles_m;
   }
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_mfma_large_kernel<DT, FMT, BM, BN, WM, WN>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_mfma_large_kernel<DT, FMT, BM, BN, WM, WN, WD>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((qbytes_mfma_large_kernel<DT, FMT, BM, BN, WM, WN>), dim3(tiles * b.S), dim3(WM * WN * 64), lds, stream, b);
+  hipLaunchKernelGGL((qbytes_mfma_large_kernel<DT, FMT, BM, BN, WM, WN, WD>), dim3(tiles * b.S), dim3(WM * WN * 64), lds, stream, b);
   return launch_status();
 }
 
 template <int DT, int FMT>
 static int launch(const Args& a, int cfg, hipStream_t stream) {
   // three 24 KiB stages: two workgroups share a CU (two interleaving streams per SIMD)
-  if (cfg == CFG_128_4W) return launch_cfg<DT, FMT, 128, 128, 1, 4>(a, stream);
+  if (cfg == CFG_128_4W) {
+    static const int wd = [] { const char* e = getenv("QUANTO_HIP_LARGE_WD"); return e ? atoi(e) : 1; }();  // 0 off, 1 auto, 5 always
+    const int nk = a.K / BK / a.S;
+    // weights-direct variant when the K-range of a workgroup is a whole number of 4-tile ring turns
+    // and every workgroup has a CU to itself: with two workgroups per CU the partner hides the DMA latency anyway and
+    // the LDS-weight loop is faster (bf16 x int8, us, LDS -> WD: 512x8192x8192 77 -> 61, 384x8192x8192 74 -> 57,
+    // 1024x4096x4096 44 -> 33; but 1024x8192x4096 as 512 workgroups 68 -> 75, 768x6144x4096 as 288 56 -> 60)
+    const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if ((wd & 1) && nk % 4 == 0 && nk >= 8 && (tiles * a.S <= 256 || (wd & 4))) return launch_cfg<DT, FMT, 128, 128, 1, 4, true>(a, stream);
+    return launch_cfg<DT, FMT, 128, 128, 1, 4>(a, stream);
+  }
   // (tried: 128-tiles as eight waves of 128 x 16 with one workgroup per CU - LDS-bound, cfg4 90-98 us vs 86-90 us)
   if (cfg == CFG_256_4W) return launch_cfg<DT, FMT, 256, 256, 2, 2>(a, stream);
   return launch_cfg<DT, FMT, 256, 256, 2, 4>(a, stream);
@@ -453,15 +579,17 @@ bool qbytes_mfma_large_supported(int64_t M, int64_t N, int64_t K, int a_dtype, i
          K >= 2 * lt::BK && M >= 1 && M * K < (1ll << 30) && N * K < (1ll << 31) && M < (1 << 30) && N < (1 << 30);
 }
 
-// split-K for the 128-tile configuration, only when its tiles cover at most half of the CUs and K is long: the partial
-// sums cost 64 KiB of system-coherent traffic per workgroup each way.  Measured (bf16 x int8, split 1 -> 2):
-// (512, 4096, 14336) 129 -> 95 us, but cfg4 (512, 8192, 8192; 256 tiles) 84 -> 105 us and (1024, 4096, 4096) 44 -> 76 us.
+// split-K for the 128-tile configuration, only when its tiles cover at most half of the CUs and K is very long: the partial
+// sums cost 64 KiB of system-coherent traffic per workgroup each way, ~12 us in all.  Measured with the weights-direct
+// loop (bf16 x int8, M = 512, N = 4096, split 1 -> 2): K = 4096 30 -> 42 us, K = 8192 55 -> 57 us, K = 14336 91 -> 80 us;
+// cfg4 (512, 8192, 8192; 256 tiles) 65 -> 100 us.
 static int large_split(int64_t M, int64_t N, int64_t K) {
   static const int forced = [] { const char* e = getenv("QUANTO_HIP_LARGE_SPLIT"); return e ? atoi(e) : 0; }();  // experiments
   const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256), tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
   int s = 1;
-  if (tiles256 < 96 && tiles128 <= 128 && K >= 4096 && (K / lt::BK) % 2 == 0) s = 2;
-  if (forced > 0 && tiles256 < 96 && (K / lt::BK) % forced == 0 && K / lt::BK / forced >= 2) s = forced;
+  if (tiles128 <= 128 && K >= 10240 && (K / lt::BK) % 2 == 0) s = 2;
+  if (forced > 0 && tiles128 <= 512 && (K / lt::BK) % forced == 0 && K / lt::BK / forced >= 2) s = forced;
+  (void)tiles256;
   return s;
 }
 static size_t large_counter_bytes(int64_t M, int64_t N) { return ((size_t)(((M + 127) / 128) * ((N + 127) / 128)) * 4 + 255) / 256 * 256; }
@@ -476,10 +604,12 @@ int qbytes_mm_mfma_large(const void* x, const void* w, const void* s, const void
   if (!qbytes_mfma_large_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
   int split = large_split(M, N, K);
   if (split > 1 && (!workspace || workspace_bytes < qbytes_mfma_large_workspace(M, N, K) || reinterpret_cast<uintptr_t>(workspace) % 16)) split = 1;
-  // 256-tiles when they give every CU at least ~3/8 of a tile; otherwise 128-tiles (4x the workgroups)
+  // 128-tiles as long as all of them are resident at once (two workgroups per CU: 512), 256-tiles beyond.  Measured,
+  // bf16 x int8, K = 4096, us with 256-tiles -> 128-tiles: (512,14336) 87 -> 67, (1024,8192) 85 -> 70, (2048,4096) 79 -> 66;
+  // but (1280,8192) 82 -> 99, (2048,8192) 107 -> 125
   static const int forced = [] { const char* e = getenv("QUANTO_HIP_LARGE_CFG"); return e ? atoi(e) : -1; }();  // experiments
-  const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
-  const int cfg = forced >= 0 ? forced : (tiles256 >= 96 ? lt::CFG_256_8W : lt::CFG_128_4W);
+  const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+  const int cfg = forced >= 0 ? forced : (tiles128 > 512 ? lt::CFG_256_8W : lt::CFG_128_4W);
   if (cfg != lt::CFG_128_4W) split = 1;  // the workspace is sized for 128-tiles
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
   lt::Args a{x, reinterpret_cast<const uint8_t*>(w), s, bias, y, (int)M, (int)N, (int)K, 1, split, reinterpret_cast<int*>(workspace),

@@ -279,17 +279,19 @@ def test_qbytes_mfma(dt, kind, M, N, K):
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("kind", [None, "e4m3fn", "e5m2"])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1024), (300, 700, 256), (1, 17, 192), (1024, 256, 4096), (256, 512, 192)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 1024), (300, 700, 256), (1, 17, 192), (1024, 256, 4096), (256, 512, 192),
+                                   (300, 700, 512), (384, 640, 768), (300, 700, 8192)])
 def test_qbytes_mfma_large_tile(dt, kind, M, N, K):
-    """256x256 LDS-DMA kernel incl. ragged M / N edges (clamped loads, masked stores), 2..64 K-tiles, odd and even tile
-    counts for the 3-stage ring."""
+    """LDS-DMA tile kernel incl. ragged M / N edges (clamped loads, masked stores), 2..128 K-tiles: odd and even tile
+    counts for the 3-stage ring of the LDS-weight loop, and 8 / 12 / 16 / 64 / 128 K-tiles (whole turns of the four-tile
+    register ring) for the weights-direct loop that 128-tile grids of at most 256 workgroups get."""
     p = make_qbytes_problem(M, N, K, dt, kind, seed=M + K + 1)
     assert_close_to_exact(_run_qbytes(p, "mfma_large"), O.qbytes_mm_exact(p["x"], p["data"], p["scale"], kind), dt, "qbytes mfma_large")
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("kind", [None, "e4m3fn"])
-@pytest.mark.parametrize("M,N,K", [(512, 512, 4096), (300, 700, 8192), (128, 256, 4096)])
+@pytest.mark.parametrize("M,N,K", [(512, 512, 10240), (300, 700, 12288), (128, 256, 10240)])
 def test_qbytes_mfma_large_tile_split_k(dt, kind, M, N, K):
     """128-tiles with the K-range halved across two workgroups per tile (few tiles, long K): partial sums through the
     workspace, last-arriver reduction, ragged edges; called twice to check that the arrival counters were left zero."""
