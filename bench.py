@@ -13,6 +13,10 @@ With N > 1 (launched by ``python -m torch.distributed.run``) every rank runs the
 path is embarrassingly parallel per Linear, no data-path collective, weak scaling; ``value`` is the whole-job
 aggregate (sum over ranks of work / max-over-ranks time).
 
+Before the timed K steps the same steps are replayed, untimed, for ``--ramp-ms`` (default 300 ms): an idle MI355X takes
+tens of milliseconds of sustained load to reach its steady clock / power state (the number is in ``config.clock_ramp_ms``;
+``--ramp-ms 0`` gives the cold-start figure).
+
 One JSON line is printed by rank 0, carrying ``roofline`` (dominant kernel, measured with device events around the
 timed region) and ``cpu_baseline`` (the numpy oracle timed on the host cores on a bounded sample).
 """
@@ -161,6 +165,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="issue the timed steps one by one from Python instead of replaying a hipGraph")
+    ap.add_argument("--ramp-ms", type=float, default=300.0,
+                    help="untimed: keep the device busy with the same steps for this long before the timed region (clock ramp)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -203,6 +209,18 @@ def main():
                     step()
         torch.cuda.current_stream().wait_stream(side)
         graph.replay()  # untimed: uploads the executable graph
+        torch.cuda.synchronize()
+    # Untimed clock ramp.  An idle MI355X needs tens of milliseconds of sustained load to reach its steady power state: the
+    # first 6 ms window of 4096^3 launches after process start averages 121 us per launch, the following ones 110, 105, 103,
+    # 102 and from ~100 ms on 100 us (scripts/microbench_qbytes.py, same shape first / last in a process).  W warm-up
+    # steps of a 0.1 ms kernel cannot cover that, so the same steps are replayed for --ramp-ms before the timed K steps.
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(args.steps):
+                step()
         torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -254,7 +272,7 @@ def main():
             "metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": ARITH_DTYPE[kind], "data": "synthetic",
-            "config": {"workload": desc, "M": M, "K": K, "N": N, "weight_buffers_rotated": n_weights, "launch": "eager" if args.eager else "hipGraph replay of the K steps",
+            "config": {"workload": desc, "M": M, "K": K, "N": N, "weight_buffers_rotated": n_weights, "launch": "eager" if args.eager else "hipGraph replay of the K steps", "clock_ramp_ms": args.ramp_ms,
                        "parallelism": f"replicas x{world} (no data-path collective)"},
             "tflops": round(flops * world / (elapsed / args.steps) / 1e12, 3),
             "gbps": round(nbytes * world / (elapsed / args.steps) / 1e9, 1),

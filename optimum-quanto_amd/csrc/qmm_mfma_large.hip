@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   QH_LT_STAMP(6);
 }
 
-enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2 };
+enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2, CFG_256_1X8 = 3 };
 
 template <int DT, int FMT, int BM, int BN, int WM, int WN, bool WD = false>
 static int launch_cfg(const Args& a, hipStream_t stream) {
@@ -568,6 +568,7 @@ static int launch(const Args& a, int cfg, hipStream_t stream) {
   }
   // (tried: 128-tiles as eight waves of 128 x 16 with one workgroup per CU - LDS-bound, cfg4 90-98 us vs 86-90 us)
   if (cfg == CFG_256_4W) return launch_cfg<DT, FMT, 256, 256, 2, 2>(a, stream);
+  if (cfg == CFG_256_1X8) return launch_cfg<DT, FMT, 256, 256, 1, 8>(a, stream);
   return launch_cfg<DT, FMT, 256, 256, 2, 4>(a, stream);
 }
 

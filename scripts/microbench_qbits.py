@@ -27,7 +27,10 @@ for (M,N,K) in shapes:
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr):
             for _ in range(32): f()
-        gr.replay(); torch.cuda.synchronize()
+        import time
+        t_ramp = time.perf_counter()  # clock ramp: an idle device needs ~100 ms of load to reach its steady state
+        while time.perf_counter() - t_ramp < 0.1:
+            gr.replay(); torch.cuda.synchronize()
         e0,e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1)/32*1000

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--ramp-ms", type=float, default=100.0)
     args = ap.parse_args()
     from optimum_quanto_amd.library.hip import quanto_hip
 
@@ -43,6 +44,12 @@ def main():
                 lib.qbytes_mm(a, b, s, kernel=args.kernel)
             kern = lib.last_kernel()
             torch.cuda.synchronize()
+            import time
+            t_ramp = time.perf_counter()  # clock ramp: an idle device needs ~100 ms of load to reach its steady state
+            while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+                for _ in range(20):
+                    lib.qbytes_mm(a, b, s, kernel=args.kernel)
+                torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             if args.graph:  # replay: a call of a few microseconds is shorter than its Python issue time
                 g = torch.cuda.CUDAGraph()
