@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--ramp-ms", type=float, default=100.0)
+    ap.add_argument("--const", action="store_true", help="constant operands (all ones): separates data-dependent power / clock effects")
     args = ap.parse_args()
     from optimum_quanto_amd.library.hip import quanto_hip
 
@@ -28,6 +29,9 @@ def main():
     dev = torch.device("cuda", 0)
 
     def make(kind, rows, K):
+        if args.const:
+            dt = {"i8": torch.int8, "f8": torch.float8_e4m3fn}.get(kind, torch.bfloat16)
+            return torch.ones(rows, K, device=dev, dtype=torch.float32).to(dt)
         if kind == "i8":
             return torch.randint(-127, 128, (rows, K), dtype=torch.int8, device=dev)
         if kind == "f8":
