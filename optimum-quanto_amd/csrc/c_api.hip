@@ -32,6 +32,8 @@ size_t qbytes_skinny_workspace(int64_t, int64_t, int64_t);
 int qbytes_mm_skinny(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, void*, size_t, hipStream_t);
 bool dense_mm_large_supported(int64_t, int64_t, int64_t, int);
 int dense_mm_large(const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, hipStream_t);
+bool dense_mm_wd_supported(int64_t, int64_t, int64_t, int);
+int dense_mm_wd(const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, hipStream_t);
 bool qbytes_native8_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_native8(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 bool qbits_skinny_supported(int64_t, const PackedGeom&, int);
@@ -76,8 +78,12 @@ static size_t dequant_mfma_workspace(const PackedGeom& g) { return (size_t)g.N *
 
 static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {
   if (M <= 4 && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
-  if (qbits_skinny_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_SKINNY;
-  if (qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
+  // the streaming kernel's time grows with M (passes of 64 rows), dequantize + dense GEMM is flat in M up to 1024 rows:
+  // (M, 4096, 4096) us streaming / dequantize + GEMM: M = 128 34 / 56, M = 256 66 / 54; (256, 14336, 4096) 116 / 79; but
+  // (256, 4096, 14336) 127 / 167
+  const bool flat_wins = M > 192 && g.K <= 8192 && have_workspace && dequant_mfma_supported(M, g, dtype);
+  if (!flat_wins && qbits_skinny_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_SKINNY;
+  if (!flat_wins && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
   if (have_workspace && M > QUANTO_HIP_GEMV_MAX_M_QBITS && dequant_mfma_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_DEQUANT_MFMA;
   if (have_workspace && qbits_mfma_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MFMA;
   // int2, per-channel and group sizes other than 64 / 128 at small M: still one fused dequantize + one dense GEMM rather than
@@ -88,7 +94,12 @@ static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool hav
 
 // The LDS-DMA pipelined kernel (256x256 or 128x128 tiles, picked inside) whenever its 128-tiles can occupy a good part of
 // the chip; the register-staged 128x128 kernel remains for what it does not support (fp32, K % 64 != 0, K < 128)
-static bool prefer_large_tile(int64_t M, int64_t N) { return ((M + 127) / 128) * ((N + 127) / 128) >= 64; }
+// ... or M fills most of a 128-row tile: with the weights-direct loop a lone 128-tile workgroup streams a K-tile in 0.42 us,
+// which beats the streaming kernel's passes of 64 rows (bf16 x int8, us, streaming -> tile: (128,4096,4096) 32 -> 27,
+// (256,4096,4096) 64 -> 27, (128,14336,4096) 45 -> 28, (128,1024,4096) 29 -> 27; but (96,4096,4096) 26 -> 32)
+static bool prefer_large_tile(int64_t M, int64_t N, int64_t K) {
+  return ((M + 127) / 128) * ((N + 127) / 128) >= 64 || (M > 96 && K >= 512);
+}
 
 }  // namespace qh
 
@@ -182,7 +193,8 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
       if (!workspace || workspace_bytes < dequant_mfma_workspace(g)) return QUANTO_HIP_EINVAL;
       r = dequantize_qbits_dispatch(packed, scale, shift, workspace, g, dtype, int_shift, stream);
       if (r != QUANTO_HIP_OK) return r;
-      r = dense_mm_large(x, workspace, bias, y, M, g.N, g.K, dtype, stream);
+      r = dense_mm_wd_supported(M, g.N, g.K, dtype) ? dense_mm_wd(x, workspace, bias, y, M, g.N, g.K, dtype, stream)
+                                                    : dense_mm_large(x, workspace, bias, y, M, g.N, g.K, dtype, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("dequant_mfma");
       return r;
     case QUANTO_HIP_KERNEL_SKINNY:
@@ -206,7 +218,7 @@ static int pick_qbytes_kernel(int64_t M, int64_t N, int64_t K, int a_dtype, int 
   const bool skinny = qbytes_skinny_supported(M, N, K, a_dtype, b_dtype, out_dtype);
   const bool large = qbytes_mfma_large_supported(M, N, K, a_dtype, b_dtype, out_dtype);
   if (skinny && M <= 64) return QUANTO_HIP_KERNEL_SKINNY;
-  if (large && prefer_large_tile(M, N)) return QUANTO_HIP_KERNEL_MFMA_LARGE;
+  if (large && prefer_large_tile(M, N, K)) return QUANTO_HIP_KERNEL_MFMA_LARGE;
   if (skinny) return QUANTO_HIP_KERNEL_SKINNY;
   if (prefer_gemv(M) && qbytes_gemv_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_KERNEL_GEMV;
   if (large) return QUANTO_HIP_KERNEL_MFMA_LARGE;

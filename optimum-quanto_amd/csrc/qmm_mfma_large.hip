@@ -68,7 +68,7 @@ struct Mma<QUANTO_HIP_F16> {
   }
 };
 
-enum { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2 };
+enum { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2, W_DENSE = 3 };  // W_DENSE: weights already in the activation dtype (weights-direct loop only)
 
 __device__ __forceinline__ int swz_a(int row) {
   const int q = (row + 4) & 15;
@@ -234,6 +234,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   using no = std::integral_constant<bool, false>;
   if constexpr (WD) {
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    constexpr bool DENSE = FMT == W_DENSE;
+    constexpr int WB = DENSE ? 2 : 1;      // bytes per weight = 16-byte loads per fragment and K-tile
+    constexpr int WLOADS = NJ * WB;        // weight loads per wave and K-tile
+    static_assert(APIECES + WLOADS <= STEPS, "unsupported tile configuration");
     // ---- weights: lane (r = lane & 15, g = lane >> 4) of fragment j owns bytes 16g..16g+15 of feature row j*16 + r of the
     // K-tile: k-half 0 operand in .xy, k-half 1 in .zw (the same 16 bytes the LDS path reads back from its weight image)
     uint32_t wofs[NJ];
@@ -241,11 +245,15 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
     for (int j = 0; j < NJ; ++j) {
       int n = n0 + wn * (NJ * 16) + j * 16 + (lane & 15);
       n = n < N ? n : N - 1;
-      wofs[j] = (uint32_t)((size_t)n * K + (lane >> 4) * 16 + (size_t)kt0 * BK);
+      wofs[j] = (uint32_t)(((size_t)n * K + (lane >> 4) * 16 + (size_t)kt0 * BK) * WB);
     }
-    u32x4 rg[4][NJ];  // rg[t & 3]: weight bytes of tile t, loaded during tile t-3, complete at the end of tile t-2
-    auto load_w = [&](int kt, u32x4& dst, int j) {
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(wofs[j]), "s"(a.w + (size_t)kt * BK) : "memory");
+    // rg[t & 3]: weight bytes of tile t, loaded during tile t-3, complete at the end of tile t-2.  W_DENSE: the lane's 32
+    // bytes are the two MFMA operands themselves ([..][0] k-half 0, [..][1] k-half 1), no conversion and no w0 / w1
+    u32x4 rg[4][NJ][WB];
+    auto load_w = [&](int kt, u32x4 (&dst)[WB], int j) {
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[0]) : "v"(wofs[j]), "s"(a.w + (size_t)kt * (BK * WB)) : "memory");
+      if constexpr (DENSE)
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(dst[1]) : "v"(wofs[j]), "s"(a.w + (size_t)kt * (BK * WB)) : "memory");
     };
     auto word = [&](const u32x4& r, int kk, int d) -> uint32_t { return kk == 0 ? (d < 2 ? r.x : r.y) : (d < 2 ? r.z : r.w); };
 
@@ -261,15 +269,19 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(rg[t][j]));
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int b = 0; b < WB; ++b) asm volatile("" : "+v"(rg[t][j][b]));
     QH_LT_STAMP(1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     QH_LT_STAMP(2);
+    if constexpr (!DENSE) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int d = 0; d < 4; ++d) w0[j][d] = convert_pair<DT, FMT>(word(rg[0][j], 0, d), d & 1);
+        for (int d = 0; d < 4; ++d) w0[j][d] = convert_pair<DT, FMT>(word(rg[0][j][0], 0, d), d & 1);
+    }
     xf[0] = read_x(smem, 0, 0);
     xf[1] = read_x(smem, 1, 0);
 
@@ -285,16 +297,20 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
         const int kk = s / MI, i = s % MI;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          if (kk == 0)
-            acc[j][i] = Mma<DT>::run(as_v8(w0[j]), xf[s & 3], acc[j][i]);
-          else
-            acc[j][i] = Mma<DT>::run(as_v8(w1[j]), xf[s & 3], acc[j][i]);
-          if (j < ND && i * ND + j < NJ * 4) {
-            const int c = i * ND + j, f = c >> 2, d = c & 3;
+          if constexpr (DENSE) {
+            acc[j][i] = Mma<DT>::run(__builtin_bit_cast(V8, rg[P][j][kk == 0 ? 0 : WB - 1]), xf[s & 3], acc[j][i]);
+          } else {
             if (kk == 0)
-              w1[f][d] = convert_pair<DT, FMT>(word(rg[P][f], 1, d), d & 1);            // this tile's k-half 1
+              acc[j][i] = Mma<DT>::run(as_v8(w0[j]), xf[s & 3], acc[j][i]);
             else
-              w0[f][d] = convert_pair<DT, FMT>(word(rg[(P + 1) & 3][f], 0, d), d & 1);  // next tile's k-half 0
+              acc[j][i] = Mma<DT>::run(as_v8(w1[j]), xf[s & 3], acc[j][i]);
+            if (j < ND && i * ND + j < NJ * 4) {
+              const int c = i * ND + j, f = c >> 2, d = c & 3;
+              if (kk == 0)
+                w1[f][d] = convert_pair<DT, FMT>(word(rg[P][f][0], 1, d), d & 1);            // this tile's k-half 1
+              else
+                w0[f][d] = convert_pair<DT, FMT>(word(rg[(P + 1) & 3][f][0], 0, d), d & 1);  // next tile's k-half 0
+            }
           }
           if (j == (ND < NJ ? ND : 0))
             xf[(s + 2) & 3] = s + 2 < STEPS ? read_x(st, (s + 2) % MI, (s + 2) / MI) : read_x(sn, s + 2 - STEPS, 0);
@@ -302,7 +318,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
             if (s < APIECES)
               issue_piece(kt + 3, (P + 3) & 3, s);
             else
-              load_w(kt + 3, rg[(P + 3) & 3][s - APIECES], s - APIECES);
+              load_w(kt + 3, rg[(P + 3) & 3][s - APIECES], s - APIECES);  // W_DENSE: two loads in this slot
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -310,9 +326,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
       if (BARRIER) {
         // the activation rows of tile kt+2 (issued during tile kt-1) feed the fragment prefetch at the end of tile kt+1,
         // its weight registers the conversions of tile kt+1's second phase.  What this tile issued stays in flight.
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA ? APIECES + NJ : 0) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA ? APIECES + WLOADS : 0) : "memory");
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(rg[(P + 2) & 3][j]));
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int b = 0; b < WB; ++b) asm volatile("" : "+v"(rg[(P + 2) & 3][j][b]));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
@@ -428,7 +446,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
 
   // ---- epilogue: scale (+bias) on the fp32 accumulator; each wave parks MI*16 tokens x 64 features per pass -------------
   T* yg = reinterpret_cast<T*>(a.y);
-  const bool has_bias = a.bias != nullptr;
+  const bool has_bias = a.bias != nullptr, has_scale = a.scale != nullptr;
   const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (N % 8 == 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -483,7 +501,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = nb + r < N ? nb + r : N - 1;
-        sc[r] = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
+        sc[r] = has_scale ? E::to_f32(reinterpret_cast<const T*>(a.scale)[n]) : 1.f;
         bv[r] = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
       }
 #pragma unroll
@@ -598,6 +616,24 @@ size_t qbytes_mfma_large_workspace(int64_t M, int64_t N, int64_t K) {
   const int S = large_split(M, N, K);
   if (S == 1) return 0;
   return large_counter_bytes(M, N) + (size_t)(((M + 127) / 128) * ((N + 127) / 128)) * S * (128 * 128 * 4);
+}
+
+// Dense 16-bit GEMM y = x @ w^T (+ bias) on the weights-direct 128-tile loop, for grids that leave every workgroup a CU of its
+// own - there the 64-byte K-tiles of qmm_native8.hip's dense kernel are barrier-latency bound.  Used by qbits_mm's
+// dequantize + GEMM path: (256, 4096, 4096) 58 -> 3x us, see DESIGN.md 4.5.
+bool dense_mm_wd_supported(int64_t M, int64_t N, int64_t K, int dtype) {
+  static const int on = [] { const char* e = getenv("QUANTO_HIP_DENSE_WD"); return e ? atoi(e) : 1; }();  // experiments
+  const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+  return on && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && K % (4 * lt::BK) == 0 && K >= 8 * lt::BK && M >= 1 &&
+         tiles128 <= 256 && M * K < (1ll << 30) && N * K < (1ll << 30);
+}
+
+int dense_mm_wd(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int dtype, hipStream_t stream) {
+  if (!dense_mm_wd_supported(M, N, K, dtype)) return QUANTO_HIP_ENOTSUP;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
+  lt::Args a{x, reinterpret_cast<const uint8_t*>(w), nullptr, bias, y, (int)M, (int)N, (int)K, 1, 1, nullptr, nullptr};
+  if (dtype == QUANTO_HIP_BF16) return lt::launch_cfg<QUANTO_HIP_BF16, lt::W_DENSE, 128, 128, 1, 4, true>(a, stream);
+  return lt::launch_cfg<QUANTO_HIP_F16, lt::W_DENSE, 128, 128, 1, 4, true>(a, stream);
 }
 
 int qbytes_mm_mfma_large(const void* x, const void* w, const void* s, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int a_dtype,
