@@ -9,10 +9,11 @@ for W in "$@"; do
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -o $W -- \
       python $REPO/bench.py --workload $W --no-cpu-baseline > $OUT/trace_$W.bench.json 2> $OUT/trace_$W.log)
   f=$(find $OUT/trace_$W -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/${W}_kernel_stats.csv
+  find $OUT/trace_$W -name "*kernel_trace.csv" -delete  # tens of thousands of rows with the clock ramp: only the stats travel back
   # 2. HBM traffic: separate --pmc passes (FETCH_SIZE needs 3 of the 4 TCC slots, WRITE_SIZE 2)
   for C in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${W}_$C -o pmc -- \
-        python $REPO/bench.py --workload $W --steps 8 --warmup 2 --no-cpu-baseline --eager > /dev/null 2> $OUT/pmc_${W}_$C.log)
+        python $REPO/bench.py --workload $W --steps 8 --warmup 2 --ramp-ms 0 --no-cpu-baseline --eager > /dev/null 2> $OUT/pmc_${W}_$C.log)
   done
   python - "$OUT" "$W" <<'PY'
 import csv, glob, json, sys, collections

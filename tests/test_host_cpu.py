@@ -56,6 +56,10 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     lib.quanto_hip_qbits_mm_pick.restype = ctypes.c_int
     lib.quanto_hip_qbits_mm_pick.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 3
     assert lib.quanto_hip_qbits_mm_pick(64, 4096, 4096, 4, 128, 2) == 5 and lib.quanto_hip_qbits_mm_pick(1, 4096, 4096, 4, 128, 2) == 2
+    # streaming kernel up to 192 rows (256 for long K, where one dequantize pass costs more than its extra passes), flat path above
+    assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 4, 128, 2) for m in (192, 256, 1024)] == [5, 7, 7]
+    assert lib.quanto_hip_qbits_mm_pick(256, 4096, 14336, 4, 128, 2) == 5
+    assert lib.quanto_hip_qbits_mm_workspace_size(256, 4096, 4096, 4, 128, 2, 0) == 4096 * 4096 * 2
     assert lib.quanto_hip_qbits_mm_workspace_size(4, 4096, 4096, 4, 128, 2, 0) == 0
     assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 4, 128, 2, 0) == 0  # GEMV needs none
     assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 3, 128, 2, 0) == -1
@@ -83,6 +87,11 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     lib.quanto_hip_qbytes_mm_pick.argtypes = [i64] * 3 + [ci] * 3
     picks = {m: lib.quanto_hip_qbytes_mm_pick(m, 4096, 4096, 2, 3, 2) for m in (1, 8, 64, 256, 4096)}
     assert picks == {1: 2, 8: 5, 64: 5, 256: 4, 4096: 4}, picks                                  # gemv, skinny, skinny, large, large
+    # one 128-row tile band beats the streaming kernel's passes of 64 rows from ~100 rows on, even on a handful of tiles
+    assert [lib.quanto_hip_qbytes_mm_pick(m, 1024, 4096, 2, 3, 2) for m in (96, 128)] == [5, 4]
+    # split-K of the 128-tile grid only for very long K; (512, 4096, 4096) runs unsplit without workspace
+    assert lib.quanto_hip_qbytes_mm_workspace_size(512, 4096, 4096, 2, 3, 2, 0) == 0
+    assert lib.quanto_hip_qbytes_mm_workspace_size(512, 4096, 14336, 2, 3, 2, 0) == 512 + 128 * 2 * 128 * 128 * 4  # 128 counters + fp32 partials
     assert lib.quanto_hip_qbytes_mm_pick(4096, 4096, 4096, 3, 3, 2) == 6                         # int8 activations: native8
 
 
@@ -215,3 +224,36 @@ def test_quantize_weight_argument_errors():
         Q.quantize_weight(w, Q.qint4, axis=0, scale=torch.ones(8, 1))
     with pytest.raises(ValueError):
         torch.ops.quanto.quantize_symmetric(torch.randn(8), torch.int8, 0, torch.ones(8))
+
+
+@pytest.mark.parametrize("kind", ["qbits_i4", "qbytes_i8", "qbytes_f8", "qbytes_i8i8", "qbytes_f8f8"])
+def test_bench_inputs_are_quantizer_outputs(kind):
+    """bench.py builds its synthetic operands with the reference quantizer's arithmetic, on the device the
+    bench runs on; here on the CPU: the dequantized weight must reproduce the bf16 weight it came from to within half a
+    quantization step, int4 codes must span 0..15 per group, int8 rows must reach +-127."""
+    import bench
+    from oracle import quanto_oracle as O
+
+    M, K, N = 8, 256, 64
+    x, sets = bench.build_inputs(kind, M, K, N, torch.device("cpu"), 2, seed=3)
+    assert len(sets) == 2 and tuple(x.shape) == (M, K)
+    if kind == "qbits_i4":
+        packed, scale, shift = sets[0]
+        assert tuple(packed.shape) == (N * K // 256, 128) and tuple(scale.shape) == (N * K // 128, 1) == tuple(shift.shape)
+        q = O.unpacked_rows(to_numpy(packed), 4, N * K // 128)
+        assert q.min() == 0 and q.max() == 15
+        assert (q.min(axis=1) == 0).all() and (q.max(axis=1) == 15).all()  # max-min affine: every group spans the range
+    else:
+        q, scale = sets[0]
+        assert tuple(q.shape) == (N, K) and tuple(scale.shape) == (N, 1) and scale.dtype == torch.bfloat16
+        if q.dtype == torch.int8:
+            a = q.to(torch.int32).abs().amax(dim=1)
+            assert int(a.max()) <= 127 and int(a.min()) >= 126  # absmax scaling (scale rounded to bf16: 126 or 127)
+        else:
+            assert q.dtype == torch.float8_e4m3fn and float(q.float().abs().max()) <= 448.0
+    if kind == "qbytes_i8i8":
+        assert x.dtype == torch.int8 and int(x.to(torch.int32).abs().max()) >= 126
+    elif kind == "qbytes_f8f8":
+        assert x.dtype == torch.float8_e4m3fn
+    else:
+        assert x.dtype == torch.bfloat16
