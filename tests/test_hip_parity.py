@@ -264,7 +264,8 @@ def test_qbytes_skinny(dt, kind, M, N, K):
     want = O.qbytes_mm_exact(p["x"], p["data"], p["scale"], kind)
     assert_close_to_exact(_run_qbytes(p, "skinny"), want, dt, "qbytes skinny")
     assert_close_to_exact(_run_qbytes(p, "auto"), want, dt, "qbytes auto")
-    assert quanto_hip.lib.last_kernel() == "skinny"
+    # from ~100 rows on one band of 128-row tiles beats the passes of 64 rows (c_api.hip prefer_large_tile)
+    assert quanto_hip.lib.last_kernel() == ("mfma_large" if M > 96 and K >= 512 else "skinny")
     bias = O.round_to(np.random.default_rng(5).standard_normal(N).astype(np.float32), dt)
     assert_close_with_bias(_run_qbytes(p, "skinny", bias), want, bias, dt, "qbytes skinny + bias")
 
@@ -479,7 +480,7 @@ def test_int4_prefill_4096_cubed():
     np.testing.assert_array_equal(_run_qbits(dict(p, x=p["x"] * 2), "auto"), y * 2)
 
 
-@pytest.mark.parametrize("M", [32, 200])
+@pytest.mark.parametrize("M", [32, 160])
 def test_batched_decode_llama_shapes(M):
     """Streaming kernels (split-K, passes) on the Llama-3-8B layer shapes with the long K: sampled rows vs float64 math."""
     for (N, K) in [(4096, 14336), (1024, 4096)]:
