@@ -133,6 +133,16 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
   tm = g * group_m + (in_g - tn * rows);
 }
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, R-1>): the weights-direct loop is unrolled over its ring slots
+template <int... Ps, class F>
+__device__ __forceinline__ void for_each_slot_impl(std::integer_sequence<int, Ps...>, F&& f) {
+  (f(std::integral_constant<int, Ps>{}), ...);
+}
+template <int R, class F>
+__device__ __forceinline__ void for_each_slot(F&& f) {
+  for_each_slot_impl(std::make_integer_sequence<int, R>{}, f);
+}
+
 // Tile configurations (BM x BN workgroup tile, WM x WN waves, each wave (BM/WM) x (BN/WN)):
 //   256 x 256, 2 x 4 waves of 128 x 64  - the default for grids that fill the chip: two interleaving streams per SIMD
 //   256 x 256, 2 x 2 waves of 128 x 128 - one stream per SIMD, least LDS traffic (experiments: QUANTO_HIP_LARGE_WN=2)
@@ -142,15 +152,14 @@ __device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, i
 //                                         2 x 2 layout converts twice as much and is VALU-issue bound (measured 105 us
 //                                         vs this layout on cfg4)
 //
-// WD ("weights direct"): the weight bytes never touch the LDS.  Every lane loads the 16 bytes of its own fragment row
-// from global memory into a register ring of four K-tiles, three tiles ahead of their use, and the LDS holds FOUR
-// activation-only stages instead of three mixed ones in less space (128-tile: 4 x 16 KiB instead of 3 x 24 KiB, still
-// two workgroups per CU).  Activation DMA and weight loads are then in flight for two whole tiles instead of one.
-// It pays only where a workgroup has its CU to itself (one wave per SIMD, nobody to hide the DMA latency): see the
-// launcher for the numbers.  Tried and rejected for the 256-tile (two waves per SIMD; a ring of two weight tiles, loaded in
+// WD ("weights direct", WD = ring depth): the weight bytes never touch the LDS.  Every lane loads the 16 bytes of its own
+// fragment row from global memory into a register ring of WD K-tiles, WD-1 tiles ahead of their use, and the LDS holds WD
+// activation-only stages (128-tile: WD x 16 KiB instead of 3 x 24 KiB).  Activation DMA and weight loads are then in flight
+// for WD-2 whole tiles instead of one.  It pays only where a workgroup has its CU to itself (one wave per SIMD, nobody to
+// hide the DMA latency, and 512 registers / 160 KiB of LDS for one workgroup): see the launcher for the numbers.  Tried and rejected for the 256-tile (two waves per SIMD; a ring of two weight tiles, loaded in
 // the second phase of tile t-2 and waited for in the middle of tile t-1, because 128 accumulators leave no room for four):
 // 4096^3 121 -> 126 us, 8192^3 783 -> 811 us.
-template <int DT, int FMT, int BM, int BN, int WM, int WN, bool WD = false>
+template <int DT, int FMT, int BM, int BN, int WM, int WN, int WD = 0>
 __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(const Args a) {
   constexpr int NWAVES = WM * WN;
   constexpr int MI = BM / WM / 16;              // 16-token fragments per wave
@@ -217,7 +226,12 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   const int ra = wm * (MI * 16) + (lane & 15), rw = wn * (NJ * 16) + (lane & 15);
   int aoff[2];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) aoff[kk] = ra * 128 + ((((lane >> 4) * 2 + kk) ^ swz_a(ra)) << 4);
+  for (int kk = 0; kk < 2; ++kk) {
+    // lane group g reads 16-byte chunk 2g + kk of the row for k-half kk (any bijection works as long as the weight operand uses
+    // the same one).  W_DENSE: chunk 4 kk + g, so that the four lane groups of one weight load cover 64 contiguous bytes
+    const int chunk = FMT == W_DENSE ? kk * 4 + (lane >> 4) : (lane >> 4) * 2 + kk;
+    aoff[kk] = ra * 128 + ((chunk ^ swz_a(ra)) << 4);
+  }
   const int boff = A_BYTES + rw * 64 + (((lane >> 4) ^ swz_w(rw)) << 4);
 
   f32x4 acc[NJ][MI];  // acc[j][i]: features j*16.., tokens i*16..
@@ -232,42 +246,47 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   auto read_x = [&](const uint8_t* st, int i, int kk) -> V8 { return *reinterpret_cast<const V8*>(st + aoff[kk] + i * 2048); };
   using yes = std::integral_constant<bool, true>;
   using no = std::integral_constant<bool, false>;
-  if constexpr (WD) {
+  if constexpr (WD != 0) {
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
     constexpr bool DENSE = FMT == W_DENSE;
     constexpr int WB = DENSE ? 2 : 1;      // bytes per weight = 16-byte loads per fragment and K-tile
     constexpr int WLOADS = NJ * WB;        // weight loads per wave and K-tile
     static_assert(APIECES + WLOADS <= STEPS, "unsupported tile configuration");
     // ---- weights: lane (r = lane & 15, g = lane >> 4) of fragment j owns bytes 16g..16g+15 of feature row j*16 + r of the
-    // K-tile: k-half 0 operand in .xy, k-half 1 in .zw (the same 16 bytes the LDS path reads back from its weight image)
+    // K-tile: k-half 0 operand in .xy, k-half 1 in .zw (the same 16 bytes the LDS path reads back from its weight image).
+    // W_DENSE: bytes 16g..16g+15 (k-half 0) and 64+16g.. (k-half 1) of the 128-byte row
     uint32_t wofs[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       int n = n0 + wn * (NJ * 16) + j * 16 + (lane & 15);
       n = n < N ? n : N - 1;
-      wofs[j] = (uint32_t)(((size_t)n * K + (lane >> 4) * 16 + (size_t)kt0 * BK) * WB);
+      wofs[j] = (uint32_t)(((size_t)n * K + (size_t)kt0 * BK) * WB + (lane >> 4) * 16);
     }
-    // rg[t & 3]: weight bytes of tile t, loaded during tile t-3, complete at the end of tile t-2.  W_DENSE: the lane's 32
-    // bytes are the two MFMA operands themselves ([..][0] k-half 0, [..][1] k-half 1), no conversion and no w0 / w1
-    u32x4 rg[4][NJ][WB];
+    // rg[t % RING]: weight bytes of tile t, loaded during tile t-RING+1, complete at the end of tile t-2.  W_DENSE: the
+    // lane's 32 bytes are the two MFMA operands themselves ([..][0] k-half 0, [..][1] k-half 1), no conversion and no w0 / w1
+    constexpr int RING = WD;                 // K-tiles in flight + in use: LDS stages and weight register slots
+    constexpr int GROUP = APIECES + WLOADS;  // vector-memory instructions a wave issues per K-tile
+    constexpr int AHEAD = (RING - 3) * GROUP;  // tiles kt+3 .. kt+RING-1 may still be in flight when tile kt ends
+    static_assert(AHEAD <= 63, "vmcnt is a 6-bit counter");
+    u32x4 rg[RING][NJ][WB];
     auto load_w = [&](int kt, u32x4 (&dst)[WB], int j) {
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[0]) : "v"(wofs[j]), "s"(a.w + (size_t)kt * (BK * WB)) : "memory");
       if constexpr (DENSE)
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(dst[1]) : "v"(wofs[j]), "s"(a.w + (size_t)kt * (BK * WB)) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(dst[1]) : "v"(wofs[j]), "s"(a.w + (size_t)kt * (BK * WB)) : "memory");
     };
     auto word = [&](const u32x4& r, int kk, int d) -> uint32_t { return kk == 0 ? (d < 2 ? r.x : r.y) : (d < 2 ? r.z : r.w); };
 
-    // ---- prologue: tiles 0..2 in flight and complete, W0(0) converted, x(0..1, kk0) of tile 0 in registers ----------------
+    // ---- prologue: tiles 0..RING-2 in flight, tiles 0 and 1 complete, W0(0) converted, x(0..1, kk0) of tile 0 in registers -
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < RING - 1; ++t) {
 #pragma unroll
       for (int p = 0; p < APIECES; ++p) issue_piece(t, t, p);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) load_w(t, rg[t][j], j);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD) : "memory");
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -285,13 +304,14 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
     xf[0] = read_x(smem, 0, 0);
     xf[1] = read_x(smem, 1, 0);
 
-    // K-tile kt with kt % 4 == P: same step schedule as the LDS-weight loop below; the activation pieces and weight loads
-    // of tile kt+3 take one issue slot each in the first APIECES + NJ steps
+    // K-tile kt with kt % RING == P: same step schedule as the LDS-weight loop below; the activation pieces and weight loads
+    // of tile kt+RING-1 take one issue slot each in the first APIECES + NJ steps
     auto tile = [&](auto p_tag, int kt, auto dma_tag, auto barrier_tag) {
       constexpr int P = decltype(p_tag)::value;
       constexpr bool DMA = decltype(dma_tag)::value, BARRIER = decltype(barrier_tag)::value;
+      constexpr int PN = (P + 1) % RING, PF = (P + RING - 1) % RING;  // next tile's slot; slot refilled during this tile
       const uint8_t* st = smem + P * STAGE_BYTES;
-      const uint8_t* sn = smem + ((P + 1) & 3) * STAGE_BYTES;
+      const uint8_t* sn = smem + PN * STAGE_BYTES;
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         const int kk = s / MI, i = s % MI;
@@ -307,50 +327,44 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
             if (j < ND && i * ND + j < NJ * 4) {
               const int c = i * ND + j, f = c >> 2, d = c & 3;
               if (kk == 0)
-                w1[f][d] = convert_pair<DT, FMT>(word(rg[P][f][0], 1, d), d & 1);            // this tile's k-half 1
+                w1[f][d] = convert_pair<DT, FMT>(word(rg[P][f][0], 1, d), d & 1);   // this tile's k-half 1
               else
-                w0[f][d] = convert_pair<DT, FMT>(word(rg[(P + 1) & 3][f][0], 0, d), d & 1);  // next tile's k-half 0
+                w0[f][d] = convert_pair<DT, FMT>(word(rg[PN][f][0], 0, d), d & 1);  // next tile's k-half 0
             }
           }
           if (j == (ND < NJ ? ND : 0))
             xf[(s + 2) & 3] = s + 2 < STEPS ? read_x(st, (s + 2) % MI, (s + 2) / MI) : read_x(sn, s + 2 - STEPS, 0);
           if (DMA && j == NJ - 1 && s < APIECES + NJ) {
             if (s < APIECES)
-              issue_piece(kt + 3, (P + 3) & 3, s);
+              issue_piece(kt + RING - 1, PF, s);
             else
-              load_w(kt + 3, rg[(P + 3) & 3][s - APIECES], s - APIECES);  // W_DENSE: two loads in this slot
+              load_w(kt + RING - 1, rg[PF][s - APIECES], s - APIECES);  // W_DENSE: two loads in this slot
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       if (BARRIER) {
-        // the activation rows of tile kt+2 (issued during tile kt-1) feed the fragment prefetch at the end of tile kt+1,
-        // its weight registers the conversions of tile kt+1's second phase.  What this tile issued stays in flight.
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA ? APIECES + WLOADS : 0) : "memory");
+        // the activation rows of tile kt+2 feed the fragment prefetch at the end of tile kt+1, its weight registers the
+        // conversions of tile kt+1's second phase.  Younger tiles stay in flight: RING-3 of them in the steady state, in
+        // the tail (no more DMA; kt % RING == P because nk is a multiple of RING) the RING-3-P that are left.
+        constexpr int LEFT = DMA ? AHEAD : (RING - 3 - P > 0 ? (RING - 3 - P) * GROUP : 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LEFT) : "memory");
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-          for (int b = 0; b < WB; ++b) asm volatile("" : "+v"(rg[(P + 2) & 3][j][b]));
+          for (int b = 0; b < WB; ++b) asm volatile("" : "+v"(rg[(P + 2) % RING][j][b]));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
     };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    using P2 = std::integral_constant<int, 2>;
-    using P3 = std::integral_constant<int, 3>;
     QH_LT_STAMP(3);
     int kt = 0;
-    for (; kt + 4 < nk; kt += 4) {  // nk % 4 == 0, nk >= 8 (checked by the launcher)
-      tile(P0{}, kt, yes{}, yes{});
-      tile(P1{}, kt + 1, yes{}, yes{});
-      tile(P2{}, kt + 2, yes{}, yes{});
-      tile(P3{}, kt + 3, yes{}, yes{});
-    }
-    tile(P0{}, kt, yes{}, yes{});  // fetches tile nk-1
-    tile(P1{}, kt + 1, no{}, yes{});
-    tile(P2{}, kt + 2, no{}, yes{});
-    tile(P3{}, kt + 3, no{}, no{});
+    for (; kt + RING < nk; kt += RING)  // nk % RING == 0, nk >= 2 * RING (checked by the launcher)
+      for_each_slot<RING>([&](auto p) { tile(p, kt + decltype(p)::value, yes{}, yes{}); });
+    for_each_slot<RING>([&](auto p) {  // last turn: only its first tile still has something to fetch (tile nk-1)
+      constexpr int P = decltype(p)::value;
+      tile(p, kt + P, std::integral_constant<bool, P == 0>{}, std::integral_constant<bool, P != RING - 1>{});
+    });
   } else {
     uint4 raw[NJ];         // 16 weight bytes per fragment: k-half 0 in .xy, k-half 1 in .zw
     auto rawword = [&](int j, int kk, int d) -> uint32_t {
@@ -547,9 +561,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
 
 enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2, CFG_256_1X8 = 3 };
 
-template <int DT, int FMT, int BM, int BN, int WM, int WN, bool WD = false>
+template <int DT, int FMT, int BM, int BN, int WM, int WN, int WD = 0>
 static int launch_cfg(const Args& a, hipStream_t stream) {
-  constexpr int lds0 = WD ? 4 * (BM * BK * 2) : STAGES * (BM * BK * 2 + BN * BK);
+  constexpr int lds0 = WD != 0 ? WD * (BM * BK * 2) : STAGES * (BM * BK * 2 + BN * BK);
   static const int pad = [] { const char* e = getenv("QUANTO_HIP_LARGE_LDS_PAD"); return e ? atoi(e) : 0; }();  // experiments
   const int lds = lds0 + pad;
   static_assert(lds0 >= BM * BN * 2, "the epilogue parks the output tile in the stage memory");
@@ -581,7 +595,11 @@ static int launch(const Args& a, int cfg, hipStream_t stream) {
     // the LDS-weight loop is faster (bf16 x int8, us, LDS -> WD: 512x8192x8192 77 -> 61, 384x8192x8192 74 -> 57,
     // 1024x4096x4096 44 -> 33; but 1024x8192x4096 as 512 workgroups 68 -> 75, 768x6144x4096 as 288 56 -> 60)
     const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if ((wd & 1) && nk % 4 == 0 && nk >= 8 && (tiles * a.S <= 256 || (wd & 4))) return launch_cfg<DT, FMT, 128, 128, 1, 4, true>(a, stream);
+    // Ring depth 4.  A ring of 8 (128 KiB of activation stages, six tiles in flight) is NOT faster: (512,8192,8192) 59.7 ->
+    // 61.5 us, (256,4096,4096) 27.1 -> 29.0 us - the lone workgroup is not latency bound any more but limited by what one CU
+    // pulls through its vector L1: 24 KiB per K-tile in 0.41 us = ~27 B/clk, the same rate the dense variant (32 KiB per
+    // K-tile, 0.64 us) and two paired workgroups (48 KiB, 1.06 us) reach.
+    if ((wd & 1) && (tiles * a.S <= 256 || (wd & 4)) && nk % 4 == 0 && nk >= 8) return launch_cfg<DT, FMT, 128, 128, 1, 4, 4>(a, stream);
     return launch_cfg<DT, FMT, 128, 128, 1, 4>(a, stream);
   }
   // (tried: 128-tiles as eight waves of 128 x 16 with one workgroup per CU - LDS-bound, cfg4 90-98 us vs 86-90 us)
@@ -619,8 +637,8 @@ size_t qbytes_mfma_large_workspace(int64_t M, int64_t N, int64_t K) {
 }
 
 // Dense 16-bit GEMM y = x @ w^T (+ bias) on the weights-direct 128-tile loop, for grids that leave every workgroup a CU of its
-// own - there the 64-byte K-tiles of qmm_native8.hip's dense kernel are barrier-latency bound.  Used by qbits_mm's
-// dequantize + GEMM path: (256, 4096, 4096) 58 -> 3x us, see DESIGN.md 4.5.
+// own.  Used by qbits_mm's dequantize + GEMM path; the gain over qmm_native8.hip's 128-tile dense kernel is small
+// ((256, 4096, 4096): 47 -> 41 us for the GEMM, 58 -> 54 us with the dequantize pass): both stream 32 KiB per K-tile and CU.
 bool dense_mm_wd_supported(int64_t M, int64_t N, int64_t K, int dtype) {
   static const int on = [] { const char* e = getenv("QUANTO_HIP_DENSE_WD"); return e ? atoi(e) : 1; }();  // experiments
   const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
@@ -632,8 +650,8 @@ int dense_mm_wd(const void* x, const void* w, const void* bias, void* y, int64_t
   if (!dense_mm_wd_supported(M, N, K, dtype)) return QUANTO_HIP_ENOTSUP;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
   lt::Args a{x, reinterpret_cast<const uint8_t*>(w), nullptr, bias, y, (int)M, (int)N, (int)K, 1, 1, nullptr, nullptr};
-  if (dtype == QUANTO_HIP_BF16) return lt::launch_cfg<QUANTO_HIP_BF16, lt::W_DENSE, 128, 128, 1, 4, true>(a, stream);
-  return lt::launch_cfg<QUANTO_HIP_F16, lt::W_DENSE, 128, 128, 1, 4, true>(a, stream);
+  if (dtype == QUANTO_HIP_BF16) return lt::launch_cfg<QUANTO_HIP_BF16, lt::W_DENSE, 128, 128, 1, 4, 4>(a, stream);
+  return lt::launch_cfg<QUANTO_HIP_F16, lt::W_DENSE, 128, 128, 1, 4, 4>(a, stream);
 }
 
 int qbytes_mm_mfma_large(const void* x, const void* w, const void* s, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int a_dtype,

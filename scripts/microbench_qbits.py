@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-call device time of quanto::qbits_mm kernels on a few (M,N,K) shapes (hipGraph replay of 20 calls)."""
-import sys, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os, sys, torch
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, "tests"))
 from optimum_quanto_amd.library.hip import quanto_hip
 lib = quanto_hip.lib
 shapes = [tuple(map(int, a.split("x"))) for a in sys.argv[1:]] or [(32,4096,4096),(32,14336,4096),(32,4096,14336),(16,4096,4096),(64,4096,4096),(8,4096,4096),(1,4096,4096)]
