@@ -443,7 +443,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
         // out of that stage while it runs, so tile kt+2 must be complete before tile kt+1 starts.  Tried and rejected:
         // five 24 KiB stages for the 128-tile (one workgroup per CU instead of two: 110 us vs 86 us on cfg4) and a
         // three-step activation prefetch distance (cfg4 95 -> 119 us, 4096^3 unchanged); touching the lines of tile kt+4 with one
-        // un-waited 4-byte load per lane so that the DMA hits in L2 (4096^3 127 -> 136 us).
+        // un-waited 4-byte load per lane so that the DMA hits in L2 (4096^3 127 -> 136 us); the two waves of a SIMD issuing
+        // their DMA share in different phases of the tile (4096^3 102 -> 112 us; even the wave-uniform branch that selected
+        // the phase, not taken, cost 5 us: every scalar instruction in this loop sits in an MFMA issue gap).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
