@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   auto as_v8 = [&](const uint32_t(&w)[4]) { return __builtin_bit_cast(V8, make_uint4(w[0], w[1], w[2], w[3])); };
   auto read_x = [&](const uint8_t* st, int i, int kk) -> V8 { return *reinterpret_cast<const V8*>(st + aoff[kk] + i * 2048); };
   using yes = std::integral_constant<bool, true>;
-  using no = std::integral_constant<bool, false>;
+
   if constexpr (WD != 0) {
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
     constexpr bool DENSE = FMT == W_DENSE;
@@ -397,13 +397,27 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
     // One K-tile.  The source order below IS the schedule: a sched_barrier after every MFMA group keeps hipcc from
     // clustering the conversions (it otherwise hoists ~50 VALU ops in front of the first MFMA of a tile, which leaves the
     // matrix pipe idle for their whole issue time).
-    int cur = 0;
-    auto tile = [&](int kt, auto dma_tag, auto barrier_tag) {
-      constexpr bool DMA = decltype(dma_tag)::value, BARRIER = decltype(barrier_tag)::value;
-      const uint8_t* st = smem + cur * STAGE_BYTES;
-      const int nxt = cur == STAGES - 1 ? 0 : cur + 1;
-      const int nxt2 = nxt == STAGES - 1 ? 0 : nxt + 1;
-      const uint8_t* sn = smem + nxt * STAGE_BYTES;
+    // Stage-dependent addresses are loop constants: the loop is unrolled over the three stages (tile kt lives in stage kt % 3),
+    // every LDS base sits in a register and every DMA destination in an SGPR, so a K-tile carries no address arithmetic at
+    // all - each scalar or vector ALU instruction in this loop takes an MFMA issue gap.  Run-time stage bookkeeping was 21 of
+    // the 247 instructions per tile and wave: (1024,8192,4096) as 512 paired 128-tiles 68 -> 59 us, 4096^3 101 -> 100 us.
+    const uint8_t* xb[STAGES][2];
+    const uint8_t* wb[STAGES];
+    uint32_t mdst[STAGES][NPIECES];
+  #pragma unroll
+    for (int t = 0; t < STAGES; ++t) {
+      xb[t][0] = smem + t * STAGE_BYTES + aoff[0];
+      xb[t][1] = smem + t * STAGE_BYTES + aoff[1];
+      wb[t] = smem + t * STAGE_BYTES + boff;
+  #pragma unroll
+      for (int p = 0; p < NPIECES; ++p)
+        mdst[t][p] = __builtin_amdgcn_readfirstlane(lds_base + t * STAGE_BYTES +
+                                                    (p < APIECES ? (p * NWAVES + wave) * 1024 : A_BYTES + ((p - APIECES) * NWAVES + wave) * 1024));
+    }
+    auto tile = [&](auto p_tag, int kt, auto dma_tag, auto barrier_tag) {
+      constexpr int P = decltype(p_tag)::value, PN = (P + 1) % STAGES, PF = (P + 2) % STAGES;
+      const bool DMA = dma_tag, BARRIER = barrier_tag;  // integral_constants in the steady state, run-time flags in the tail
+      auto rx = [&](int stage, int i, int kk) -> V8 { return *reinterpret_cast<const V8*>(xb[stage][kk] + i * 2048); };
   #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         const int kk = s / MI, i = s % MI;
@@ -423,16 +437,24 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
           }
           if (j == (ND < NJ ? ND : 0)) {
             // activation fragment of step s+2 (the first two of the next tile at the end; garbage, unused, on the last tile)
-            xf[(s + 2) & 3] = s + 2 < STEPS ? read_x(st, (s + 2) % MI, (s + 2) / MI) : read_x(sn, s + 2 - STEPS, 0);
+            xf[(s + 2) & 3] = s + 2 < STEPS ? rx(P, (s + 2) % MI, (s + 2) / MI) : rx(PN, s + 2 - STEPS, 0);
           }
           if (j == (ND + 1 < NJ ? ND + 1 : NJ - 1)) {
             // next tile's raw weight bytes: fragment f is dead once the last dword of its k-half 1 is converted, i.e. after
             // phase-0 step (4f+3)/ND; it is reloaded in the following step (phase-1 step 0 for the last fragment)
   #pragma unroll
             for (int f = 0; f < NJ; ++f)
-              if (s == (4 * f + 3) / ND + 1) raw[f] = read_raw(sn, f);
+              if (s == (4 * f + 3) / ND + 1) raw[f] = *reinterpret_cast<const uint4*>(wb[PN] + f * 1024);
           }
-          if (DMA && j >= NJ - PPS && s < DSTEPS) issue_piece(kt + 2, nxt2, PPS * s + (j - (NJ - PPS)));
+          if (j >= NJ - PPS && s < DSTEPS) {
+            if (DMA) {
+              const int piece = PPS * s + (j - (NJ - PPS));
+              if (piece < APIECES)
+                glds16(xbase + (size_t)(kt + 2) * (BK * 2), asrc[piece], mdst[PF][piece]);
+              else
+                glds16(a.w + (size_t)(kt + 2) * BK, wsrc[piece - APIECES], mdst[PF][piece]);
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -445,18 +467,29 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
         // three-step activation prefetch distance (cfg4 95 -> 119 us, 4096^3 unchanged); touching the lines of tile kt+4 with one
         // un-waited 4-byte load per lane so that the DMA hits in L2 (4096^3 127 -> 136 us); the two waves of a SIMD issuing
         // their DMA share in different phases of the tile (4096^3 102 -> 112 us; even the wave-uniform branch that selected
-        // the phase, not taken, cost 5 us: every scalar instruction in this loop sits in an MFMA issue gap).
+        // the phase, not taken, cost 5 us).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
-      cur = nxt;
     };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    static_assert(STAGES == 3, "the loop below is unrolled over three stages");
     QH_LT_STAMP(3);
     int kt = 0;
-    for (; kt + 2 < nk; ++kt) tile(kt, yes{}, yes{});
-    tile(kt, no{}, yes{});  // nk >= 2: tiles nk-2 and nk-1 have nothing left to prefetch
-    tile(kt + 1, no{}, no{});
+    for (; kt + 4 < nk; kt += 3) {  // three tiles that all still have a tile kt+2 to fetch
+      tile(S0{}, kt, yes{}, yes{});
+      tile(S1{}, kt + 1, yes{}, yes{});
+      tile(S2{}, kt + 2, yes{}, yes{});
+    }
+    // tail: 2..4 tiles (nk >= 2), kt % 3 == 0; the last two have nothing left to prefetch, the last one no barrier
+    const int rem = nk - kt;
+    tile(S0{}, kt, rem > 2, true);
+    tile(S1{}, kt + 1, rem > 3, rem > 2);
+    if (rem > 2) tile(S2{}, kt + 2, false, rem > 3);
+    if (rem > 3) tile(S0{}, kt + 3, false, false);
   }
   QH_LT_STAMP(4);
 

@@ -28,15 +28,14 @@ constexpr int STAGES = 4;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
+// M0 is written and not restored (see qmm_mfma_large.hip: nothing else in these kernels reads it, and every scalar
+// instruction in the K loop takes an MFMA issue gap).
 __device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  uint32_t keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
+      "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
+      "global_load_lds_dwordx4 %0, %1"
+      :
       : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");
 }
@@ -111,7 +110,20 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
     wdst[j] = A_BYTES + (j * NWAVES + wave) * 1024;
   }
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
-  auto issue = [&](int kt, int stage) {
+  // DMA destinations of the four pieces (2 activation + 2 weight) in each stage: loop constants, kept in SGPRs
+  uint32_t mdst[STAGES][4];
+#pragma unroll
+  for (int t = 0; t < STAGES; ++t)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      mdst[t][p] = __builtin_amdgcn_readfirstlane(lds_base + t * STAGE_BYTES + (p < 2 ? adst[p] : wdst[p - 2]));
+  auto issue_piece_to = [&](int kt, const uint32_t (&dst)[4], int piece) {
+    if (piece < 2)
+      glds16(a.a + (size_t)kt * BK, asrc[piece], dst[piece]);
+    else
+      glds16(a.w + (size_t)kt * BK, wsrc[piece - 2], dst[piece]);
+  };
+  auto issue = [&](int kt, int stage) {  // prologue only (run-time stage)
     const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
 #pragma unroll
     for (int j = 0; j < 2; ++j) glds16(a.a + (size_t)kt * BK, asrc[j], st + adst[j]);
@@ -124,6 +136,14 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
   const int ra = wm * 128 + (lane & 15), rw = wn * (NJ * 16) + (lane & 15);
   const int aoff0 = ra * 64 + (((lane >> 4) ^ swz64(ra)) << 4);
   const int boff0 = A_BYTES + rw * 64 + (((lane >> 4) ^ swz64(rw)) << 4);
+  // The K loops are unrolled over the four stages (tile kt lives in stage kt & 3): fragment bases per stage are loop
+  // constants in registers, a K-tile carries no address arithmetic (run-time stage bookkeeping was ~40 of the ~190
+  // instructions per two tiles and wave)
+  // (two base registers per operand: the 16-bit offset field of ds_read reaches stage t from the base of stage t & ~1)
+  const uint8_t* xb2[2] = {smem + aoff0, smem + 2 * STAGE_BYTES + aoff0};
+  const uint8_t* wb2[2] = {smem + boff0, smem + 2 * STAGE_BYTES + boff0};
+  auto xbs = [&](int t) -> const uint8_t* { return xb2[t >> 1] + (t & 1) * STAGE_BYTES; };
+  auto wbs = [&](int t) -> const uint8_t* { return wb2[t >> 1] + (t & 1) * STAGE_BYTES; };
 
   // acc[j][i]: the weight fragment is the MFMA A operand (rows = output features), the activation fragment the B operand
   AV acc[NJ][8];
@@ -141,13 +161,6 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
   uint4 xf[8], wq[2][NJ];
   auto read_x = [&](const uint8_t* st, int i) -> uint4 { return *reinterpret_cast<const uint4*>(st + aoff0 + i * 1024); };
   auto read_w = [&](const uint8_t* st, int j) -> uint4 { return *reinterpret_cast<const uint4*>(st + boff0 + j * 1024); };
-  auto issue_piece = [&](int kt, int stage, int piece) {
-    const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
-    if (piece < 2)
-      glds16(a.a + (size_t)kt * BK, asrc[piece], st + adst[piece]);
-    else
-      glds16(a.w + (size_t)kt * BK, wsrc[piece - 2], st + wdst[piece - 2]);
-  };
   auto mma = [&](AV& c, const uint4& w, const uint4& x) {
     if constexpr (KIND == K_I8) {
       c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, w), __builtin_bit_cast(i32x4, x), c, 0, 0, 0);
@@ -208,6 +221,8 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
     for (int j = 0; j < NJ; ++j) load_pair(W[j], smem, smem + STAGE_BYTES, boff0 + j * 1024);
 #pragma unroll
     for (int i = 0; i < 4; ++i) load_pair(X[i], smem, smem + STAGE_BYTES, aoff0 + i * 1024);
+    // (this loop keeps run-time stage pointers: unrolled over the pair parity it spills - 8-register operand tuples - and a
+    // pair of 32 K = 128 MFMAs amortises the bookkeeping)
     for (int p = 0; p < np; ++p) {
       const uint8_t* c0 = smem + ((2 * p) & 3) * STAGE_BYTES;
       const uint8_t* c1 = smem + ((2 * p + 1) & 3) * STAGE_BYTES;
@@ -263,23 +278,22 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
 
     // tile kt (stage kt & 3): refill the stage of tile kt-1 with tile kt+3, prefetch from the stage of tile kt+1, and before
     // the closing barrier wait for the own DMA share of tile kt+2 (tile kt+3 may stay in flight)
-    auto tile = [&](int kt, auto parity_tag, bool dma, int wait_mode /* 2: vmcnt(4), 1: vmcnt(0), 0: none */, bool barrier) {
-      constexpr int P = decltype(parity_tag)::value;
-      const uint8_t* sn = smem + ((kt + 1) & 3) * STAGE_BYTES;
+    auto tile = [&](int kt, auto stage_tag, bool dma, int wait_mode /* 2: vmcnt(4), 1: vmcnt(0), 0: none */, bool barrier) {
+      constexpr int ST = decltype(stage_tag)::value, P = ST & 1, SN = (ST + 1) & 3, SF = (ST + 3) & 3;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           mma(acc[j][i], wq[P][j], xf[i]);
           if (j == 1 % NJ) {
-            if (i < NJ) wq[P ^ 1][i] = read_w(sn, i);
+            if (i < NJ) wq[P ^ 1][i] = *reinterpret_cast<const uint4*>(wbs(SN) + i * 1024);
           }
           if (j == 2 % NJ) {
 #if QH_N8_ABLATE != 1
-            if (i >= 4 && dma) issue_piece(kt + 3, (kt + 3) & 3, i - 4);
+            if (i >= 4 && dma) issue_piece_to(kt + 3, mdst[SF], i - 4);
 #endif
           }
-          if (j == NJ - 1) xf[i] = read_x(sn, i);  // same fragment of the next tile
+          if (j == NJ - 1) xf[i] = *reinterpret_cast<const uint4*>(xbs(SN) + i * 1024);  // same fragment of the next tile
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -292,21 +306,27 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
         asm volatile("" ::: "memory");
       }
     };
-    using even = std::integral_constant<int, 0>;
-    using odd = std::integral_constant<int, 1>;
+    using st0 = std::integral_constant<int, 0>;
+    using st1 = std::integral_constant<int, 1>;
+    using st2 = std::integral_constant<int, 2>;
+    using st3 = std::integral_constant<int, 3>;
     int kt = 0;
-    for (; kt + 4 < nk; kt += 2) {  // steady state: tiles kt+3 and kt+4 exist
-      tile(kt, even{}, true, 2, true);
-      tile(kt + 1, odd{}, true, 2, true);
+    for (; kt + 6 < nk; kt += 4) {  // steady state: every one of the four tiles still has a tile kt+3 to fetch
+      tile(kt, st0{}, true, 2, true);
+      tile(kt + 1, st1{}, true, 2, true);
+      tile(kt + 2, st2{}, true, 2, true);
+      tile(kt + 3, st3{}, true, 2, true);
     }
-    // at most four tiles left (kt is even): nothing, or less, to prefetch - straight-line so the parity stays static
-#define QH_TAIL_TILE(J, PARITY)                                                                                          \
+    // at most six tiles left (kt is a multiple of 4): nothing, or less, to prefetch - straight-line so the stage stays static
+#define QH_TAIL_TILE(J, STAGE)                                                                                           \
     if (kt + (J) < nk)                                                                                                     \
-      tile(kt + (J), PARITY{}, kt + (J) + 3 < nk, kt + (J) + 3 < nk ? 2 : (kt + (J) + 2 < nk ? 1 : 0), kt + (J) + 1 < nk)
-    QH_TAIL_TILE(0, even);
-    QH_TAIL_TILE(1, odd);
-    QH_TAIL_TILE(2, even);
-    QH_TAIL_TILE(3, odd);
+      tile(kt + (J), STAGE{}, kt + (J) + 3 < nk, kt + (J) + 3 < nk ? 2 : (kt + (J) + 2 < nk ? 1 : 0), kt + (J) + 1 < nk)
+    QH_TAIL_TILE(0, st0);
+    QH_TAIL_TILE(1, st1);
+    QH_TAIL_TILE(2, st2);
+    QH_TAIL_TILE(3, st3);
+    QH_TAIL_TILE(4, st0);
+    QH_TAIL_TILE(5, st1);
 #undef QH_TAIL_TILE
 
   }
