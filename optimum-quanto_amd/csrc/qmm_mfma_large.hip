@@ -145,7 +145,10 @@ __device__ __forceinline__ void for_each_slot(F&& f) {
 
 // Tile configurations (BM x BN workgroup tile, WM x WN waves, each wave (BM/WM) x (BN/WN)):
 //   256 x 256, 2 x 4 waves of 128 x 64  - the default for grids that fill the chip: two interleaving streams per SIMD
-//   256 x 256, 2 x 2 waves of 128 x 128 - one stream per SIMD, least LDS traffic (experiments: QUANTO_HIP_LARGE_WN=2)
+//   256 x 256, 2 x 2 waves of 128 x 128 - one stream per SIMD, least LDS traffic (experiments: QUANTO_HIP_LARGE_CFG=1)
+//   256 x 256, 1 x 8 waves of 256 x 32  - every weight fragment converted once per workgroup, twice the activation reads
+//                                         (experiments: QUANTO_HIP_LARGE_CFG=3).  All three 256-tile layouts run 4096^3
+//                                         within 2 % of each other (102 - 104 us)
 //   128 x 128, 1 x 4 waves of 128 x 32  - four times the workgroups for prefill shapes whose 256-tiles cannot fill 256 CUs
 //                                         (e.g. M = 512).  All waves side by side along the features: every converted
 //                                         weight fragment feeds 8 MFMAs (1.5 VALU ops per MFMA, as in the 256-tiles); a
@@ -374,10 +377,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
     auto read_raw = [&](const uint8_t* st, int j) -> uint4 { return *reinterpret_cast<const uint4*>(st + boff + j * 1024); };
 
     // ---- prologue: tiles 0 and 1 in flight, tile 0 visible, W0(0) converted, x(0..1, kk0) of tile 0 in registers -----------
-  #pragma unroll
+#pragma unroll
     for (int p = 0; p < NPIECES; ++p) issue_piece(0, 0, p);
     if (nk > 1) {
-  #pragma unroll
+#pragma unroll
       for (int p = 0; p < NPIECES; ++p) issue_piece(1, 1, p);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile 1 too: its weight bytes are fetched during tile 0
@@ -385,11 +388,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     QH_LT_STAMP(2);
-  #pragma unroll
+#pragma unroll
     for (int j = 0; j < NJ; ++j) raw[j] = read_raw(smem, j);
-  #pragma unroll
+#pragma unroll
     for (int j = 0; j < NJ; ++j)
-  #pragma unroll
+#pragma unroll
       for (int d = 0; d < 4; ++d) w0[j][d] = convert_pair<DT, FMT>(rawword(j, 0, d), d & 1);
     xf[0] = read_x(smem, 0, 0);
     xf[1] = read_x(smem, 1, 0);
@@ -404,12 +407,12 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
     const uint8_t* xb[STAGES][2];
     const uint8_t* wb[STAGES];
     uint32_t mdst[STAGES][NPIECES];
-  #pragma unroll
+#pragma unroll
     for (int t = 0; t < STAGES; ++t) {
       xb[t][0] = smem + t * STAGE_BYTES + aoff[0];
       xb[t][1] = smem + t * STAGE_BYTES + aoff[1];
       wb[t] = smem + t * STAGE_BYTES + boff;
-  #pragma unroll
+#pragma unroll
       for (int p = 0; p < NPIECES; ++p)
         mdst[t][p] = __builtin_amdgcn_readfirstlane(lds_base + t * STAGE_BYTES +
                                                     (p < APIECES ? (p * NWAVES + wave) * 1024 : A_BYTES + ((p - APIECES) * NWAVES + wave) * 1024));
@@ -418,10 +421,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
       constexpr int P = decltype(p_tag)::value, PN = (P + 1) % STAGES, PF = (P + 2) % STAGES;
       const bool DMA = dma_tag, BARRIER = barrier_tag;  // integral_constants in the steady state, run-time flags in the tail
       auto rx = [&](int stage, int i, int kk) -> V8 { return *reinterpret_cast<const V8*>(xb[stage][kk] + i * 2048); };
-  #pragma unroll
+#pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         const int kk = s / MI, i = s % MI;
-  #pragma unroll
+#pragma unroll
         for (int j = 0; j < NJ; ++j) {
           if (kk == 0)
             acc[j][i] = Mma<DT>::run(as_v8(w0[j]), xf[s & 3], acc[j][i]);
@@ -442,7 +445,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
           if (j == (ND + 1 < NJ ? ND + 1 : NJ - 1)) {
             // next tile's raw weight bytes: fragment f is dead once the last dword of its k-half 1 is converted, i.e. after
             // phase-0 step (4f+3)/ND; it is reloaded in the following step (phase-1 step 0 for the last fragment)
-  #pragma unroll
+#pragma unroll
             for (int f = 0; f < NJ; ++f)
               if (s == (4 * f + 3) / ND + 1) raw[f] = *reinterpret_cast<const uint4*>(wb[PN] + f * 1024);
           }
