@@ -1,2 +1,4 @@
+from .conv import *
+from .layernorm import *
 from .linear import *
 from .module import *

@@ -28,6 +28,43 @@ from .packing import PackedTensor
 __all__ = ["WeightQBytesTensor", "WeightQBitsTensor", "quantize_weight"]
 
 
+def conv2d_patches(input, kernel_size, stride, padding, dilation):
+    """im2col: NCHW ``input`` -> ([B*L, C*kh*kw] rows in the weight's (c, i, j) order, output height, output width)."""
+    pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+    (kh, kw), stride, padding, dilation = pair(kernel_size), pair(stride), pair(padding), pair(dilation)
+    b, c, h, w = input.shape
+    oh = (h + 2 * padding[0] - dilation[0] * (kh - 1) - 1) // stride[0] + 1
+    ow = (w + 2 * padding[1] - dilation[1] * (kw - 1) - 1) // stride[1] + 1
+    if kh == 1 and kw == 1 and stride == (1, 1) and padding == (0, 0):
+        a = input.permute(0, 2, 3, 1).reshape(b * h * w, c)  # pointwise convolution: no patches to gather
+    else:
+        cols = torch.nn.functional.unfold(input, (kh, kw), dilation=dilation, padding=padding, stride=stride)  # [B, K, L]
+        a = cols.transpose(1, 2).reshape(b * oh * ow, c * kh * kw)
+    return a.contiguous(), oh, ow
+
+
+def conv2d_as_gemm(input, weight, bias, stride, padding, dilation, groups, gemm):
+    """``F.conv2d`` with a quantized [N, C, kh, kw] weight as im2col + one fused GEMM on the device.
+
+    The reference has no kernel here: ``QConv2d.forward`` (nn/qconv2d.py:54-55) reaches aten::convolution with a
+    QTensor, which dequantizes the whole weight on every call (qfallback).  An axis-0 quantized convolution weight is,
+    byte for byte, the [N, K = C*kh*kw] operand of ``quanto::qbytes_mm`` / ``quanto::qbits_mm`` (per-channel scales;
+    sub-byte groups run along the flattened K), so a dense convolution is ``conv2d_patches(x)`` [B*L, K] times that
+    operand.  Returns None when the call is not eligible (grouped convolution, string padding, not a ROCm device, not
+    batched NCHW input); the caller then keeps the reference behaviour.  ``gemm(a)`` maps [B*L, K] -> [B*L, N] (+ bias).
+    """
+    if groups != 1 or isinstance(padding, str) or input.dim() != 4 or input.device.type != "cuda" or weight.dim() != 4:
+        return None
+    if type(input) is not torch.Tensor:
+        input = input.dequantize()
+    n, c, kh, kw = weight.shape
+    if input.shape[1] != c:
+        return None
+    a, oh, ow = conv2d_patches(input, (kh, kw), stride, padding, dilation)
+    y = gemm(a)  # [B*L, N]
+    return y.view(input.shape[0], oh * ow, n).permute(0, 2, 1).reshape(input.shape[0], n, oh, ow)
+
+
 # ================================================================================================
 # 8-bit weights
 # ================================================================================================
@@ -130,6 +167,19 @@ class WeightQBytesTensor(QBytesTensor):
                 return WeightQBytesLinearFunction.apply(input, other, bias)
 
             return qlinear(*args, **kwargs)
+        if func is torch.nn.functional.conv2d:
+            def qconv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+                if not isinstance(weight, WeightQBytesTensor) or weight.axis not in (0, None):
+                    return None
+                n = weight.shape[0]
+                scale = weight._scale.reshape(-1, 1).expand(n, 1).contiguous()  # per-channel [N,1,1,1] or per-tensor
+                data = weight._data.reshape(n, -1)
+                return conv2d_as_gemm(input, weight, bias, stride, padding, dilation, groups,
+                                      lambda a: torch.ops.quanto.qbytes_mm_bias(a, data, scale, bias))
+
+            out = qconv2d(*args, **kwargs)
+            if out is not None:
+                return out
         if func is torch.equal:
             a, b = args
             return a.equal(b)
@@ -283,6 +333,19 @@ class WeightQBitsTensor(QBitsTensor):
                 return QuantizedLinearFunction.apply(input, other, bias)
 
             return qlinear(*args, **kwargs)
+        if func is torch.nn.functional.conv2d:
+            def qconv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+                if not (isinstance(weight, WeightQBitsTensor) and weight.axis == 0 and isinstance(weight._data, PackedTensor)
+                        and not weight.qtype.is_floating_point):
+                    return None
+                n, k = weight.shape[0], weight.numel() // weight.shape[0]
+                return conv2d_as_gemm(input, weight, bias, stride, padding, dilation, groups,
+                                      lambda a: torch.ops.quanto.qbits_mm(a, weight._data._data, weight._scale, weight._shift, bias,
+                                                                          weight._data.bits, weight._group_size, n, k))
+
+            out = qconv2d(*args, **kwargs)
+            if out is not None:
+                return out
         if func is torch.equal:
             a, b = args
             return a.equal(b)

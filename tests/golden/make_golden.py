@@ -252,6 +252,38 @@ def main():
         out[key + "/y_data"] = f32(yq._data)
         out[key + "/y_scale"] = f32(yq._scale)
 
+    # ---- 7. QConv2d (nn/qconv2d.py:26-55; tests/nn/test_qconv2d.py): quantize -> freeze -> forward.  in_features = C*kh*kw:
+    # 144 -> per-channel int4 (no group size divides it), 288 -> groups of 96
+    from optimum.quanto import QConv2d
+
+    for dtname in ("fp32", "bf16"):
+        tdt = getattr(torch, DT[dtname])
+        for tag, wq in (("int8", qint8), ("int4", qint4), ("e4m3fn", qfloat8_e4m3fn)):
+            for cname, (cin, cout, ksz, stride, pad) in (("c16k3", (16, 32, 3, 1, 1)), ("c32k3s2", (32, 24, 3, 2, 0)),
+                                                          ("c64k1", (64, 48, 1, 1, 0))):
+                torch.manual_seed(77 + cin)
+                conv = torch.nn.Conv2d(cin, cout, ksz, stride=stride, padding=pad).to(tdt)
+                q = QConv2d.from_module(conv, weights=wq)
+                freeze(q)
+                gg = torch.Generator().manual_seed(78 + cout)
+                x = torch.randn((2, cin, 12, 10), generator=gg).to(tdt)
+                with torch.no_grad():
+                    y = q(x)
+                qw = q.weight.detach()
+                key = f"qconv2d/{tag}_{cname}_{dtname}"
+                out[key + "/w"] = f32(conv.weight.detach())
+                out[key + "/bias"] = f32(conv.bias.detach())
+                out[key + "/x"] = f32(x)
+                out[key + "/y"] = f32(y)
+                out[key + "/wscale"] = f32(qw._scale)
+                if wq is qint4:
+                    out[key + "/wpacked"] = f32(qw._data._data)
+                    out[key + "/wshift"] = f32(qw._shift)
+                    out[key + "/group_size"] = np.array(-1 if qw._group_size is None else qw._group_size)
+                else:
+                    out[key + "/wdata"] = f32(qw._data)
+                out[key + "/wdq"] = f32(qw.dequantize())
+
     path = os.path.join(HERE, "quanto_golden.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")

@@ -1,0 +1,162 @@
+"""QConv2d: the host mirror against the reference's golden vectors (tests/golden section 7, produced
+by the real QConv2d: quantize -> freeze -> forward), and on the GPU the im2col + fused-GEMM lowering
+(tensor/weights.py conv2d_as_gemm) against exact math on the reference's integers and against the reference's outputs with
+the tolerance the reference's own test uses (tests/nn/test_qconv2d.py: assert_similar, atol 1e-2 class)."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import optimum_quanto_amd as Q
+from optimum_quanto_amd.library.hip import quanto_hip
+from optimum_quanto_amd.tensor.weights import conv2d_patches
+
+from oracle import quanto_oracle as O
+
+from helpers import TORCH_DT, assert_close_to_exact, assert_close_with_bias, assert_similar, to_numpy, to_torch
+
+QTYPES = {"int8": "qint8", "int4": "qint4", "e4m3fn": "qfloat8_e4m3fn"}
+CONVS = {"c16k3": (16, 32, 3, 1, 1), "c32k3s2": (32, 24, 3, 2, 0), "c64k1": (64, 48, 1, 1, 0)}
+CASES = [(t, c, d) for t in QTYPES for c in CONVS for d in ("fp32", "bf16")]
+
+
+def _build(golden, tag, cname, dt, device="cpu"):
+    key = f"qconv2d/{tag}_{cname}_{dt}"
+    cin, cout, ksz, stride, pad = CONVS[cname]
+    conv = torch.nn.Conv2d(cin, cout, ksz, stride=stride, padding=pad).to(TORCH_DT[dt])
+    with torch.no_grad():
+        conv.weight.copy_(to_torch(golden[key + "/w"], dt))
+        conv.bias.copy_(to_torch(golden[key + "/bias"], dt))
+    # quantize on the CPU (bit-identical to the reference; a device computes absmax / 127 through a reciprocal and may land
+    # one ulp away), then move the frozen module: what a user does when loading a quantized checkpoint onto the GPU
+    q = Q.QConv2d.from_module(conv, weights=getattr(Q, QTYPES[tag]))
+    Q.freeze(q)
+    return key, q.to(device), to_torch(golden[key + "/x"], dt, device)
+
+
+def _check_inner_tensors(golden, key, tag, qw):
+    np.testing.assert_array_equal(to_numpy(qw._scale), golden[key + "/wscale"])
+    if tag == "int4":
+        gs = int(golden[key + "/group_size"])
+        assert qw._group_size == (None if gs < 0 else gs)
+        np.testing.assert_array_equal(to_numpy(qw._data._data), golden[key + "/wpacked"])
+        np.testing.assert_array_equal(to_numpy(qw._shift), golden[key + "/wshift"])
+    else:
+        np.testing.assert_array_equal(to_numpy(qw._data), golden[key + "/wdata"])
+    np.testing.assert_array_equal(to_numpy(qw.dequantize()), golden[key + "/wdq"])
+
+
+@pytest.mark.parametrize("shape", [(16, 32, 3, 1, 1, 1), (8, 24, 3, 2, 0, 1), (4, 8, (3, 5), (2, 1), (1, 2), (1, 2)), (16, 8, 1, 1, 0, 1),
+                                   (3, 5, 2, 3, 2, 1)])
+def test_conv2d_patches_times_flat_weight_is_conv2d(shape):
+    """im2col rows are in the weight's (c, i, j) order: patches @ W.view(N, -1).T, folded back, equals F.conv2d."""
+    cin, cout, k, s, p, d = shape
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, dilation=d).double()
+    x = torch.randn(2, cin, 13, 11, dtype=torch.float64)
+    a, oh, ow = conv2d_patches(x, conv.kernel_size, conv.stride, conv.padding, conv.dilation)
+    y = (a @ conv.weight.reshape(cout, -1).t() + conv.bias).view(2, oh * ow, cout).permute(0, 2, 1).reshape(2, cout, oh, ow)
+    torch.testing.assert_close(y, conv(x), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag,cname,dt", CASES)
+def test_qconv2d_matches_reference_golden_cpu(golden, tag, cname, dt):
+    """Quantized weight bit-identical to the reference's; CPU forward (reference behaviour: dequantize + float convolution)
+    equal to the reference's output."""
+    key, q, x = _build(golden, tag, cname, dt)
+    assert isinstance(q, Q.QConv2d) and q.frozen
+    _check_inner_tensors(golden, key, tag, q.weight)
+    with torch.no_grad():
+        y = q(x)
+    assert y.dtype == TORCH_DT[dt]
+    np.testing.assert_allclose(to_numpy(y), golden[key + "/y"], rtol=0, atol=0 if dt == "fp32" else 1e-6)
+
+
+def test_qconv2d_quantize_freeze_state_dict_roundtrip():
+    torch.manual_seed(5)
+    model = torch.nn.Sequential(torch.nn.Conv2d(16, 32, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(32, 8, 3, stride=2))
+    x = torch.randn(2, 16, 12, 12)
+    ref = model(x)
+    Q.quantize(model, weights=Q.qint4)
+    assert isinstance(model[0], Q.QConv2d) and model[0].weight_group_size is None and model[2].weight_group_size == 96
+    y_dyn = model(x)
+    Q.freeze(model)
+    y = model(x)
+    torch.testing.assert_close(y, y_dyn, rtol=0, atol=0)
+    assert (y - ref).abs().max() < 0.1 * ref.abs().max()
+    buf = io.BytesIO()
+    torch.save(model.state_dict(), buf)
+    buf.seek(0)
+    fresh = torch.nn.Sequential(torch.nn.Conv2d(16, 32, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(32, 8, 3, stride=2))
+    Q.quantize(fresh, weights=Q.qint4)
+    Q.freeze(fresh)
+    fresh.load_state_dict(torch.load(buf, weights_only=False))
+    torch.testing.assert_close(fresh(x), y, rtol=0, atol=0)
+
+
+def test_qlayernorm_only_with_quantized_activations():
+    ln = torch.nn.LayerNorm(32)
+    assert Q.QLayerNorm.from_module(ln, weights=Q.qint8) is None  # nn/qlayernorm.py:38-39
+    q = Q.QLayerNorm.from_module(ln, activations=Q.qint8)
+    assert isinstance(q, Q.QLayerNorm) and q.weight_qtype is None
+    x = torch.randn(4, 32)
+    y = q(x)
+    assert isinstance(y, Q.ActivationQBytesTensor)  # output quantized with output_scale = 1
+    torch.testing.assert_close(y.dequantize(), torch.round(ln(x)).clamp(-127, 127))
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,cname,dt", CASES)
+def test_qconv2d_fused_gemm_gpu(golden, tag, cname, dt):
+    """On the device the convolution is im2col + quanto::qbytes_mm / quanto::qbits_mm.  Gate: exact float64 convolution
+    with the reference's dequantized weight (the parity gate of the Linear kernels), and the reference's own output with
+    the reference test's similarity criterion."""
+    dev = torch.device("cuda")
+    key, q, x = _build(golden, tag, cname, dt, dev)
+    _check_inner_tensors(golden, key, tag, q.weight)
+    with torch.no_grad():
+        y = q(x)
+    kernel = quanto_hip.lib.last_kernel()
+    assert kernel in ("gemv", "skinny", "mfma", "mfma_large", "dequant_mfma", "naive"), kernel
+    assert y.is_cuda and y.dtype == TORCH_DT[dt] and tuple(y.shape) == golden[key + "/y"].shape
+    # exact math on the reference's integers: float64 convolution, product rounded, bias added, rounded again
+    cin, cout, ksz, stride, pad = CONVS[cname]
+    x64 = torch.from_numpy(golden[key + "/x"]).double()
+    a64, _, _ = conv2d_patches(x64, (ksz, ksz), stride, pad, 1)
+    a64 = a64.numpy()
+    if tag == "int4" and kernel != "dequant_mfma":
+        # the fused int4 kernels use q * scale - shift unrounded (exact math on the reference's integers and scales)
+        gs = int(golden[key + "/group_size"])
+        w64 = O.dequantize_qbits_exact(golden[key + "/wpacked"], 4, golden[key + "/wscale"], golden[key + "/wshift"], 0,
+                                       None if gs < 0 else gs, (cout, cin * ksz * ksz))
+        prod = a64 @ np.asarray(w64, np.float64).reshape(cout, -1).T
+    elif tag == "int4":
+        # the flat path multiplies by the weight rounded exactly as the reference rounds it, which is what wdq holds
+        prod = a64 @ golden[key + "/wdq"].astype(np.float64).reshape(cout, -1).T
+    else:
+        # 8-bit: exact integer / fp8 products, the per-channel scale applied to the accumulator (library/qbytes_mm.py:25-33)
+        prod = O.qbytes_mm_exact(a64, golden[key + "/wdata"].reshape(cout, -1), golden[key + "/wscale"].reshape(cout, 1),
+                                 "e4m3fn" if tag == "e4m3fn" else None)
+    bias = golden[key + "/bias"]
+    yn = to_numpy(y).transpose(0, 2, 3, 1).reshape(-1, cout)
+    if dt == "fp32":  # fp32 accumulation order is visible at fp32 output precision: the north-star 1e-3 gate (expect ~1e-6)
+        assert_close_to_exact(yn, prod + bias.astype(np.float64), dt, f"qconv2d {key} ({kernel})")
+    else:
+        assert_close_with_bias(yn, prod, bias, dt, f"qconv2d {key} ({kernel})")
+    assert_similar(torch.from_numpy(golden[key + "/y"]), y.float().cpu(), atol=1e-2 if dt == "bf16" else 1e-3)
+
+
+@pytest.mark.gpu
+def test_qconv2d_grouped_convolution_keeps_reference_behaviour_gpu():
+    """groups != 1 is not lowered to a GEMM: dequantize + float convolution on the device, as the reference does."""
+    torch.manual_seed(9)
+    conv = torch.nn.Conv2d(16, 32, 3, padding=1, groups=4).to(torch.bfloat16).cuda()
+    q = Q.QConv2d.from_module(conv, weights=Q.qint8)
+    Q.freeze(q)
+    x = torch.randn(2, 16, 9, 9, device="cuda", dtype=torch.bfloat16)
+    with torch.no_grad():
+        y = q(x)
+        want = torch.nn.functional.conv2d(x, q.weight.dequantize(), q.bias, padding=1, groups=4)
+    torch.testing.assert_close(y, want, rtol=0, atol=0)
