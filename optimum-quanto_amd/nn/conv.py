@@ -17,15 +17,19 @@ from .module import QModuleMixin, register_qmodule
 __all__ = ["QConv2d"]
 
 
+# constructor arguments that describe the convolution geometry, copied verbatim from the float module
+_GEOMETRY = ("in_channels", "out_channels", "kernel_size", "stride", "padding", "dilation", "groups", "padding_mode")
+
+
 @register_qmodule(torch.nn.Conv2d)
 class QConv2d(QModuleMixin, torch.nn.Conv2d):
     @classmethod
     def qcreate(cls, module, weights: qtype, activations: Optional[qtype] = None, optimizer: Optional[Optimizer] = None,
                 device: Optional[torch.device] = None):
-        return cls(in_channels=module.in_channels, out_channels=module.out_channels, kernel_size=module.kernel_size,
-                   stride=module.stride, padding=module.padding, dilation=module.dilation, groups=module.groups,
-                   bias=module.bias is not None, padding_mode=module.padding_mode, dtype=module.weight.dtype, device=device,
-                   weights=weights, activations=activations, optimizer=optimizer)
+        geometry = {name: getattr(module, name) for name in _GEOMETRY}
+        return cls(**geometry, bias=module.bias is not None, dtype=module.weight.dtype, device=device, weights=weights,
+                   activations=activations, optimizer=optimizer)
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
+        # F.conv2d is intercepted by the weight's __torch_function__ (im2col + fused GEMM on a ROCm device)
         return self._conv_forward(input, self.qweight, self.bias)

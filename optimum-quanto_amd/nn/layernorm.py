@@ -16,10 +16,11 @@ class QLayerNorm(QModuleMixin, torch.nn.LayerNorm):
     def qcreate(cls, module, weights: Optional[qtype] = None, activations: Optional[qtype] = None,
                 optimizer: Optional[Optimizer] = None, device: Optional[torch.device] = None):
         if activations is None:
-            return None
-        dtype = None if module.weight is None else module.weight.dtype
-        return cls(module.normalized_shape, module.eps, module.elementwise_affine, module.bias is not None, dtype=dtype,
-                   device=device, weights=None, activations=activations, optimizer=None)
+            return None  # nothing to do: the normalisation weights are never quantized, only the outputs are
+        affine = module.elementwise_affine
+        return cls(module.normalized_shape, eps=module.eps, elementwise_affine=affine, bias=module.bias is not None,
+                   dtype=module.weight.dtype if affine else None, device=device, weights=None, activations=activations,
+                   optimizer=None)
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         return torch.nn.functional.layer_norm(input, self.normalized_shape, self.weight, self.bias, self.eps)
