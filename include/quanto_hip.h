@@ -183,6 +183,15 @@ int quanto_hip_quantize_affine(const void* base, const void* scale, const void* 
                                int bits, int group_size, int dtype, int shift_dtype, void* stream);
 
 /*
+ * quantize_affine + pack_weights fused: what freezing an int4 / int2 weight does (library/quantize.py:66-78 followed by
+ * tensor/packed.py:24-69, i.e. nn/qmodule.py:301-304 -> WeightQBitsTensor.__init__ -> PackedTensor.pack), in one pass.
+ * Arguments as quanto_hip_quantize_affine; packed: uint8[ceil(R / (8/bits)), C] with R = N*K/C grouped rows - the
+ * PackedTensor._data of the frozen weight, bit-identical to quanto_hip_pack(quanto_hip_quantize_affine(...)).
+ */
+int quanto_hip_quantize_affine_packed(const void* base, const void* scale, const void* shift, uint8_t* packed, int64_t N, int64_t K,
+                                      int bits, int group_size, int dtype, int shift_dtype, void* stream);
+
+/*
  * pack_weights (tensor/packed.py:24-69): packed[r, c] = OR_i unpacked[r + i*row_dim, c] << (bits*i), row_dim = ceil(rows / (8/bits)).
  * unpacked: uint8[rows, cols]; packed: uint8[row_dim, cols].  Inverse of quanto_hip_unpack (+ the trailing-row trim).
  */

@@ -26,6 +26,7 @@ int qbytes_mm_mfma_large(const void*, const void*, const void*, const void*, voi
 size_t qbytes_mfma_large_workspace(int64_t, int64_t, int64_t);
 int quantize_symmetric(const void*, const void*, void*, int64_t, int64_t, int, int, int, hipStream_t);
 int quantize_affine(const void*, const void*, const void*, void*, int64_t, int64_t, int, int, bool, hipStream_t);
+int quantize_affine_packed(const void*, const void*, const void*, void*, int64_t, int64_t, int, int, bool, hipStream_t);
 int pack_weights(const uint8_t*, uint8_t*, int64_t, int64_t, int, hipStream_t);
 bool qbytes_skinny_supported(int64_t, int64_t, int64_t, int, int, int);
 size_t qbytes_skinny_workspace(int64_t, int64_t, int64_t);
@@ -307,6 +308,16 @@ int quanto_hip_quantize_affine(const void* base, const void* scale, const void* 
   if (!base || !scale || !shift || !out) return QUANTO_HIP_EINVAL;
   const int64_t C = group_size > 0 ? group_size : K;
   return quantize_affine(base, scale, shift, out, N * K, C, bits, dtype, int_shift, reinterpret_cast<hipStream_t>(stream));
+}
+
+int quanto_hip_quantize_affine_packed(const void* base, const void* scale, const void* shift, uint8_t* packed, int64_t N, int64_t K,
+                                      int bits, int group_size, int dtype, int shift_dtype, void* stream) {
+  bool int_shift = false;
+  const int st = check_qbits(1, N, K, bits, group_size, dtype, shift_dtype, &int_shift);
+  if (st != QUANTO_HIP_OK) return st;
+  if (!base || !scale || !shift || !packed) return QUANTO_HIP_EINVAL;
+  const int64_t C = group_size > 0 ? group_size : K;
+  return quantize_affine_packed(base, scale, shift, packed, N * K / C, C, bits, dtype, int_shift, reinterpret_cast<hipStream_t>(stream));
 }
 
 int quanto_hip_pack(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int64_t cols, int bits, void* stream) {

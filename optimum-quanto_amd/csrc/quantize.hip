@@ -145,11 +145,28 @@ int launch_out(const void* x, const void* s, void* out, int64_t numel, int64_t i
 // element i uses scale/shift entry i / C.  float shift: round(round_T(round_T(base + shift) / scale)); integer zero-point:
 // round(round_T(base / scale)) + zp; both clamped to [0, 2^bits - 1] - every intermediate rounded to T like the torch sequence.
 template <int IDT, bool INT_SHIFT>
+__device__ __forceinline__ uint32_t affine_code(float xv, float s, const void* __restrict__ shift, int64_t r, float qmax) {
+  using E = Elem<IDT>;
+  using T = typename E::T;
+  float q;
+  if constexpr (INT_SHIFT) {
+    const float zp = (float)(int8_t) reinterpret_cast<const uint8_t*>(shift)[r];
+    q = __builtin_rintf(E::to_f32(E::from_f32(xv / s))) + zp;
+    q = E::to_f32(E::from_f32(q));
+  } else {
+    const float z = E::to_f32(reinterpret_cast<const T*>(shift)[r]);
+    float t = E::to_f32(E::from_f32(xv + z));
+    q = __builtin_rintf(E::to_f32(E::from_f32(t / s)));
+  }
+  q = __builtin_fminf(__builtin_fmaxf(q, 0.f), qmax);
+  return (uint32_t)(int)q & 0xFFu;
+}
+
+template <int IDT, bool INT_SHIFT>
 __global__ void __launch_bounds__(256) quantize_affine_kernel(const typename Elem<IDT>::T* __restrict__ x,
                                                               const typename Elem<IDT>::T* __restrict__ scale, const void* __restrict__ shift,
                                                               uint8_t* __restrict__ out, int64_t numel, int64_t C, float qmax) {
   using E = Elem<IDT>;
-  using T = typename E::T;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
   for (int64_t i0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i0 < numel; i0 += stride) {
     uint32_t word = 0;
@@ -158,19 +175,7 @@ __global__ void __launch_bounds__(256) quantize_affine_kernel(const typename Ele
       const int64_t i = i0 + k;
       if (i < numel) {
         const int64_t r = i / C;
-        const float s = E::to_f32(scale[r]);
-        float q;
-        if constexpr (INT_SHIFT) {
-          const float zp = (float)(int8_t) reinterpret_cast<const uint8_t*>(shift)[r];
-          q = __builtin_rintf(E::to_f32(E::from_f32(E::to_f32(x[i]) / s))) + zp;
-          q = E::to_f32(E::from_f32(q));
-        } else {
-          const float z = E::to_f32(reinterpret_cast<const T*>(shift)[r]);
-          float t = E::to_f32(E::from_f32(E::to_f32(x[i]) + z));
-          q = __builtin_rintf(E::to_f32(E::from_f32(t / s)));
-        }
-        q = __builtin_fminf(__builtin_fmaxf(q, 0.f), qmax);
-        word |= ((uint32_t)(int)q & 0xFFu) << (8 * k);
+        word |= affine_code<IDT, INT_SHIFT>(E::to_f32(x[i]), E::to_f32(scale[r]), shift, r, qmax) << (8 * k);
       }
     }
     if (i0 + 3 < numel && (reinterpret_cast<uintptr_t>(out + i0) & 3) == 0) {
@@ -178,6 +183,29 @@ __global__ void __launch_bounds__(256) quantize_affine_kernel(const typename Ele
     } else {
       for (int k = 0; k < 4 && i0 + k < numel; ++k) out[i0 + k] = (uint8_t)(word >> (8 * k));
     }
+  }
+}
+
+// ---- quantize_affine + pack_weights in one pass (what freeze() does to an int4 / int2 weight: library/quantize.py:66-78, then
+// tensor/packed.py:24-69).  The grouped matrix is [rows, C] with one scale/shift per row, so packed byte (r, c) holds the codes
+// of elements (r + k*row_dim, c), k = 0 .. 8/bits - 1: each thread quantizes those 2 or 4 elements and writes one byte; the
+// one-code-per-byte intermediate (2 x the packed size written, then re-read) never exists.
+template <int IDT, bool INT_SHIFT>
+__global__ void __launch_bounds__(256) quantize_affine_pack_kernel(const typename Elem<IDT>::T* __restrict__ x,
+                                                                   const typename Elem<IDT>::T* __restrict__ scale,
+                                                                   const void* __restrict__ shift, uint8_t* __restrict__ out, int64_t rows,
+                                                                   int64_t C, int64_t row_dim, int bits, float qmax) {
+  using E = Elem<IDT>;
+  const int64_t total = row_dim * C;
+  const int vpi = 8 / bits;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / C, c = i - r * C;
+    uint32_t v = 0;
+    for (int k = 0; k < vpi; ++k) {
+      const int64_t rr = r + k * row_dim;
+      if (rr < rows) v |= affine_code<IDT, INT_SHIFT>(E::to_f32(x[rr * C + c]), E::to_f32(scale[rr]), shift, rr, qmax) << (bits * k);
+    }
+    out[i] = (uint8_t)v;
   }
 }
 
@@ -231,6 +259,32 @@ int quantize_affine(const void* x, const void* scale, const void* shift, void* o
     default: return QUANTO_HIP_ENOTSUP;
   }
 #undef QH_QA
+  return launch_status();
+}
+
+int quantize_affine_packed(const void* x, const void* scale, const void* shift, void* out, int64_t rows, int64_t C, int bits, int dtype,
+                           bool int_shift, hipStream_t stream) {
+  const int vpi = 8 / bits;
+  const int64_t row_dim = (rows + vpi - 1) / vpi;
+  int64_t blocks = (row_dim * C + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  const float qmax = (float)((1 << bits) - 1);
+  uint8_t* op = reinterpret_cast<uint8_t*>(out);
+#define QH_QAP(DT)                                                                                                              \
+  if (int_shift)                                                                                                                \
+    hipLaunchKernelGGL((quantize_affine_pack_kernel<DT, true>), dim3(blocks), dim3(256), 0, stream,                             \
+                       reinterpret_cast<const Elem<DT>::T*>(x), reinterpret_cast<const Elem<DT>::T*>(scale), shift, op, rows, C, row_dim, bits, qmax); \
+  else                                                                                                                          \
+    hipLaunchKernelGGL((quantize_affine_pack_kernel<DT, false>), dim3(blocks), dim3(256), 0, stream,                            \
+                       reinterpret_cast<const Elem<DT>::T*>(x), reinterpret_cast<const Elem<DT>::T*>(scale), shift, op, rows, C, row_dim, bits, qmax)
+  switch (dtype) {
+    case QUANTO_HIP_F32: QH_QAP(QUANTO_HIP_F32); break;
+    case QUANTO_HIP_F16: QH_QAP(QUANTO_HIP_F16); break;
+    case QUANTO_HIP_BF16: QH_QAP(QUANTO_HIP_BF16); break;
+    default: return QUANTO_HIP_ENOTSUP;
+  }
+#undef QH_QAP
   return launch_status();
 }
 

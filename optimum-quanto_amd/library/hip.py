@@ -82,6 +82,8 @@ class _Bindings:
         c.quanto_hip_quantize_symmetric.argtypes = [vp, vp, vp, i64, i64, ci, ci, ci, vp]
         c.quanto_hip_quantize_affine.restype = ci
         c.quanto_hip_quantize_affine.argtypes = [vp, vp, vp, vp, i64, i64, ci, ci, ci, ci, vp]
+        c.quanto_hip_quantize_affine_packed.restype = ci
+        c.quanto_hip_quantize_affine_packed.argtypes = [vp, vp, vp, vp, i64, i64, ci, ci, ci, ci, vp]
         c.quanto_hip_pack.restype = ci
         c.quanto_hip_pack.argtypes = [vp, vp, i64, i64, ci, vp]
         self._c = c
@@ -153,6 +155,24 @@ class _Bindings:
             st = self._c.quanto_hip_quantize_affine(_ptr(base), _ptr(scale), _ptr(shift), _ptr(out), N, K, bits, group_size or 0,
                                                     _dt(base), _dt(shift), self._stream(base))
         self._check(st, "quantize_affine")
+        return out
+
+    def quantize_affine_packed(self, base: torch.Tensor, bits: int, group_size, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+        """quantize_affine + pack_weights in one pass: the packed bytes [ceil(R / (8/bits)), C] of the grouped matrix [R, C]."""
+        self._require_cuda(base, scale, shift)
+        N = base.shape[0]
+        K = base.numel() // N
+        base = base.contiguous()
+        scale = scale.to(base.dtype).contiguous()
+        shift = shift.contiguous() if not shift.dtype.is_floating_point else shift.to(base.dtype).contiguous()
+        C = group_size or K
+        rows = N * K // C
+        vpi = 8 // bits
+        out = torch.empty(((rows + vpi - 1) // vpi, C), dtype=torch.uint8, device=base.device)
+        with torch.cuda.device(base.device):
+            st = self._c.quanto_hip_quantize_affine_packed(_ptr(base), _ptr(scale), _ptr(shift), _ptr(out), N, K, bits,
+                                                           group_size or 0, _dt(base), _dt(shift), self._stream(base))
+        self._check(st, "quantize_affine_packed")
         return out
 
     def pack(self, t: torch.Tensor, bits: int) -> torch.Tensor:

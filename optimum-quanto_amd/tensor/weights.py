@@ -219,6 +219,28 @@ class WeightQBytesTensor(QBytesTensor):
 # ================================================================================================
 # sub-byte weights
 # ================================================================================================
+def _quantize_affine_packed(base, bits, axis, group_size, scale, shift):
+    """Device weights in the hot-path layout (axis 0, one scale / shift per group): quantize and pack in ONE kernel
+    (csrc/quantize.hip::quantize_affine_pack_kernel) and wrap the bytes as the PackedTensor the two-step path would have
+    produced (library/quantize.py:66-78 + tensor/packed.py:24-69).  None when not eligible."""
+    if not (base.is_cuda and axis == 0 and base.ndim >= 2 and base.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+        return None
+    n, k = base.shape[0], base.numel() // base.shape[0]
+    if group_size is not None and k % group_size != 0:
+        return None
+    rows = n * k // (group_size or k)
+    if scale.numel() != rows or shift.numel() != rows or shift.dtype not in (base.dtype, torch.uint8, torch.int8):
+        return None
+    from ..library.hip import quanto_hip  # raises if the HIP library is missing: no silent fallback for device tensors
+
+    packed = quanto_hip.lib.quantize_affine_packed(base, bits, group_size, scale, shift)
+    size = torch.Size(grouped_shape(base.shape, axis, group_size)) if group_size is not None else base.size()
+    if group_size is None:
+        packed = packed.reshape((packed.shape[0],) + tuple(base.shape[1:]))
+    stride = torch.empty(size, device="meta").stride()
+    return PackedTensor(packed, bits, size, stride)
+
+
 class _QuantizeBitsWeight(Function):
     @staticmethod
     def forward(ctx, base, qtype, axis, group_size, scale, shift, optimized):
@@ -226,8 +248,10 @@ class _QuantizeBitsWeight(Function):
             raise ValueError("WeightQBitsTensor can only be of qint2 or qint4 qtype")
         if axis not in (0, -1):
             raise ValueError("WeightQBitsTensor axis parameter must be 0 (first axis) or -1 (last axis)")
-        data = torch.ops.quanto.quantize_affine(base, bits=qtype.bits, axis=axis, group_size=group_size, scale=scale,
-                                                shift=shift)
+        data = _quantize_affine_packed(base, qtype.bits, axis, group_size, scale, shift)
+        if data is None:
+            data = torch.ops.quanto.quantize_affine(base, bits=qtype.bits, axis=axis, group_size=group_size, scale=scale,
+                                                    shift=shift)
         make = WeightQBitsTensor.create if optimized else WeightQBitsTensor
         return make(qtype, axis, group_size, base.size(), base.stride(), data, scale, shift)
 

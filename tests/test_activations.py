@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import optimum_quanto_amd as Q
+from optimum_quanto_amd.library.hip import quanto_hip
 from oracle import quanto_oracle as O
 
 from helpers import FP8_TORCH, TORCH_DT, assert_similar, fp8_tensor, to_numpy, to_torch
@@ -321,6 +322,9 @@ def test_hip_quantize_affine_and_pack_bit_exact(N, K, gs, zeropoint, bits, dt):
     np.testing.assert_array_equal(to_numpy(packed), O.pack_weights(want, bits))
     pt = PackedTensor.pack(got, bits)
     np.testing.assert_array_equal(to_numpy(pt.unpack()), want)
+    # the one-pass kernel (quantize + pack, what quantize_weight / freeze use on the device) writes the same bytes
+    fused = quanto_hip.lib.quantize_affine_packed(to_torch(w, dt, DEV), bits, gs, to_torch(scale, dt, DEV), tshift)
+    np.testing.assert_array_equal(to_numpy(fused), O.pack_weights(want, bits))
 
 
 @pytest.mark.gpu

@@ -63,6 +63,10 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.quanto_hip_qbits_mm_workspace_size(4, 4096, 4096, 4, 128, 2, 0) == 0
     assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 4, 128, 2, 0) == 0  # GEMV needs none
     assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 3, 128, 2, 0) == -1
+    lib.quanto_hip_quantize_affine_packed.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 2 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    assert lib.quanto_hip_quantize_affine_packed(None, None, None, None, 8, 128, 3, 128, 2, 2, None) == -1   # bits
+    assert lib.quanto_hip_quantize_affine_packed(None, None, None, None, 8, 100, 4, 64, 2, 2, None) == -1   # K % group
+    assert lib.quanto_hip_quantize_affine_packed(None, None, None, None, 8, 128, 4, 128, 2, 2, None) == -1  # null pointers
     # entry points added for the "next" rows: argument validation happens before any device call
     vp, i64, ci, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
     lib.quanto_hip_quantize_symmetric.argtypes = [vp, vp, vp, i64, i64, ci, ci, ci, vp]
