@@ -302,7 +302,7 @@ def main():
             "gbps": round(nbytes * world / (elapsed / args.steps) / 1e9, 1),
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the host baseline is reported at N = 1 only
             t, cflops, cbytes, cores, sample, n = cpu_baseline(kind, M, K, N)
             cval = cflops / t / 1e12 if compute_bound else cbytes / t / 1e9
             out["cpu_baseline"] = {"value": round(cval, 5), "unit": unit, "cores": cores, "kind": "port", "sample": sample,
