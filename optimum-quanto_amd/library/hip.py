@@ -106,14 +106,16 @@ class _Bindings:
             if t is not None and not t.is_cuda:
                 raise QuantoHipError("quanto_hip kernels only accept tensors on a ROCm device")
 
-    def _zeroed_workspace(self, device: torch.device, nbytes: int) -> torch.Tensor:
-        """Per-device buffer that is zero-filled once when (re)allocated and only ever handed to kernels that restore the
-        zero words they use (stream-ordered reuse; concurrent launches on several streams of one device must not share it)."""
+    def _zeroed_workspace(self, device: torch.device, nbytes: int, stream) -> torch.Tensor:
+        """Per-(device, stream) buffer that is zero-filled once when (re)allocated and only ever handed to kernels that
+        restore the zero words they use.  Launches on one stream reuse it in stream order; launches on different streams of
+        one device may overlap, so each stream gets its own arrival counters."""
         cache = self.__dict__.setdefault("_zero_ws", {})
-        buf = cache.get(device)
+        key = (device, stream)
+        buf = cache.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.zeros((max(nbytes, 8 << 20),), dtype=torch.uint8, device=device)
-            cache[device] = buf
+            cache[key] = buf
         return buf
 
     def last_kernel(self) -> str:
@@ -241,7 +243,7 @@ class _Bindings:
             if ws_bytes == 0:
                 ws = None
             elif k == KERNEL_SKINNY:
-                ws = self._zeroed_workspace(x.device, ws_bytes)  # split-K arrival counters: zero on entry, left zero by the kernel
+                ws = self._zeroed_workspace(x.device, ws_bytes, self._stream(x).value)  # split-K arrival counters: zero on entry, left zero by the kernel
             else:
                 ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
             st = self._c.quanto_hip_qbits_mm(
@@ -275,7 +277,7 @@ class _Bindings:
             if k in (KERNEL_SKINNY, KERNEL_MFMA_LARGE):
                 ws_bytes = self._c.quanto_hip_qbytes_mm_workspace_size(M, N, K, _dt(a2), _dt(b), _dt(s), k)
                 if ws_bytes > 0:
-                    ws = self._zeroed_workspace(a.device, ws_bytes)  # split-K arrival counters: zero on entry, left zero
+                    ws = self._zeroed_workspace(a.device, ws_bytes, self._stream(a).value)  # split-K arrival counters: zero on entry, left zero
             st = self._c.quanto_hip_qbytes_mm_ws(_ptr(a2), _ptr(b), _ptr(s), _ptr(bias), _ptr(y), M, N, K, _dt(a2), _dt(b),
                                                  _dt(s), k, _ptr(ws), max(ws_bytes, 0), self._stream(a))
         self._check(st, "qbytes_mm")
