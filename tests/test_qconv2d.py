@@ -160,3 +160,23 @@ def test_qconv2d_grouped_convolution_keeps_reference_behaviour_gpu():
         y = q(x)
         want = torch.nn.functional.conv2d(x, q.weight.dequantize(), q.bias, padding=1, groups=4)
     torch.testing.assert_close(y, want, rtol=0, atol=0)
+
+
+def test_conv_model_with_quantized_activations_calibrates_and_runs():
+    """quantize(weights=qint8, activations=qint8) on a small conv net: QConv2d / QLayerNorm / QLinear are created, a
+    Calibration pass sets the activation scales (calibrate.py), the frozen model stays close to the float model."""
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(16, 4, 3), torch.nn.Flatten(),
+                                torch.nn.LayerNorm(4 * 6 * 6), torch.nn.Linear(4 * 6 * 6, 10))
+    x = torch.randn(2, 8, 8, 8)
+    ref = model(x)
+    Q.quantize(model, weights=Q.qint8, activations=Q.qint8)
+    assert [type(layer).__name__ for layer in model] == ["QConv2d", "ReLU", "QConv2d", "Flatten", "QLayerNorm", "QLinear"]
+    with torch.no_grad(), Q.Calibration():
+        model(x)
+    assert float(model[0].output_scale) != 1.0 and float(model[5].input_scale) != 1.0
+    Q.freeze(model)
+    with torch.no_grad():
+        y = model(x)
+    y = y.dequantize() if isinstance(y, Q.QTensor) else y
+    assert (y - ref).abs().max() < 0.05 * ref.abs().max()
