@@ -6,7 +6,7 @@
  * /root/reference/optimum/quanto).  The reference binds native code through pybind11 torch
  * extensions loaded by library/extensions/extension.py:12-55; this library is the torch-free
  * equivalent: plain pointers, sizes and a HIP stream, so it can be bound from ctypes (what
- * optimum-quanto_amd/library does), from a pybind11 shim, or from C++ directly.
+ * optimum_quanto_amd/library does), from a pybind11 shim, or from C++ directly.
  *
  * Conventions
  *  - All pointers are DEVICE pointers owned by the caller; the library never allocates,

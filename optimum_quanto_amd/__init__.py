@@ -1,4 +1,4 @@
-"""optimum-quanto_amd: MI355X-native backend for the optimum-quanto quantized-linear hot path.
+"""optimum_quanto_amd: MI355X-native backend for the optimum-quanto quantized-linear hot path.
 
 Public names follow ``optimum.quanto`` so that code written against the reference runs unchanged::
 

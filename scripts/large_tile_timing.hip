@@ -3,7 +3,7 @@
 #include <cstdio>
 #include <vector>
 #include <algorithm>
-#include "../optimum-quanto_amd/csrc/qmm_mfma_large.hip"
+#include "../optimum_quanto_amd/csrc/qmm_mfma_large.hip"
 namespace qh { int launch_status() { return hipGetLastError() == hipSuccess ? 0 : -3; } void set_last_kernel(const char*) {} }
 int main() {
   const int M = 4096, N = 4096;
