@@ -64,6 +64,12 @@ typedef enum {
   QUANTO_HIP_KERNEL_DEQUANT_MFMA = 7 /* qbits_mm, prefill-sized M: fused dequantize into the workspace + 256x256 dense MFMA GEMM */
 } quanto_hip_kernel;
 
+/* Split-K workspaces (SKINNY and MFMA_LARGE kernels) all share ONE layout: the first QUANTO_HIP_WS_COUNTER_BYTES bytes are
+ * arrival counters - zero on entry, restored to zero by the kernel - and the fp32 partial sums start right behind them,
+ * whatever the problem size.  A buffer whose counter region was zeroed once can therefore serve any sequence of calls on one
+ * stream; a kernel never splits a problem that needs more counters than the region holds. */
+#define QUANTO_HIP_WS_COUNTER_BYTES 4096
+
 #define QUANTO_HIP_GEMV_MAX_M 8         /* qbytes_mm: rows of x the GEMV kernel accepts                    */
 #define QUANTO_HIP_SKINNY_MAX_M 256      /* qbits_mm: rows of x the streaming MFMA kernel accepts (passes of 64) */
 #define QUANTO_HIP_GEMV_MAX_M_QBITS 64  /* qbits_mm: ditto (passes of up to 8 rows; weights re-read from MALL) */
@@ -74,6 +80,11 @@ const char* quanto_hip_status_string(int status);
 /* Name of the kernel the last successful *_mm call on this thread dispatched to
  * ("naive", "gemv", "mfma", ...).  Used by tests to assert that the intended path ran. */
 const char* quanto_hip_last_kernel(void);
+
+/* 0 when `stream` is not being captured into a hipGraph, otherwise the (positive) id of the capture sequence; negative
+ * status on error.  Lets a binding keep one zero-initialised split-K workspace per capture: memory allocated and zeroed
+ * while capturing belongs to that graph and must not be handed to eager launches (or to another capture). */
+int64_t quanto_hip_stream_capture_id(void* stream);
 
 /*
  * quanto::unpack(Tensor self, int bits) -> Tensor
@@ -122,7 +133,7 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
  * call on the same stream.  The MFMA kernel stores the per-group row sums of x there
  * (fp32 [K/group_size][roundup(M,128)]); the DEQUANT_MFMA path stores the dequantized weight (dtype[N, K]).
  * The SKINNY kernel splits K across workgroups when N alone cannot occupy the chip: its workspace starts with
- * ceil(N/16*4 / 256)*256 bytes of arrival counters that MUST BE ZERO on entry (the kernel leaves them zero), followed by
+ * QUANTO_HIP_WS_COUNTER_BYTES bytes of arrival counters that MUST BE ZERO on entry (the kernel leaves them zero), followed by
  * fp32 partial sums; without a workspace it runs unsplit.  quanto_hip_qbits_mm_pick tells which kernel AUTO selects, so
  * that a caller can hand the zero-initialised buffer to exactly those calls.
  * Returns a negative status on invalid arguments.

@@ -123,6 +123,17 @@ const char* quanto_hip_status_string(int status) {
 
 const char* quanto_hip_last_kernel(void) { return g_last_kernel; }
 
+int64_t quanto_hip_stream_capture_id(void* stream) {
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo(reinterpret_cast<hipStream_t>(stream), &status, &id) != hipSuccess) {
+    (void)hipGetLastError();
+    return QUANTO_HIP_EINVAL;
+  }
+  if (status != hipStreamCaptureStatusActive) return 0;
+  return (int64_t)(id & 0x7FFFFFFFFFFFFFFFull) + 1;  // ids start at 0 on some runtimes: keep "capturing" non-zero
+}
+
 int quanto_hip_unpack(const uint8_t* packed, uint8_t* unpacked, int64_t packed_numel, int bits, void* stream) {
   if (bits != 2 && bits != 4) return QUANTO_HIP_EINVAL;
   if (packed_numel < 0) return QUANTO_HIP_EINVAL;

@@ -374,7 +374,10 @@ static int skinny_split(const PackedGeom& g) {
   if (forced > 0 && g.G % forced == 0) s = forced;
   return s;
 }
-static size_t skinny_counter_bytes(const PackedGeom& g) { return ((size_t)(g.N / 16) * 4 + 255) / 256 * 256; }
+// The arrival counters of every split-K kernel of the library live in the same fixed-size region at the start of the
+// workspace and the partial sums always start behind it: a buffer that served one problem can serve any other without a
+// later call reading an earlier call's partial sums as counters (the partials are never reset, the counters always are).
+static size_t skinny_counter_bytes(const PackedGeom&) { return QUANTO_HIP_WS_COUNTER_BYTES; }
 
 bool qbits_skinny_supported(int64_t M, const PackedGeom& g, int dtype) {
   const int64_t Mp = M > 64 ? 64 : M;  // rows per pass

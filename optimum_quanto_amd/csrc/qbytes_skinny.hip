@@ -310,9 +310,11 @@ static int skinny8_split(int64_t N, int64_t K) {
   int s = 1;
   while (s < 8 && waves * s * 2 <= 1024 && G % (s * 2) == 0 && G / (s * 2) >= 4) s *= 2;
   if (forced > 0 && G % forced == 0) s = forced;
+  if ((size_t)((N + 63) / 64) * 4 > QUANTO_HIP_WS_COUNTER_BYTES) s = 1;  // one counter per feature block of 64
   return s;
 }
-static size_t skinny8_counter_bytes(int64_t N) { return ((size_t)((N + 63) / 64) * 4 + 255) / 256 * 256; }
+// fixed-size counter region shared by all split-K kernels of the library (see qbits_skinny.hip)
+static size_t skinny8_counter_bytes(int64_t) { return QUANTO_HIP_WS_COUNTER_BYTES; }
 
 bool qbytes_skinny_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
   const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2;

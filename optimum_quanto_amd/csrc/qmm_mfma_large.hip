@@ -665,9 +665,11 @@ static int large_split(int64_t M, int64_t N, int64_t K) {
   if (tiles128 <= 128 && K >= 10240 && (K / lt::BK) % 2 == 0) s = 2;
   if (forced > 0 && tiles128 <= 512 && (K / lt::BK) % forced == 0 && K / lt::BK / forced >= 2) s = forced;
   (void)tiles256;
+  if ((size_t)tiles128 * 4 > QUANTO_HIP_WS_COUNTER_BYTES) s = 1;  // one counter per 128-tile
   return s;
 }
-static size_t large_counter_bytes(int64_t M, int64_t N) { return ((size_t)(((M + 127) / 128) * ((N + 127) / 128)) * 4 + 255) / 256 * 256; }
+// fixed-size counter region shared by all split-K kernels of the library (see qbits_skinny.hip)
+static size_t large_counter_bytes(int64_t, int64_t) { return QUANTO_HIP_WS_COUNTER_BYTES; }
 size_t qbytes_mfma_large_workspace(int64_t M, int64_t N, int64_t K) {
   const int S = large_split(M, N, K);
   if (S == 1) return 0;

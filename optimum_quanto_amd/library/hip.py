@@ -60,6 +60,8 @@ class _Bindings:
         c.quanto_hip_status_string.restype = ctypes.c_char_p
         c.quanto_hip_status_string.argtypes = [ci]
         c.quanto_hip_last_kernel.restype = ctypes.c_char_p
+        c.quanto_hip_stream_capture_id.restype = i64
+        c.quanto_hip_stream_capture_id.argtypes = [vp]
         c.quanto_hip_unpack.restype = ci
         c.quanto_hip_unpack.argtypes = [vp, vp, i64, ci, vp]
         c.quanto_hip_dequantize_qbits.restype = ci
@@ -107,13 +109,22 @@ class _Bindings:
                 raise QuantoHipError("quanto_hip kernels only accept tensors on a ROCm device")
 
     def _zeroed_workspace(self, device: torch.device, nbytes: int, stream) -> torch.Tensor:
-        """Per-(device, stream) buffer that is zero-filled once when (re)allocated and only ever handed to kernels that
-        restore the zero words they use.  Launches on one stream reuse it in stream order; launches on different streams of
-        one device may overlap, so each stream gets its own arrival counters."""
+        """Split-K workspace: [QUANTO_HIP_WS_COUNTER_BYTES of arrival counters | fp32 partial sums] (include/quanto_hip.h).
+        One buffer per (device, stream, capture): zero-filled once when (re)allocated and only ever handed to kernels that
+        restore the counter words they use.  Launches on one stream reuse it in stream order; launches on different streams
+        of one device may overlap, so each stream gets its own counters.  A buffer allocated while the stream is being
+        captured lives in that graph's memory pool and its zero-fill is a node of that graph (re-run on every replay): it is
+        keyed by the capture id so that neither eager launches nor another capture ever see it."""
         cache = self.__dict__.setdefault("_zero_ws", {})
-        key = (device, stream)
+        capture = self._c.quanto_hip_stream_capture_id(ctypes.c_void_p(stream))
+        if capture < 0:
+            self._check(int(capture), "stream_capture_id")
+        key = (device, stream, capture)
         buf = cache.get(key)
         if buf is None or buf.numel() < nbytes:
+            if len(cache) > 64:  # stream handles / capture ids come and go: do not keep dead buffers alive forever
+                for k in [k for k in cache if k[2] != 0 and k != key]:
+                    del cache[k]
             buf = torch.zeros((max(nbytes, 8 << 20),), dtype=torch.uint8, device=device)
             cache[key] = buf
         return buf

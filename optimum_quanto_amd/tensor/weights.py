@@ -55,6 +55,10 @@ def conv2d_as_gemm(input, weight, bias, stride, padding, dilation, groups, gemm)
     """
     if groups != 1 or isinstance(padding, str) or input.dim() != 4 or input.device.type != "cuda" or weight.dim() != 4:
         return None
+    # The fused GEMM ops are opaque to autograd (ctypes kernels, no backward registered): whenever a gradient is wanted -
+    # QAT, calibration with grad enabled, an unfrozen module - keep the reference's differentiable dequantize + convolution.
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (input, weight, bias)):
+        return None
     if type(input) is not torch.Tensor:
         input = input.dequantize()
     n, c, kh, kw = weight.shape

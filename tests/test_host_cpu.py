@@ -50,8 +50,8 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.quanto_hip_qbits_mm_workspace_size(4096, 4096, 4096, 4, 128, 2, 3) == 32 * 4096 * 4  # kernel MFMA: per-group row sums of x
     assert lib.quanto_hip_qbits_mm_workspace_size(300, 256, 4096, 4, 128, 2, 0) == 256 * 4096 * 2  # above the streaming kernel's range
     assert lib.quanto_hip_qbits_mm_workspace_size(40, 256, 512, 4, 64, 2, 0) == 8 * 128 * 4  # group size 64, small M: 128x128 kernel (row sums of x)
-    # streaming MFMA kernel, N = 4096: 256 waves -> K split 4 ways; 1 KiB of arrival counters + fp32 partials (TF = 4)
-    assert lib.quanto_hip_qbits_mm_workspace_size(64, 4096, 4096, 4, 128, 2, 0) == 1024 + 256 * 4 * 64 * 4 * 16
+    # streaming MFMA kernel, N = 4096: 256 waves -> K split 4 ways; the fixed 4 KiB counter region (QUANTO_HIP_WS_COUNTER_BYTES) + fp32 partials (TF = 4)
+    assert lib.quanto_hip_qbits_mm_workspace_size(64, 4096, 4096, 4, 128, 2, 0) == 4096 + 256 * 4 * 64 * 4 * 16
     assert lib.quanto_hip_qbits_mm_workspace_size(64, 14336, 4096, 4, 128, 2, 0) == 0  # wide enough: not split
     lib.quanto_hip_qbits_mm_pick.restype = ctypes.c_int
     lib.quanto_hip_qbits_mm_pick.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 3
@@ -86,7 +86,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     lib.quanto_hip_qbytes_mm_workspace_size.restype = i64
     lib.quanto_hip_qbytes_mm_workspace_size.argtypes = [i64] * 3 + [ci] * 4
     assert lib.quanto_hip_qbytes_mm_workspace_size(32, 14336, 4096, 2, 3, 2, 0) == 0           # wide N: not split
-    assert lib.quanto_hip_qbytes_mm_workspace_size(32, 4096, 4096, 2, 3, 2, 0) == 256 + 64 * 4 * 256 * 2 * 16  # 64 counters, split 4, TF = 2
+    assert lib.quanto_hip_qbytes_mm_workspace_size(32, 4096, 4096, 2, 3, 2, 0) == 4096 + 64 * 4 * 256 * 2 * 16  # fixed counter region, split 4, TF = 2
     assert lib.quanto_hip_qbytes_mm_workspace_size(4096, 4096, 4096, 2, 3, 2, 0) == 0          # 256-tiles: no workspace
     lib.quanto_hip_qbytes_mm_pick.argtypes = [i64] * 3 + [ci] * 3
     picks = {m: lib.quanto_hip_qbytes_mm_pick(m, 4096, 4096, 2, 3, 2) for m in (1, 8, 64, 256, 4096)}
@@ -95,7 +95,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert [lib.quanto_hip_qbytes_mm_pick(m, 1024, 4096, 2, 3, 2) for m in (96, 128)] == [5, 4]
     # split-K of the 128-tile grid only for very long K; (512, 4096, 4096) runs unsplit without workspace
     assert lib.quanto_hip_qbytes_mm_workspace_size(512, 4096, 4096, 2, 3, 2, 0) == 0
-    assert lib.quanto_hip_qbytes_mm_workspace_size(512, 4096, 14336, 2, 3, 2, 0) == 512 + 128 * 2 * 128 * 128 * 4  # 128 counters + fp32 partials
+    assert lib.quanto_hip_qbytes_mm_workspace_size(512, 4096, 14336, 2, 3, 2, 0) == 4096 + 128 * 2 * 128 * 128 * 4  # fixed counter region + fp32 partials
     assert lib.quanto_hip_qbytes_mm_pick(4096, 4096, 4096, 3, 3, 2) == 6                         # int8 activations: native8
 
 
