@@ -70,6 +70,7 @@ typedef enum {
  * stream; a kernel never splits a problem that needs more counters than the region holds. */
 #define QUANTO_HIP_WS_COUNTER_BYTES 4096
 
+#define QUANTO_HIP_MAX_MULTI 4           /* Linears per quanto_hip_qbits_mm_multi call                        */
 #define QUANTO_HIP_GEMV_MAX_M 8         /* qbytes_mm: rows of x the GEMV kernel accepts                    */
 #define QUANTO_HIP_SKINNY_MAX_M 256      /* qbits_mm: rows of x the streaming MFMA kernel accepts (passes of 64) */
 #define QUANTO_HIP_GEMV_MAX_M_QBITS 64  /* qbits_mm: ditto (passes of up to 8 rows; weights re-read from MALL) */
@@ -126,6 +127,20 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
                         const void* bias, void* y, int64_t M, int64_t N, int64_t K, int bits, int group_size,
                         int dtype, int shift_dtype, int kernel, void* workspace, size_t workspace_bytes,
                         void* stream);
+
+/*
+ * `count` (1..QUANTO_HIP_MAX_MULTI) qbits_mm products that share the same input x and the same K, bits, group size and dtypes -
+ * the q/k/v or gate/up projections of a decoder layer - in one call: y[i] = x @ dequant(W[i]).T (+ bias[i]), W[i] of N[i]
+ * output features.  The reference issues one F.linear per module (nn/qlinear.py:49-50); its CUDA GEMV analog processes one
+ * weight per launch as well (library/extensions/cuda/awq/v2/gemv_cuda.cu:220-308).  A decode-shaped (M <= 4) call is mostly
+ * launch + first-byte latency, so when every W[i] is eligible for the GEMV kernel (quanto_hip_qbits_mm_pick says GEMV) all
+ * products run in ONE kernel launch; otherwise this is exactly `count` quanto_hip_qbits_mm calls with KERNEL_AUTO and no
+ * workspace.  Results are bit-identical to the separate calls.  The pointer arrays are HOST arrays of device pointers;
+ * `bias` may be NULL or hold NULL entries.
+ */
+int quanto_hip_qbits_mm_multi(const void* x, int count, const uint8_t* const* packed, const void* const* scale,
+                              const void* const* shift, const void* const* bias, void* const* y, const int64_t* N, int64_t M,
+                              int64_t K, int bits, int group_size, int dtype, int shift_dtype, void* stream);
 
 /*
  * Scratch bytes quanto_hip_qbits_mm needs for this problem (0 when the selected kernel needs none).

@@ -17,6 +17,8 @@ int qbits_mm_naive(const void*, const uint8_t*, const void*, const void*, const 
 bool qbits_gemv_supported(int64_t, const PackedGeom&, int);
 int qbits_mm_gemv(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool,
                   hipStream_t);
+int qbits_mm_gemv_multi(const void*, int, const uint8_t* const*, const void* const*, const void* const*, const void* const*, void* const*,
+                        const int64_t*, int64_t, int64_t, int, bool, hipStream_t);
 bool qbytes_gemv_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_gemv(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 bool qbytes_mfma_supported(int64_t, int64_t, int64_t, int, int, int);
@@ -215,6 +217,32 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
       return r;
   }
   return QUANTO_HIP_EINVAL;
+}
+
+int quanto_hip_qbits_mm_multi(const void* x, int count, const uint8_t* const* packed, const void* const* scale, const void* const* shift,
+                              const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int bits, int group_size,
+                              int dtype, int shift_dtype, void* stream_) {
+  if (count < 1 || count > QUANTO_HIP_MAX_MULTI || !packed || !scale || !shift || !y || !N) return QUANTO_HIP_EINVAL;
+  bool int_shift = false, one_launch = M >= 1 && M <= 4;
+  for (int i = 0; i < count; ++i) {
+    const int st = check_qbits(M, N[i], K, bits, group_size, dtype, shift_dtype, &int_shift);
+    if (st != QUANTO_HIP_OK) return st;
+    if (M > 0 && (!x || !packed[i] || !scale[i] || !shift[i] || !y[i])) return QUANTO_HIP_EINVAL;
+    one_launch = one_launch && qbits_gemv_supported(M, make_geom(N[i], K, bits, group_size), dtype);
+  }
+  if (M == 0) return QUANTO_HIP_OK;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (one_launch) {
+    const int r = qbits_mm_gemv_multi(x, count, packed, scale, shift, bias, y, N, M, K, dtype, int_shift, stream);
+    if (r == QUANTO_HIP_OK) set_last_kernel("gemv_multi");
+    if (r != QUANTO_HIP_EALIGN) return r;  // misaligned views: the separate calls below pick a kernel that copes
+  }
+  for (int i = 0; i < count; ++i) {
+    const int r = quanto_hip_qbits_mm(x, packed[i], scale[i], shift[i], bias ? bias[i] : nullptr, y[i], M, N[i], K, bits, group_size, dtype,
+                                      shift_dtype, QUANTO_HIP_KERNEL_AUTO, nullptr, 0, stream_);
+    if (r != QUANTO_HIP_OK) return r;
+  }
+  return QUANTO_HIP_OK;
 }
 
 // qbytes_mm kernel choice (measured with bf16 x int8, hipGraph replay, N = K = 4096 unless noted):

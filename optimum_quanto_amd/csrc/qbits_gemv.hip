@@ -21,6 +21,8 @@
 // accumulator with -128*sum(x).  Per lane and group: y += scale * dot - shift * sum(x), fp32
 // throughout, so the result is the exact-math value of the reference's integers/scales (no bf16
 // rounding of W).  Wave reductions use DPP adds (no LDS traffic).
+#include <cstdlib>
+
 #include "qh_common.h"
 
 namespace qh {
@@ -75,44 +77,91 @@ __device__ __forceinline__ float quad_bcast(float v) {
 
 constexpr int RR = 4;  // packed rows per wave pass
 
-template <int DT, int MT, int ITERS, bool INT_SHIFT>
+// Several Linears that share the same input (q/k/v, gate/up of a decoder layer) in ONE launch: a decode-shaped call lasts
+// 4-8 us of which ~3 us are launch + first-byte latency, so every launch that disappears is worth about one small Linear.
+// The weights stay separate allocations (the reference's modules are untouched): the kernel gets a table of segments and
+// a block looks up which Linear it works for.
+constexpr int MAX_SEGS = QUANTO_HIP_MAX_MULTI;
+static_assert(MAX_SEGS == 4, "the segment lookup in the kernel compares against first_block[1..3]");
+struct GemvSegs {
+  const uint8_t* packed[MAX_SEGS];
+  const uint16_t* scale[MAX_SEGS];
+  const void* shift[MAX_SEGS];
+  const uint16_t* bias[MAX_SEGS];
+  uint16_t* y[MAX_SEGS];
+  int N[MAX_SEGS];
+  int first_block[MAX_SEGS];  // first workgroup of each segment (INT_MAX for unused slots)
+};
+
+// VARIANT (experiments, bf16 / M = 1 only; the product default is picked by the launcher):
+//   bit 0: request x and the scale/shift entries BEFORE the weights.  Loads return in order: with the small L2-resident
+//          loads at the tail of the queue, no row can be processed before the wave's last weight byte has landed; at the
+//          head, row r is processed while rows r+1.. are still in flight.
+//   bit 1: non-temporal weight loads (each weight byte is read exactly once per call).
+template <int DT, int MT, int ITERS, bool INT_SHIFT, int VARIANT = 0, bool MULTI = false>
 __global__ void __launch_bounds__(256)
-    qbits_gemv_g128_kernel(const uint16_t* __restrict__ x, const uint8_t* __restrict__ packed, const uint16_t* __restrict__ scale,
-                           const void* __restrict__ shift_, const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int N,
-                           int K, int wpr /* waves cooperating on one row group: 1, 2 or 4 */) {
+    qbits_gemv_g128_kernel(const uint16_t* __restrict__ x, const GemvSegs segs, int K,
+                           int wpr_log2 /* log2 of the waves cooperating on one row group: 0, 1 or 2 */) {
   using E = Elem<DT>;
   using T = typename E::T;
   using D2 = Dot2<DT>;
   __shared__ float red[4][RR][2][MT];
+  constexpr bool EARLY_X = (VARIANT & 1) != 0, NT = (VARIANT & 2) != 0;
+  constexpr bool ABLATE = (VARIANT & 4) != 0;  // measurement only (WRONG results): 1/4 of the arithmetic, all of the loads
 
+  // Prologue discipline: the call lasts a few microseconds, so nothing slow may sit in front of the first load - shifts
+  // instead of divisions, and for the plain op (MULTI = false: segment 0, known at compile time) ONE round of scalar loads
+  // for all kernel arguments.  The multi-Linear launch pays a second, dependent round for the selected segment's pointers
+  // (cheap next to the launches it replaces).
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int slab0 = wave % wpr;   // first K-slab of this wave; further slabs at stride wpr
-  const int rgroup = wave / wpr;  // which row group of the block
-  const int groups_per_block = 4 / wpr;
+  const int wpr = 1 << wpr_log2;
+  const int slab0 = wave & (wpr - 1);   // first K-slab of this wave; further slabs at stride wpr
+  const int rgroup = wave >> wpr_log2;  // which row group of the block
+  const int bid = blockIdx.x;
+  const int seg = MULTI ? (bid >= segs.first_block[1]) + (bid >= segs.first_block[2]) + (bid >= segs.first_block[3]) : 0;
+  const uint8_t* __restrict__ packed = segs.packed[seg];
+  const uint16_t* __restrict__ scale = segs.scale[seg];
+  const void* __restrict__ shift_ = segs.shift[seg];
+  const uint16_t* __restrict__ bias = segs.bias[seg];
+  uint16_t* __restrict__ y = segs.y[seg];
+  const int N = segs.N[seg];
+  const int seg_first = MULTI ? segs.first_block[seg] : 0;
   const int P = N >> 1;
   const int G = K >> 7;
-  const int p0 = (blockIdx.x * groups_per_block + rgroup) * RR;
-
+  const int p0 = (((bid - seg_first) << (2 - wpr_log2)) + rgroup) * RR;
   // ---- 1. request everything this wave will touch: weights, scales/shifts, x slice ---------------
   int k0[ITERS];
   bool valid[ITERS];
   uint4 W[RR][ITERS];
+  float sq[ITERS][2], zq[ITERS][2];
+  uint4 xa[ITERS][MT], xb[ITERS][MT];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     k0[it] = ((slab0 + it * wpr) * 64 + lane) * 16;
     valid[it] = k0[it] < K;
     k0[it] = valid[it] ? k0[it] : 0;  // out-of-range slabs read (and then ignore) the start of the row
-#pragma unroll
-    for (int r = 0; r < RR; ++r) {
-      // unconditional, clamped loads: rows beyond P are computed on duplicate data and never stored
-      const int pr = p0 + r < P ? p0 + r : P - 1;
-      W[r][it] = *reinterpret_cast<const uint4*>(packed + (size_t)pr * K + k0[it]);
-    }
   }
-  // lane l fetches the entries of row (l & 3), group of its 16 bytes, both planes
-  float sq[ITERS][2], zq[ITERS][2];
-  {
+  auto load_weights = [&]() {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+      for (int r = 0; r < RR; ++r) {
+        // unconditional, clamped loads: rows beyond P are computed on duplicate data and never stored
+        const int pr = p0 + r < P ? p0 + r : P - 1;
+        const uint4* src = reinterpret_cast<const uint4*>(packed + (size_t)pr * K + k0[it]);
+        if constexpr (NT) {
+          typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+          const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+          W[r][it] = make_uint4(v.x, v.y, v.z, v.w);
+        } else {
+          W[r][it] = *src;
+        }
+      }
+    }
+  };
+  auto load_small = [&]() {
+    // lane l fetches the entries of row (l & 3), group of its 16 bytes, both planes
     const int rq = p0 + (lane & 3) < P ? p0 + (lane & 3) : P - 1;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
@@ -126,6 +175,24 @@ __global__ void __launch_bounds__(256)
           zq[it][h] = E::to_f32(__builtin_bit_cast(T, reinterpret_cast<const uint16_t*>(shift_)[idx]));
       }
     }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const uint4* px = reinterpret_cast<const uint4*>(x + (size_t)m * K + k0[it]);
+        xa[it][m] = px[0];
+        xb[it][m] = px[1];
+      }
+    }
+  };
+  if constexpr (EARLY_X) {
+    load_small();
+    // keep the issue order: without this the scheduler is free to hoist the (independent) weight loads back to the front
+    __builtin_amdgcn_sched_barrier(0);
+    load_weights();
+  } else {
+    load_weights();
+    load_small();
   }
   uint32_t X02[ITERS][MT][4], X13[ITERS][MT][4];
   float xs[ITERS][MT];
@@ -133,8 +200,7 @@ __global__ void __launch_bounds__(256)
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const uint4* px = reinterpret_cast<const uint4*>(x + (size_t)m * K + k0[it]);
-      const uint4 a = px[0], b = px[1];
+      const uint4 a = xa[it][m], b = xb[it][m];
       const uint32_t keep = valid[it] ? 0xFFFFFFFFu : 0u;  // x = 0 beyond K: such a slab contributes exactly 0
       const uint32_t pr[8] = {a.x & keep, a.y & keep, a.z & keep, a.w & keep, b.x & keep, b.y & keep, b.z & keep, b.w & keep};
       float s = 0.f;
@@ -182,8 +248,9 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int m = 0; m < MT; ++m) dot[0][m] = dot[1][m] = -D2::OFFSET * xs[it][m];
       const uint32_t w4[4] = {W[r][it].x, W[r][it].y, W[r][it].z, W[r][it].w};
+      if constexpr (ABLATE) asm volatile("" ::"v"(w4[1]), "v"(w4[2]), "v"(w4[3]));
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
+      for (int d = 0; d < (ABLATE ? 1 : 4); ++d) {
         const uint32_t w = w4[d];
         const uint32_t lo02 = (w & kmask) | kmagic;
         const uint32_t hi02 = ((w >> 4) & kmask) | kmagic;
@@ -235,23 +302,76 @@ __global__ void __launch_bounds__(256)
 }
 
 // ------------------------------------------------------------------------------------------------
+// host side: `nseg` Linears sharing x (nseg = 1 for the plain op)
+struct GemvProblem {
+  int nseg;
+  const uint8_t* packed[MAX_SEGS];
+  const void* scale[MAX_SEGS];
+  const void* shift[MAX_SEGS];
+  const void* bias[MAX_SEGS];
+  void* y[MAX_SEGS];
+  int N[MAX_SEGS];
+};
+
+static int gemv_variant() {
+  // experiments: QUANTO_HIP_GEMV_VARIANT = bit 0 (x / scales requested first) | bit 1 (non-temporal weight loads) |
+  // bit 2 (ablation, wrong results: a quarter of the arithmetic - tells how much of a call is VALU work)
+  static const int v = [] { const char* e = getenv("QUANTO_HIP_GEMV_VARIANT"); return e ? atoi(e) & 7 : QUANTO_HIP_GEMV_DEFAULT_VARIANT; }();
+  return v;
+}
+
 template <int DT, int MT, bool INT_SHIFT>
-static int gemv_launch_iters(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y,
-                             int N, int K, hipStream_t stream) {
+static int gemv_launch_iters(const void* x, const GemvProblem& pb, int m0, int K, hipStream_t stream) {
   const int nslab = (K + 1023) / 1024;
   const int wpr = nslab >= 3 ? 4 : nslab;  // 1, 2 or 4 waves per row group
+  const int wpr_log2 = wpr == 4 ? 2 : wpr - 1;
   const int iters = (nslab + wpr - 1) / wpr;
   if (iters > 4) return QUANTO_HIP_ENOTSUP;
   const int rows_per_block = RR * (4 / wpr);
-  const int P = N / 2;
-  const int grid = (P + rows_per_block - 1) / rows_per_block;
-  auto xs = reinterpret_cast<const uint16_t*>(x);
-  auto ss = reinterpret_cast<const uint16_t*>(scale);
-  auto bs = reinterpret_cast<const uint16_t*>(bias);
-  auto ys = reinterpret_cast<uint16_t*>(y);
-#define QH_LAUNCH(IT)                                                                                                        \
-  hipLaunchKernelGGL((qbits_gemv_g128_kernel<DT, MT, IT, INT_SHIFT>), dim3(grid), dim3(256), 0, stream, xs, packed, ss, shift, bs, \
-                     ys, N, K, wpr)
+  GemvSegs segs;
+  int grid = 0;
+  for (int i = 0; i < MAX_SEGS; ++i) {
+    const int j = i < pb.nseg ? i : 0;  // unused slots repeat segment 0 and are never selected
+    segs.packed[i] = pb.packed[j];
+    segs.scale[i] = reinterpret_cast<const uint16_t*>(pb.scale[j]);
+    segs.shift[i] = pb.shift[j];
+    segs.bias[i] = reinterpret_cast<const uint16_t*>(pb.bias[j]);
+    segs.y[i] = reinterpret_cast<uint16_t*>(pb.y[j]) + (size_t)m0 * pb.N[j];
+    segs.N[i] = pb.N[j];
+    segs.first_block[i] = i < pb.nseg ? grid : 0x7FFFFFFF;
+    if (i < pb.nseg) grid += (pb.N[i] / 2 + rows_per_block - 1) / rows_per_block;
+  }
+  auto xs = reinterpret_cast<const uint16_t*>(x) + (size_t)m0 * K;
+#define QH_LAUNCH_VM(IT, V, MULTI) \
+  hipLaunchKernelGGL((qbits_gemv_g128_kernel<DT, MT, IT, INT_SHIFT, V, MULTI>), dim3(grid), dim3(256), 0, stream, xs, segs, K, wpr_log2)
+#define QH_LAUNCH_V(IT, V)                    \
+  do {                                        \
+    if constexpr (MT <= 4) {                  \
+      if (pb.nseg > 1)                        \
+        QH_LAUNCH_VM(IT, V, true);            \
+      else                                    \
+        QH_LAUNCH_VM(IT, V, false);           \
+    } else {                                  \
+      QH_LAUNCH_VM(IT, V, false);             \
+    }                                         \
+  } while (0)
+  // the load-order / cache-policy variants exist for the decode configuration the bench measures (bf16, float shift, M = 1)
+  constexpr bool HAS_VARIANTS = DT == QUANTO_HIP_BF16 && MT == 1 && !INT_SHIFT;
+#define QH_LAUNCH(IT)                           \
+  do {                                          \
+    if constexpr (HAS_VARIANTS) {               \
+      switch (gemv_variant()) {                 \
+        case 1: QH_LAUNCH_V(IT, 1); break;      \
+        case 2: QH_LAUNCH_V(IT, 2); break;      \
+        case 3: QH_LAUNCH_V(IT, 3); break;      \
+        case 4: QH_LAUNCH_V(IT, 4); break;      \
+        case 6: QH_LAUNCH_V(IT, 6); break;      \
+        default: QH_LAUNCH_V(IT, 0); break;     \
+      }                                         \
+    } else {                                    \
+      QH_LAUNCH_V(IT, 0);                       \
+    }                                           \
+  } while (0)
   if constexpr (MT == 8) {
     switch (iters) {
       case 1: QH_LAUNCH(1); break;
@@ -267,12 +387,14 @@ static int gemv_launch_iters(const void* x, const uint8_t* packed, const void* s
     }
   }
 #undef QH_LAUNCH
+#undef QH_LAUNCH_V
+#undef QH_LAUNCH_VM
+  if (pb.nseg > 1 && MT > 4) return QUANTO_HIP_ENOTSUP;  // not reachable: the multi entry point is limited to M <= 4
   return launch_status();
 }
 
 template <int DT, bool INT_SHIFT>
-static int gemv_launch_m(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int M,
-                         int N, int K, hipStream_t stream) {
+static int gemv_launch_m(const void* x, const GemvProblem& pb, int M, int K, hipStream_t stream) {
   // Rows of x are processed in passes of at most 8 (x lives in registers: 8 VGPRs per slab and row); the weights of
   // later passes come from the Infinity Cache (a Linear's packed weight is 8-30 MB).  8 rows per pass need
   // iters <= 2 slabs per wave (K <= 8192) to stay inside the register file.
@@ -283,17 +405,15 @@ static int gemv_launch_m(const void* x, const uint8_t* packed, const void* scale
   while (m0 < M) {
     const int left = M - m0;
     const int mt = (left >= 8 && mt_max >= 8) ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1));
-    const void* xp = reinterpret_cast<const uint16_t*>(x) + (size_t)m0 * K;
-    void* yp = reinterpret_cast<uint16_t*>(y) + (size_t)m0 * N;
     int st;
     if (mt == 8)
-      st = gemv_launch_iters<DT, 8, INT_SHIFT>(xp, packed, scale, shift, bias, yp, N, K, stream);
+      st = gemv_launch_iters<DT, 8, INT_SHIFT>(x, pb, m0, K, stream);
     else if (mt == 4)
-      st = gemv_launch_iters<DT, 4, INT_SHIFT>(xp, packed, scale, shift, bias, yp, N, K, stream);
+      st = gemv_launch_iters<DT, 4, INT_SHIFT>(x, pb, m0, K, stream);
     else if (mt == 2)
-      st = gemv_launch_iters<DT, 2, INT_SHIFT>(xp, packed, scale, shift, bias, yp, N, K, stream);
+      st = gemv_launch_iters<DT, 2, INT_SHIFT>(x, pb, m0, K, stream);
     else
-      st = gemv_launch_iters<DT, 1, INT_SHIFT>(xp, packed, scale, shift, bias, yp, N, K, stream);
+      st = gemv_launch_iters<DT, 1, INT_SHIFT>(x, pb, m0, K, stream);
     if (st != QUANTO_HIP_OK) return st;
     m0 += mt;
   }
@@ -305,16 +425,47 @@ bool qbits_gemv_supported(int64_t M, const PackedGeom& g, int dtype) {
          M <= QUANTO_HIP_GEMV_MAX_M_QBITS && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30);
 }
 
+static int gemv_dispatch(const void* x, const GemvProblem& pb, int M, int K, int dtype, bool int_shift, hipStream_t stream) {
+  if (dtype == QUANTO_HIP_BF16)
+    return int_shift ? gemv_launch_m<QUANTO_HIP_BF16, true>(x, pb, M, K, stream) : gemv_launch_m<QUANTO_HIP_BF16, false>(x, pb, M, K, stream);
+  return int_shift ? gemv_launch_m<QUANTO_HIP_F16, true>(x, pb, M, K, stream) : gemv_launch_m<QUANTO_HIP_F16, false>(x, pb, M, K, stream);
+}
+
 int qbits_mm_gemv(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t M,
                   const PackedGeom& g, int dtype, bool int_shift, hipStream_t stream) {
   if (!qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_ENOTSUP;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed)) % 16) return QUANTO_HIP_EALIGN;
-  const int Mi = (int)M, N = (int)g.N, K = (int)g.K;
-  if (dtype == QUANTO_HIP_BF16)
-    return int_shift ? gemv_launch_m<QUANTO_HIP_BF16, true>(x, packed, scale, shift, bias, y, Mi, N, K, stream)
-                     : gemv_launch_m<QUANTO_HIP_BF16, false>(x, packed, scale, shift, bias, y, Mi, N, K, stream);
-  return int_shift ? gemv_launch_m<QUANTO_HIP_F16, true>(x, packed, scale, shift, bias, y, Mi, N, K, stream)
-                   : gemv_launch_m<QUANTO_HIP_F16, false>(x, packed, scale, shift, bias, y, Mi, N, K, stream);
+  GemvProblem pb{};
+  pb.nseg = 1;
+  pb.packed[0] = packed;
+  pb.scale[0] = scale;
+  pb.shift[0] = shift;
+  pb.bias[0] = bias;
+  pb.y[0] = y;
+  pb.N[0] = (int)g.N;
+  return gemv_dispatch(x, pb, (int)M, (int)g.K, dtype, int_shift, stream);
+}
+
+// nseg (2..QUANTO_HIP_MAX_MULTI) int4 g128 Linears with the same K applied to the same x in one launch per pass of rows.
+// The caller has checked qbits_gemv_supported for every segment.
+int qbits_mm_gemv_multi(const void* x, int nseg, const uint8_t* const* packed, const void* const* scale, const void* const* shift,
+                        const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, bool int_shift,
+                        hipStream_t stream) {
+  if (nseg < 1 || nseg > MAX_SEGS) return QUANTO_HIP_EINVAL;
+  GemvProblem pb{};
+  pb.nseg = nseg;
+  uintptr_t align = reinterpret_cast<uintptr_t>(x);
+  for (int i = 0; i < nseg; ++i) {
+    pb.packed[i] = packed[i];
+    pb.scale[i] = scale[i];
+    pb.shift[i] = shift[i];
+    pb.bias[i] = bias ? bias[i] : nullptr;
+    pb.y[i] = y[i];
+    pb.N[i] = (int)N[i];
+    align |= reinterpret_cast<uintptr_t>(packed[i]);
+  }
+  if (align % 16) return QUANTO_HIP_EALIGN;
+  return gemv_dispatch(x, pb, (int)M, (int)K, dtype, int_shift, stream);
 }
 
 }  // namespace qh

@@ -16,6 +16,12 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int kWave = 64;
 
+// qbits GEMV load policy used when QUANTO_HIP_GEMV_VARIANT is unset (see qbits_gemv.hip): bit 0 = x / scale loads first,
+// bit 1 = non-temporal weight loads
+#ifndef QUANTO_HIP_GEMV_DEFAULT_VARIANT
+#define QUANTO_HIP_GEMV_DEFAULT_VARIANT 0
+#endif
+
 // ---- element traits for the three float dtypes of the ABI ------------------------------------
 template <int DT>
 struct Elem;

@@ -68,6 +68,9 @@ class _Bindings:
         c.quanto_hip_dequantize_qbits.argtypes = [vp, vp, vp, vp, i64, i64, ci, ci, ci, ci, vp]
         c.quanto_hip_qbits_mm.restype = ci
         c.quanto_hip_qbits_mm.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, ci, ci, ci, vp, sz, vp]
+        c.quanto_hip_qbits_mm_multi.restype = ci
+        c.quanto_hip_qbits_mm_multi.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                                ctypes.POINTER(vp), ctypes.POINTER(i64), i64, i64, ci, ci, ci, ci, vp]
         c.quanto_hip_qbits_mm_workspace_size.restype = i64
         c.quanto_hip_qbits_mm_workspace_size.argtypes = [i64, i64, i64, ci, ci, ci, ci]
         c.quanto_hip_qbits_mm_pick.restype = ci
@@ -262,6 +265,46 @@ class _Bindings:
                 bits, group_size or 0, _dt(scale), _dt(shift), k, _ptr(ws), ws_bytes, self._stream(x))
         self._check(st, "qbits_mm")
         return y.reshape(*lead, out_features)
+
+    # -- quanto::qbits_mm_multi ---------------------------------------------------------------------
+    MAX_MULTI = 4  # QUANTO_HIP_MAX_MULTI
+
+    def qbits_mm_multi(self, x, packed, scale, shift, bias, bits: int, group_size, out_features, in_features: int):
+        """Several qbits_mm products sharing ``x`` (q/k/v, gate/up).  One kernel launch when every product is eligible for
+        the decode GEMV (M <= 4, int4, group size 128); otherwise the separate ops (each with its own kernel choice and
+        workspace).  Returns the list of outputs; bit-identical to the separate calls either way."""
+        n = len(packed)
+        bias = list(bias) if bias is not None else [None] * n
+        if not (len(scale) == len(shift) == len(bias) == len(out_features) == n) or n < 1:
+            raise QuantoHipError("qbits_mm_multi: inconsistent argument lists")
+        self._require_cuda(x, *packed, *scale, *shift, *bias)
+        sdt = scale[0].dtype
+        if x.dtype != sdt:
+            x = x.to(sdt)
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, in_features).contiguous()
+        M = x2.shape[0]
+        one_launch = 1 <= M <= 4 and n <= self.MAX_MULTI and all(s.dtype == sdt for s in scale) and \
+            len({sh.dtype for sh in shift}) == 1
+        if one_launch:
+            with torch.cuda.device(x.device):
+                one_launch = all(self._c.quanto_hip_qbits_mm_pick(M, nf, in_features, bits, group_size or 0, _dt(scale[0])) == KERNEL_GEMV
+                                 for nf in out_features)
+        if not one_launch:
+            return [self.qbits_mm(x, packed[i], scale[i], shift[i], bias[i], bits, group_size, out_features[i], in_features)
+                    for i in range(n)]
+        packed = [t.contiguous() for t in packed]
+        scale = [t.contiguous() for t in scale]
+        shift = [t.contiguous() for t in shift]
+        bias = [None if b is None else b.to(sdt).contiguous() for b in bias]
+        ys = [torch.empty((M, nf), dtype=sdt, device=x.device) for nf in out_features]
+        arr = lambda ts: (ctypes.c_void_p * n)(*[0 if t is None else t.data_ptr() for t in ts])  # noqa: E731
+        nfs = (ctypes.c_int64 * n)(*out_features)
+        with torch.cuda.device(x.device):
+            st = self._c.quanto_hip_qbits_mm_multi(_ptr(x2), n, arr(packed), arr(scale), arr(shift), arr(bias), arr(ys), nfs, M, in_features,
+                                                   bits, group_size or 0, _dt(scale[0]), _dt(shift[0]), self._stream(x))
+        self._check(st, "qbits_mm_multi")
+        return [y.reshape(*lead, nf) for y, nf in zip(ys, out_features)]
 
     # -- quanto::qbytes_mm --------------------------------------------------------------------------
     def qbytes_mm(self, a, b, scales, bias=None, kernel: str = "auto"):

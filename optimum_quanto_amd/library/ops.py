@@ -273,3 +273,20 @@ if _define("qbits_mm",
            "int out_features, int in_features) -> Tensor"):
     _impl("qbits_mm", "CompositeExplicitAutograd", qbits_mm_default, True)
     _impl("qbits_mm", "CUDA", qbits_mm_hip, True)
+
+
+# several Linears applied to the same input in one launch (q/k/v, gate/up of a decoder layer at decode time)
+def qbits_mm_multi_default(input, packed, scale, shift, bias, bits: int, group_size: Optional[int], out_features, in_features: int):
+    return [torch.ops.quanto.qbits_mm(input, packed[i], scale[i], shift[i], bias[i], bits, group_size, out_features[i], in_features)
+            for i in range(len(packed))]
+
+
+def qbits_mm_multi_hip(input, packed, scale, shift, bias, bits: int, group_size: Optional[int], out_features, in_features: int):
+    return quanto_hip.lib.qbits_mm_multi(input, packed, scale, shift, bias, bits, group_size, list(out_features), in_features)
+
+
+if _define("qbits_mm_multi",
+           "(Tensor input, Tensor[] packed, Tensor[] scale, Tensor[] shift, Tensor?[] bias, int bits, int? group_size, "
+           "int[] out_features, int in_features) -> Tensor[]"):
+    _impl("qbits_mm_multi", "CompositeExplicitAutograd", qbits_mm_multi_default, True)
+    _impl("qbits_mm_multi", "CUDA", qbits_mm_multi_hip, True)

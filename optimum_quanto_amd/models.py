@@ -16,7 +16,7 @@ from .model_api import freeze, quantization_map, quantize, requantize
 from .nn import QModuleMixin
 from .tensor import Optimizer, qtype
 
-__all__ = ["QuantizedTransformersModel", "QuantizedModelForCausalLM"]
+__all__ = ["QuantizedTransformersModel", "QuantizedModelForCausalLM", "fuse_decode_projections"]
 
 _QMAP_NAME = "quanto_qmap.json"
 
@@ -102,3 +102,76 @@ class QuantizedModelForCausalLM(QuantizedTransformersModel):
         from transformers import AutoModelForCausalLM
 
         return AutoModelForCausalLM
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# decode-time launch fusion: Linears that read the same activation (q/k/v, gate/up) in ONE quanto::qbits_mm_multi launch
+# ------------------------------------------------------------------------------------------------------------------------
+class _SiblingGroup:
+    """The frozen int4 QLinears of one parent module that are applied to the same input tensor.
+
+    The model code is left alone (it still calls ``q_proj(h)``, ``k_proj(h)``, ``v_proj(h)`` one after the other): the first
+    sibling called with a decode-shaped input runs ``quanto::qbits_mm_multi`` for all of them and parks the other outputs,
+    which the following calls pick up when they arrive with the very same tensor object.  Anything else - another input, a
+    larger batch, an unfrozen weight, gradients - takes the module's normal forward."""
+
+    def __init__(self, modules):
+        self.modules = modules
+        self.input = None      # strong reference: the storage cannot be recycled while outputs are parked
+        self.outputs = {}
+
+    def eligible(self, x) -> bool:
+        if type(x) is not torch.Tensor or not x.is_cuda or x.numel() // x.shape[-1] > 4 or torch.is_grad_enabled() and x.requires_grad:
+            return False
+        from .tensor import WeightQBitsTensor
+
+        w0 = self.modules[0].weight
+        for m in self.modules:
+            w = m.weight
+            if not (isinstance(w, WeightQBitsTensor) and w.qtype.bits == 4 and w._group_size == 128 and w.axis == 0
+                    and w.shape[1] == w0.shape[1] and w._shift.dtype == w0._shift.dtype and w.dtype == x.dtype
+                    and m.activation_qtype is None):
+                return False
+        return True
+
+    def forward(self, index: int, x):
+        if self.input is x and index in self.outputs:
+            y = self.outputs.pop(index)
+            if not self.outputs:
+                self.input = None
+            return y
+        self.input, self.outputs = None, {}
+        if not self.eligible(x):
+            return None
+        ws = [m.weight for m in self.modules]
+        ys = torch.ops.quanto.qbits_mm_multi(x, [w._data._data for w in ws], [w._scale for w in ws], [w._shift for w in ws],
+                                             [m.bias for m in self.modules], 4, 128, [w.shape[0] for w in ws], ws[0].shape[1])
+        self.input = x
+        self.outputs = {i: y for i, y in enumerate(ys) if i != index}
+        return ys[index]
+
+
+def fuse_decode_projections(model, groups=(("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"))):
+    """Opt-in: make sibling QLinears (same parent, same input) share one kernel launch at decode time (M <= 4).
+
+    Weights, state dict and module tree are untouched; only ``forward`` of the listed children is wrapped.  Returns the
+    number of groups that were linked."""
+    from .nn import QLinear
+
+    linked = 0
+    for parent in model.modules():
+        for names in groups:
+            mods = [getattr(parent, n, None) for n in names]
+            if not all(isinstance(m, QLinear) for m in mods) or any(getattr(m, "_sibling_group", None) is not None for m in mods):
+                continue
+            group = _SiblingGroup(mods)
+            for i, m in enumerate(mods):
+                m._sibling_group = group
+
+                def forward(input, _m=m, _i=i, _g=group, _orig=m.forward):
+                    y = _g.forward(_i, input)
+                    return _orig(input) if y is None else y
+
+                m.forward = forward
+            linked += 1
+    return linked

@@ -1,0 +1,134 @@
+"""``quanto::qbits_mm_multi`` / ``quanto_hip_qbits_mm_multi``: several int4 Linears that read the same activation (q/k/v,
+gate/up) in one launch at decode time.  The contract is "bit-identical to the separate quanto::qbits_mm calls", which in
+turn are gated against the exact-math oracle in test_hip_parity.py - so the checks here are (a) equality with the separate
+ops and (b) the oracle once more on the fused launch itself."""
+import numpy as np
+import pytest
+import torch
+
+import optimum_quanto_amd as Q
+from oracle import quanto_oracle as O
+
+from helpers import assert_close_to_exact, make_qbits_problem, to_numpy, to_torch
+
+
+def _problems(M, K, Ns, dt, dev, seed=0, bias=False, zeropoint=False):
+    ps = [make_qbits_problem(M, n, K, dt, seed=seed + 17 * i, zeropoint=zeropoint) for i, n in enumerate(Ns)]
+    x = to_torch(ps[0]["x"], dt, dev)  # one shared activation
+    packed = [torch.from_numpy(p["packed"]).to(dev) for p in ps]
+    scale = [to_torch(p["scale"], dt, dev) for p in ps]
+    shift = [torch.from_numpy(p["shift"]).to(dev) if zeropoint else to_torch(p["shift"], dt, dev) for p in ps]
+    rng = np.random.default_rng(seed + 99)
+    biases = [to_torch(O.round_to(rng.standard_normal(n).astype(np.float32), dt), dt, dev) if bias else None for n in Ns]
+    return ps, x, packed, scale, shift, biases
+
+
+def test_multi_default_equals_separate_ops_cpu():
+    Ns, K = [64, 32, 32], 256
+    ps, x, packed, scale, shift, biases = _problems(3, K, Ns, "fp32", "cpu", bias=True)
+    ys = torch.ops.quanto.qbits_mm_multi(x, packed, scale, shift, biases, 4, 128, Ns, K)
+    assert len(ys) == 3
+    for i, n in enumerate(Ns):
+        want = torch.ops.quanto.qbits_mm(x, packed[i], scale[i], shift[i], biases[i], 4, 128, n, K)
+        assert torch.equal(ys[i], want)
+        exact = O.qbits_mm_exact(ps[0]["x"], ps[i]["packed"], 4, ps[i]["scale"], ps[i]["shift"], 128, n, K) + to_numpy(biases[i])
+        assert O.rel_fro(to_numpy(ys[i]), exact) < 1e-5
+
+
+def _tiny_llama(device):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, vocab_size=160, max_position_embeddings=64)
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+    Q.QuantizedModelForCausalLM.quantize(model, weights=Q.qint4, exclude="lm_head")
+    return model.to(device), cfg
+
+
+def test_fuse_decode_projections_is_transparent_on_cpu():
+    """On CPU tensors the sibling groups never engage: logits must be identical with and without the wrapper."""
+    model, cfg = _tiny_llama("cpu")
+    ids = torch.randint(1, cfg.vocab_size - 1, (1, 7), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = model(ids).logits
+        assert Q.fuse_decode_projections(model) == 2 * cfg.num_hidden_layers
+        assert Q.fuse_decode_projections(model) == 0  # idempotent
+        got = model(ids).logits
+    assert torch.equal(ref, got)
+    assert list(model.state_dict().keys()) == list(_tiny_llama("cpu")[0].state_dict().keys())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("Ns,K", [((4096, 1024, 1024), 4096), ((14336, 14336), 4096), ((512, 256, 128, 64), 1024),
+                                  ((1024, 1024), 14336), ((130, 2), 256)])
+def test_multi_is_bit_identical_to_separate_calls_gpu(dt, M, Ns, K):
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    lib = quanto_hip.lib
+    ps, x, packed, scale, shift, biases = _problems(M, K, list(Ns), dt, "cuda", seed=M, bias=(M % 2 == 0))
+    ys = torch.ops.quanto.qbits_mm_multi(x, packed, scale, shift, biases, 4, 128, list(Ns), K)
+    assert lib.last_kernel() == "gemv_multi"
+    for i, n in enumerate(Ns):
+        want = torch.ops.quanto.qbits_mm(x, packed[i], scale[i], shift[i], biases[i], 4, 128, n, K)
+        assert lib.last_kernel() == "gemv"
+        assert torch.equal(ys[i], want), f"segment {i} (N={n}) differs from the separate call"
+    if M == 1 and dt == "bf16":  # and the oracle on the fused launch itself
+        for i, n in enumerate(Ns):
+            if biases[i] is None:
+                exact = O.qbits_mm_exact(ps[0]["x"], ps[i]["packed"], 4, ps[i]["scale"], ps[i]["shift"], 128, n, K)
+                assert_close_to_exact(to_numpy(ys[i]), exact, dt, f"multi segment {i}")
+
+
+@pytest.mark.gpu
+def test_multi_zero_point_and_fallbacks_gpu():
+    """Integer zero-points run fused as well; M > 4 and group sizes the GEMV does not serve fall back to the separate ops."""
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    lib = quanto_hip.lib
+    Ns, K = [256, 128], 512
+    ps, x, packed, scale, shift, biases = _problems(2, K, Ns, "bf16", "cuda", zeropoint=True)
+    ys = torch.ops.quanto.qbits_mm_multi(x, packed, scale, shift, biases, 4, 128, Ns, K)
+    assert lib.last_kernel() == "gemv_multi"
+    for i, n in enumerate(Ns):
+        assert torch.equal(ys[i], torch.ops.quanto.qbits_mm(x, packed[i], scale[i], shift[i], None, 4, 128, n, K))
+    ps, x, packed, scale, shift, biases = _problems(9, K, Ns, "bf16", "cuda")
+    ys = torch.ops.quanto.qbits_mm_multi(x, packed, scale, shift, biases, 4, 128, Ns, K)
+    assert lib.last_kernel() != "gemv_multi"
+    for i, n in enumerate(Ns):
+        assert torch.equal(ys[i], torch.ops.quanto.qbits_mm(x, packed[i], scale[i], shift[i], None, 4, 128, n, K))
+
+
+@pytest.mark.gpu
+def test_fused_decode_projections_on_device():
+    """Tiny Llama, decode step by step with a static cache: logits with q/k/v and gate/up fused are identical to the unfused
+    model's (same kernels, same arithmetic, one launch instead of five)."""
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    model, cfg = _tiny_llama("cuda")
+    ids = torch.randint(1, cfg.vocab_size - 1, (1, 9), generator=torch.Generator().manual_seed(2)).cuda()
+    with torch.no_grad():
+        ref = [model(ids[:, : t + 1]).logits[:, -1] for t in range(3, 9)]
+        ref1 = model(ids[:, :1]).logits[:, -1]
+        assert Q.fuse_decode_projections(model) == 2 * cfg.num_hidden_layers
+        seen = set()
+        orig = quanto_hip.lib.qbits_mm_multi
+
+        def spy(*a, **k):
+            out = orig(*a, **k)
+            seen.add(quanto_hip.lib.last_kernel())
+            return out
+
+        quanto_hip.lib.qbits_mm_multi = spy
+        try:
+            out = model(ids[:, :1], use_cache=True)  # M = 1: the fused launch engages
+            got1 = out.logits[:, -1]
+        finally:
+            del quanto_hip.lib.qbits_mm_multi
+        got = [model(ids[:, : t + 1]).logits[:, -1] for t in range(3, 9)]  # M > 4 rows after t >= 4: normal path
+    assert "gemv_multi" in seen
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    assert torch.equal(got1, ref1)
