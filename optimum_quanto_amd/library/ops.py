@@ -54,11 +54,15 @@ def _define(name: str, schema: str) -> bool:
 def _impl(name: str, key: str, fn, owned: bool):
     if owned:
         _lib_impl.impl(name, fn, key)
-    else:  # plug-in mode: replace the reference's registration for this key
-        try:
-            _lib_impl.impl(name, fn, key, allow_override=True)
-        except TypeError:  # older torch without allow_override
-            _lib_impl.impl(name, fn, key)
+    else:  # plug-in mode: replace the reference's registration for this key (intended: silence torch's override notice)
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                _lib_impl.impl(name, fn, key, allow_override=True)
+            except TypeError:  # older torch without allow_override
+                _lib_impl.impl(name, fn, key)
 
 
 # ------------------------------------------------------------------------------------------------
