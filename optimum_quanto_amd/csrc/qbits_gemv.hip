@@ -316,7 +316,7 @@ struct GemvProblem {
 static int gemv_variant() {
   // experiments: QUANTO_HIP_GEMV_VARIANT = bit 0 (x / scales requested first) | bit 1 (non-temporal weight loads) |
   // bit 2 (ablation, wrong results: a quarter of the arithmetic - tells how much of a call is VALU work)
-  static const int v = [] { const char* e = getenv("QUANTO_HIP_GEMV_VARIANT"); return e ? atoi(e) & 7 : QUANTO_HIP_GEMV_DEFAULT_VARIANT; }();
+  const int v = env_int("QUANTO_HIP_GEMV_VARIANT", QUANTO_HIP_GEMV_DEFAULT_VARIANT) & 7;
   return v;
 }
 

@@ -342,7 +342,7 @@ static int launch(const Args& a, hipStream_t stream) {
 // 21.9 us, 2 waves 21.8 us, 1 wave 26.1 us): the kernel is bound by the instruction stream of the single wave each SIMD gets,
 // not by the number of occupied CUs - what it lacks for N <= 4096 is K-parallelism.
 inline int pick_waves(int N) {
-  static const int forced = [] { const char* e = getenv("QUANTO_HIP_SKINNY_WAVES"); return e ? atoi(e) : 0; }();  // experiments
+  const int forced = env_int("QUANTO_HIP_SKINNY_WAVES", 0);  // experiments
   if (forced == 1 || forced == 2 || forced == 4) return (N % (16 * forced)) == 0 ? forced : 1;
   return N % 64 == 0 ? 4 : (N % 32 == 0 ? 2 : 1);
 }
@@ -367,7 +367,7 @@ static int launch_tf(const Args& a, hipStream_t stream) {
 // split factor: enough K-ranges that every SIMD of the chip gets a wave (N = 4096 alone gives 256 waves for 1024 SIMDs),
 // each range at least 4 groups long and the group count divisible by it
 static int skinny_split(const PackedGeom& g) {
-  static const int forced = [] { const char* e = getenv("QUANTO_HIP_SKINNY_SPLIT"); return e ? atoi(e) : 0; }();  // experiments
+  const int forced = env_int("QUANTO_HIP_SKINNY_SPLIT", 0);  // experiments
   const int waves = (int)(g.N / 16);
   int s = 1;
   while (s < 8 && waves * s * 2 <= 1024 && g.G % (s * 2) == 0 && g.G / (s * 2) >= 4) s *= 2;

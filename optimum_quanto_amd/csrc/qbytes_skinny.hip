@@ -305,7 +305,7 @@ static int launch_tf(const Args& a, hipStream_t stream) {
 }  // namespace skinny8
 
 static int skinny8_split(int64_t N, int64_t K) {
-  static const int forced = [] { const char* e = getenv("QUANTO_HIP_SKINNY_SPLIT"); return e ? atoi(e) : 0; }();  // experiments
+  const int forced = env_int("QUANTO_HIP_SKINNY_SPLIT", 0);  // experiments
   const int waves = (int)((N + 63) / 64) * 4, G = (int)(K / skinny8::BK);
   int s = 1;
   while (s < 8 && waves * s * 2 <= 1024 && G % (s * 2) == 0 && G / (s * 2) >= 4) s *= 2;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/quanto_hip.h"
 
@@ -101,6 +102,13 @@ inline PackedGeom make_geom(int64_t N, int64_t K, int bits, int group_size) {
   g.R = N * g.G;
   g.row_dim = (g.R + g.vpi - 1) / g.vpi;
   return g;
+}
+
+// Experiment knobs: read on every call (a getenv is ~100 ns next to a microsecond launch path) so that one process can
+// A/B the variants - scripts/ab.py flips the variable between hipGraph captures.
+inline int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
 }
 
 int launch_status();  // hipGetLastError() -> quanto_hip_status (defined in c_api.hip)

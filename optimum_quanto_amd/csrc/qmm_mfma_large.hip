@@ -602,7 +602,7 @@ enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2, CFG_256_1X8 = 3 };
 template <int DT, int FMT, int BM, int BN, int WM, int WN, int WD = 0>
 static int launch_cfg(const Args& a, hipStream_t stream) {
   constexpr int lds0 = WD != 0 ? WD * (BM * BK * 2) : STAGES * (BM * BK * 2 + BN * BK);
-  static const int pad = [] { const char* e = getenv("QUANTO_HIP_LARGE_LDS_PAD"); return e ? atoi(e) : 0; }();  // experiments
+  const int pad = env_int("QUANTO_HIP_LARGE_LDS_PAD", 0);  // experiments
   const int lds = lds0 + pad;
   static_assert(lds0 >= BM * BN * 2, "the epilogue parks the output tile in the stage memory");
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, tiles = tiles_m * tiles_n;
@@ -612,7 +612,7 @@ static int launch_cfg(const Args& a, hipStream_t stream) {
     const int band = (tiles + 7) / 8;
     int g = 1;
     while ((g + 1) * (g + 1) * 2 * BM <= band * BN) ++g;
-    static const int forced = [] { const char* e = getenv("QUANTO_HIP_GROUP_M"); return e ? atoi(e) : 0; }();  // experiments
+    const int forced = env_int("QUANTO_HIP_GROUP_M", 0);  // experiments
     if (forced > 0) g = forced;
     b.group_m = g < tiles_m ? g : tiles_m;
   }
@@ -626,7 +626,7 @@ template <int DT, int FMT>
 static int launch(const Args& a, int cfg, hipStream_t stream) {
   // three 24 KiB stages: two workgroups share a CU (two interleaving streams per SIMD)
   if (cfg == CFG_128_4W) {
-    static const int wd = [] { const char* e = getenv("QUANTO_HIP_LARGE_WD"); return e ? atoi(e) : 1; }();  // 0 off, 1 auto, 5 always
+    const int wd = env_int("QUANTO_HIP_LARGE_WD", 1);  // 0 off, 1 auto, 5 always
     const int nk = a.K / BK / a.S;
     // weights-direct variant when the K-range of a workgroup is a whole number of 4-tile ring turns
     // and every workgroup has a CU to itself: with two workgroups per CU the partner hides the DMA latency anyway and
@@ -659,7 +659,7 @@ bool qbytes_mfma_large_supported(int64_t M, int64_t N, int64_t K, int a_dtype, i
 // loop (bf16 x int8, M = 512, N = 4096, split 1 -> 2): K = 4096 30 -> 42 us, K = 8192 55 -> 57 us, K = 14336 91 -> 80 us;
 // cfg4 (512, 8192, 8192; 256 tiles) 65 -> 100 us.
 static int large_split(int64_t M, int64_t N, int64_t K) {
-  static const int forced = [] { const char* e = getenv("QUANTO_HIP_LARGE_SPLIT"); return e ? atoi(e) : 0; }();  // experiments
+  const int forced = env_int("QUANTO_HIP_LARGE_SPLIT", 0);  // experiments
   const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256), tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
   int s = 1;
   if (tiles128 <= 128 && K >= 10240 && (K / lt::BK) % 2 == 0) s = 2;
@@ -680,7 +680,7 @@ size_t qbytes_mfma_large_workspace(int64_t M, int64_t N, int64_t K) {
 // own.  Used by qbits_mm's dequantize + GEMM path; the gain over qmm_native8.hip's 128-tile dense kernel is small
 // ((256, 4096, 4096): 47 -> 41 us for the GEMM, 58 -> 54 us with the dequantize pass): both stream 32 KiB per K-tile and CU.
 bool dense_mm_wd_supported(int64_t M, int64_t N, int64_t K, int dtype) {
-  static const int on = [] { const char* e = getenv("QUANTO_HIP_DENSE_WD"); return e ? atoi(e) : 1; }();  // experiments
+  const int on = env_int("QUANTO_HIP_DENSE_WD", 1);  // experiments
   const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
   return on && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && K % (4 * lt::BK) == 0 && K >= 8 * lt::BK && M >= 1 &&
          tiles128 <= 256 && M * K < (1ll << 30) && N * K < (1ll << 30);
@@ -702,7 +702,7 @@ int qbytes_mm_mfma_large(const void* x, const void* w, const void* s, const void
   // 128-tiles as long as all of them are resident at once (two workgroups per CU: 512), 256-tiles beyond.  Measured,
   // bf16 x int8, K = 4096, us with 256-tiles -> 128-tiles: (512,14336) 87 -> 67, (1024,8192) 85 -> 70, (2048,4096) 79 -> 66;
   // but (1280,8192) 82 -> 99, (2048,8192) 107 -> 125
-  static const int forced = [] { const char* e = getenv("QUANTO_HIP_LARGE_CFG"); return e ? atoi(e) : -1; }();  // experiments
+  const int forced = env_int("QUANTO_HIP_LARGE_CFG", -1);  // experiments
   const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
   const int cfg = forced >= 0 ? forced : (tiles128 > 512 ? lt::CFG_256_8W : lt::CFG_128_4W);
   if (cfg != lt::CFG_128_4W) split = 1;  // the workspace is sized for 128-tiles

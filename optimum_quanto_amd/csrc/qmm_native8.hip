@@ -417,13 +417,13 @@ static int launch(const Args& a, hipStream_t stream) {
   // int8 / 16-bit: 256-tiles when they give every CU at least ~3/8 of a tile, otherwise 128-tiles.  fp8 (paired MX loop):
   // 128-tiles as long as all of them are resident at once, two per CU.  Measured, K = 4096, us with 256- -> 128-tiles:
   // int8 (768,8192) 43 -> 44, (1024,8192) 50 -> 56; fp8 (768,8192) 51 -> 39, (1024,8192) 56 -> 47, (1280,8192) 56 -> 68
-  static const int small_env = [] { const char* e = getenv("QUANTO_HIP_NATIVE8_SMALL"); return e ? atoi(e) : -1; }();  // experiments
+  const int small_env = env_int("QUANTO_HIP_NATIVE8_SMALL", -1);  // experiments
   const int64_t tiles256 = (int64_t)((a.N + 255) / 256) * ((a.M + 255) / 256), tiles128 = (int64_t)((a.N + 127) / 128) * ((a.M + 127) / 128);
   // the paired loop pays off only where one instruction consumes both tiles (fp8); as two MFMAs per pair it measured
   // slower than the per-tile loop (int8 4096^3: 72 vs 66 us; dense bf16: 135 vs 127 us) - QUANTO_HIP_PAIRED=1 forces it
   constexpr int ES = (KIND == K_BF16 || KIND == K_F16) ? 2 : 1;
   constexpr bool FP8 = KIND == K_F8E4M3 || KIND == K_F8E5M2;
-  static const int paired_env = [] { const char* e = getenv("QUANTO_HIP_PAIRED"); return e ? atoi(e) : -1; }();  // experiments
+  const int paired_env = env_int("QUANTO_HIP_PAIRED", -1);  // experiments
   const bool paired = (paired_env == 1 || (FP8 && paired_env != 0)) && (a.K * ES) % 128 == 0;
   const bool small = small_env >= 0 ? small_env != 0 : (FP8 && paired ? tiles128 <= 512 : tiles256 < 96);
   if (paired) return small ? launch_cfg<ODT, KIND, true, true>(a, stream) : launch_cfg<ODT, KIND, true, false>(a, stream);
