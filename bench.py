@@ -59,6 +59,8 @@ WORKLOADS = {
     "fp8a8": ("qbytes_f8f8", 4096, 4096, 4096, "fp8-e4m3fn x fp8-e4m3fn qbytes_mm (quantized activations), (M,K,N)=(4096,4096,4096)"),
     "int4_prefill": ("qbits_i4", 4096, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, prefill (M,K,N)=(4096,4096,4096)"),
     "int4_prefill512": ("qbits_i4", 512, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, (M,K,N)=(512,4096,4096)"),
+    "int8_8k": ("qbytes_i8", 8192, 8192, 8192, "bf16 x int8 qbytes_mm, per-channel scale, (M,K,N)=(8192,8192,8192)"),
+    "fp8_4k": ("qbytes_f8", 4096, 4096, 4096, "bf16 x fp8-e4m3fn qbytes_mm, per-channel scale, (M,K,N)=(4096,4096,4096)"),
     "int8_decode": ("qbytes_i8", 1, 4096, 4096, "bf16 x int8 qbytes_mm, per-channel scale, decode (M,K,N)=(1,4096,4096)"),
     "int4_decode32": ("qbits_i4", 32, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,4096)"),
     "int4_decode32_up": ("qbits_i4", 32, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,14336)"),

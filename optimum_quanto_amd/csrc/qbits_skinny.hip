@@ -41,6 +41,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
+// non-temporal flavour for the weight stream: every weight byte is read once per pass (MI355X_MICROARCH.md "nt-weights":
+// issued -> landed 18 % sooner on one-shot streams)
+__device__ __forceinline__ void glds16_nt(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off nt\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
 
 template <int DT>
 struct Mma;
@@ -89,6 +103,7 @@ struct Args {
   int S;
   int* counters;    // [N / (16*WAVES)]
   float* partials;  // [blocks][WAVES*64 lanes][TF] float4
+  int nt;           // non-temporal weight DMA (single-pass calls: M <= 64)
 };
 
 // WAVES per block: 4 (64 features per block), 2 or 1 (16 features) - so that any N that is a multiple of 16 is served.
@@ -136,7 +151,10 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
   auto issue = [&](int kt, int stage) {
     const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
-    glds16(wsrc + (size_t)kt * BK, st + wave * 1024);
+    if (a.nt)
+      glds16_nt(wsrc + (size_t)kt * BK, st + wave * 1024);
+    else
+      glds16(wsrc + (size_t)kt * BK, st + wave * 1024);
 #pragma unroll
     for (int u = 0; u < XP; ++u) glds16(xsrc[u] + (size_t)kt * (BK * 2), st + W_BYTES + (wave * XP + u) * 1024);
   };
@@ -329,7 +347,7 @@ static int launch_s(const Args& a, hipStream_t stream) {
 // blocks budget for two (or three) blocks per CU.
 template <int DT, int TF, bool INT_SHIFT, int WAVES>
 static int launch(const Args& a, hipStream_t stream) {
-  constexpr int budget = WAVES == 4 ? 150 * 1024 : 76 * 1024;
+  const int budget = env_int("QUANTO_HIP_SKINNY_LDS_KB", WAVES == 4 ? 150 : 76) * 1024;  // experiments: smaller = more blocks per CU
   constexpr int per_tile = 1 + TF * 4 / WAVES;  // DMA instructions per wave and tile; vmcnt counts at most 63 of them
   if constexpr ((8 - 4) * per_tile <= 60)
     if (lds_bytes(TF, 8, a.G / a.S, WAVES) <= budget) return launch_s<DT, TF, 8, INT_SHIFT, WAVES>(a, stream);
@@ -408,7 +426,9 @@ int qbits_mm_skinny(const void* x, const uint8_t* packed, const void* scale, con
     skinny::Args a{reinterpret_cast<const uint8_t*>(x) + (size_t)m0 * g.K * esize, packed, scale, shift, bias,
                    reinterpret_cast<uint8_t*>(y) + (size_t)m0 * g.N * esize, (int)rows, (int)g.N, (int)g.K, (int)g.G, S,
                    reinterpret_cast<int*>(workspace),
-                   S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr};
+                   S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr,
+                   // later passes of a multi-pass call re-read the weights from the Infinity Cache: keep them cacheable there
+                   env_int("QUANTO_HIP_SKINNY_NT", M <= 64 ? 1 : 0)};
     int r;
     if (dtype == QUANTO_HIP_BF16)
       r = int_shift ? skinny::launch_tf<QUANTO_HIP_BF16, true>(a, stream) : skinny::launch_tf<QUANTO_HIP_BF16, false>(a, stream);

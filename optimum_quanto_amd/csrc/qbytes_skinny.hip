@@ -35,6 +35,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
+// non-temporal flavour for the weight stream: every weight byte is read once per pass (MI355X_MICROARCH.md "nt-weights":
+// issued -> landed 18 % sooner on one-shot streams)
+__device__ __forceinline__ void glds16_nt(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off nt\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
 
 template <int DT>
 struct Mma;
@@ -58,23 +72,29 @@ struct Mma<QUANTO_HIP_F16> {
 
 enum { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2 };
 
-// bytes (2p, 2p+1) of `word` -> two 16-bit elements (exact: every int8 / fp8 value is representable in bf16 and fp16)
+// bytes (2p, 2p+1) of `word` -> two 16-bit elements (exact: every int8 / fp8 value is representable in bf16 and fp16);
+// fp8 / bf8 in one op with gfx950's v_cvt_scalef32_pk_{bf16,f16}_{fp8,bf8} at scale 1.0 (see qmm_large_common.h)
 template <int DT, int FMT>
 __device__ __forceinline__ uint32_t convert_pair(uint32_t word, int p) {
-  float f0, f1;
   if constexpr (FMT == W_I8) {
-    f0 = p == 0 ? (float)(int8_t)(word & 0xFFu) : (float)(int8_t)((word >> 16) & 0xFFu);
-    f1 = p == 0 ? (float)(int8_t)((word >> 8) & 0xFFu) : (float)(int8_t)(word >> 24);
+    const float f0 = p == 0 ? (float)(int8_t)(word & 0xFFu) : (float)(int8_t)((word >> 16) & 0xFFu);
+    const float f1 = p == 0 ? (float)(int8_t)((word >> 8) & 0xFFu) : (float)(int8_t)(word >> 24);
+    return Mma<DT>::pack(f0, f1);
   } else if constexpr (FMT == W_F8E4M3) {
-    const f32x2 v = p == 0 ? __builtin_amdgcn_cvt_pk_f32_fp8((int)word, false) : __builtin_amdgcn_cvt_pk_f32_fp8((int)word, true);
-    f0 = v.x;
-    f1 = v.y;
+    if constexpr (DT == QUANTO_HIP_BF16)
+      return __builtin_bit_cast(uint32_t, p == 0 ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)word, 1.0f, false)
+                                                 : __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)word, 1.0f, true));
+    else
+      return __builtin_bit_cast(uint32_t, p == 0 ? __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)word, 1.0f, false)
+                                                 : __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)word, 1.0f, true));
   } else {
-    const f32x2 v = p == 0 ? __builtin_amdgcn_cvt_pk_f32_bf8((int)word, false) : __builtin_amdgcn_cvt_pk_f32_bf8((int)word, true);
-    f0 = v.x;
-    f1 = v.y;
+    if constexpr (DT == QUANTO_HIP_BF16)
+      return __builtin_bit_cast(uint32_t, p == 0 ? __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8((int)word, 1.0f, false)
+                                                 : __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8((int)word, 1.0f, true));
+    else
+      return __builtin_bit_cast(uint32_t, p == 0 ? __builtin_amdgcn_cvt_scalef32_pk_f16_bf8((int)word, 1.0f, false)
+                                                 : __builtin_amdgcn_cvt_scalef32_pk_f16_bf8((int)word, 1.0f, true));
   }
-  return Mma<DT>::pack(f0, f1);
 }
 
 template <int MAXN, int PER>
@@ -100,6 +120,7 @@ struct Args {
   int S;              // K split (see qbits_skinny.hip)
   int* counters;
   float* partials;
+  int nt;             // non-temporal weight DMA (single-pass calls)
 };
 
 template <int DT, int FMT, int TF, int STAGES>
@@ -149,8 +170,13 @@ __global__ void __launch_bounds__(256) qbytes_skinny_kernel(const Args a) {
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
   auto issue = [&](int kt, int stage) {
     const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
-    glds16(wsrc[0] + (size_t)kt * BK, st + (wave * 2 + 0) * 1024);
-    glds16(wsrc[1] + (size_t)kt * BK, st + (wave * 2 + 1) * 1024);
+    if (a.nt) {
+      glds16_nt(wsrc[0] + (size_t)kt * BK, st + (wave * 2 + 0) * 1024);
+      glds16_nt(wsrc[1] + (size_t)kt * BK, st + (wave * 2 + 1) * 1024);
+    } else {
+      glds16(wsrc[0] + (size_t)kt * BK, st + (wave * 2 + 0) * 1024);
+      glds16(wsrc[1] + (size_t)kt * BK, st + (wave * 2 + 1) * 1024);
+    }
 #pragma unroll
     for (int u = 0; u < XPI; ++u) {
       const int piece = XP > 0 ? wave * XP + u : wave;
@@ -340,7 +366,8 @@ int qbytes_mm_skinny(const void* x, const void* w, const void* s, const void* bi
     const int64_t rows = M - m0 < 64 ? M - m0 : 64;
     skinny8::Args a{reinterpret_cast<const uint8_t*>(x) + (size_t)m0 * K * 2, reinterpret_cast<const uint8_t*>(w), s, bias,
                     reinterpret_cast<uint8_t*>(y) + (size_t)m0 * N * 2, (int)rows, (int)N, (int)K, S, reinterpret_cast<int*>(workspace),
-                    S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny8_counter_bytes(N)) : nullptr};
+                    S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny8_counter_bytes(N)) : nullptr,
+                    env_int("QUANTO_HIP_SKINNY_NT", M <= 64 ? 1 : 0)};
     int r;
 #define QH_FMT(DT)                                                                              \
   r = b_dtype == QUANTO_HIP_I8 ? skinny8::launch_tf<DT, skinny8::W_I8>(a, stream)               \

@@ -18,9 +18,12 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 constexpr int kWave = 64;
 
 // qbits GEMV load policy used when QUANTO_HIP_GEMV_VARIANT is unset (see qbits_gemv.hip): bit 0 = x / scale loads first,
-// bit 1 = non-temporal weight loads
+// bit 1 = non-temporal weight loads.  Measured (r2, hipGraph replay, us per launch, variant 0 / 1 / 2 / 3): (1,4096,4096) 4.54 /
+// 4.93 / 4.57 / 4.70, (1,4096,11008) 7.49 / 8.33 / 7.40 / 7.99, fused gate+up 2 x (1,4096,14336) 15.5 / 16.0 / 14.2 / 15.4:
+// non-temporal loads pay once the stream is long, forcing the small loads to the front never does (hipcc already
+// issues them first where it matters).
 #ifndef QUANTO_HIP_GEMV_DEFAULT_VARIANT
-#define QUANTO_HIP_GEMV_DEFAULT_VARIANT 0
+#define QUANTO_HIP_GEMV_DEFAULT_VARIANT 2
 #endif
 
 // ---- element traits for the three float dtypes of the ABI ------------------------------------

@@ -21,79 +21,10 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "qh_common.h"
-
+#include "qmm_large_common.h"
 
 namespace qh {
 namespace lt {
-
-constexpr int BK = 64;
-constexpr int STAGES = 3;
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-// LDS-DMA, 16 bytes per lane, wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset (see v2 for why asm).
-// M0 is written and not restored: on gfx9+ the compiler only needs M0 for constructs this kernel does not contain
-// (movrel, GWS, sendmsg, its own LDS-DMA builtins), and two SALU instructions per piece matter in a one-wave-per-SIMD
-// instruction stream where every issue slot next to an MFMA is accounted for.
-__device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  asm volatile(
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %1"
-      :
-      : "v"(voff), "s"(sbase), "s"(lds_dst)
-      : "memory");
-}
-
-template <int DT>
-struct Mma;
-template <>
-struct Mma<QUANTO_HIP_BF16> {
-  using V8 = bf16x8;
-  static __device__ __forceinline__ f32x4 run(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ uint32_t pack(float a, float b) {
-    bf16x2 r;
-    r.x = (__bf16)a;
-    r.y = (__bf16)b;
-    return __builtin_bit_cast(uint32_t, r);
-  }
-};
-template <>
-struct Mma<QUANTO_HIP_F16> {
-  using V8 = f16x8;
-  static __device__ __forceinline__ f32x4 run(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ uint32_t pack(float a, float b) {
-    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));  // exact for int8 / fp8 values
-  }
-};
-
-enum { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2, W_DENSE = 3 };  // W_DENSE: weights already in the activation dtype (weights-direct loop only)
-
-__device__ __forceinline__ int swz_a(int row) {
-  const int q = (row + 4) & 15;
-  return ((((q >> 3) ^ 1) << 2) | ((q >> 1) & 3));
-}
-__device__ __forceinline__ int swz_w(int row) { return (-(row >> 2)) & 3; }
-
-// bytes (2p, 2p+1) of `word` -> two 16-bit elements: 3 VALU ops
-template <int DT, int FMT>
-__device__ __forceinline__ uint32_t convert_pair(uint32_t word, int p) {
-  float f0, f1;
-  if constexpr (FMT == W_I8) {
-    f0 = p == 0 ? (float)(int8_t)(word & 0xFFu) : (float)(int8_t)((word >> 16) & 0xFFu);
-    f1 = p == 0 ? (float)(int8_t)((word >> 8) & 0xFFu) : (float)(int8_t)(word >> 24);
-  } else if constexpr (FMT == W_F8E4M3) {
-    const f32x2 v = p == 0 ? __builtin_amdgcn_cvt_pk_f32_fp8((int)word, false) : __builtin_amdgcn_cvt_pk_f32_fp8((int)word, true);
-    f0 = v.x;
-    f1 = v.y;
-  } else {
-    const f32x2 v = p == 0 ? __builtin_amdgcn_cvt_pk_f32_bf8((int)word, false) : __builtin_amdgcn_cvt_pk_f32_bf8((int)word, true);
-    f0 = v.x;
-    f1 = v.y;
-  }
-  return Mma<DT>::pack(f0, f1);
-}
 
 #ifdef QH_LT_STAMPS
 __device__ unsigned long long g_stamps[256 * 8];  // per workgroup: s_memrealtime (100 MHz) at entry / loop start / loop end / exit
@@ -101,37 +32,6 @@ __device__ unsigned long long g_stamps[256 * 8];  // per workgroup: s_memrealtim
 #else
 #define QH_LT_STAMP(i) do { } while (0)
 #endif
-
-struct Args {
-  const void* x;
-  const uint8_t* w;
-  const void* scale;
-  const void* bias;
-  void* y;
-  int M, N, K;
-  int group_m;  // tile raster: groups of group_m tile rows, column-major inside a group (see tile_coords)
-  // split-K (S > 1): workgroup b computes K-range b % S of tile b / S; fp32 partial sums go to `partials` and the last
-  // workgroup of a tile to arrive adds them in split order (same protocol and workspace contract as qbits_skinny.hip)
-  int S;
-  int* counters;    // [tiles], zero on entry, zero on exit
-  float* partials;  // [tiles * S][threads][NJ * MI] float4
-};
-
-// XCD-aware tile order.  Consecutive workgroup ids land on different XCDs (id % 8), so first give every XCD a contiguous
-// band of tile indices; inside the index space walk groups of `group_m` tile rows column by column, so that a band of
-// B = tiles/8 consecutive indices is a (group_m x B/group_m) rectangle: its activation panels (group_m) and weight panels
-// (B/group_m) are what that XCD's L2 has to fetch.  group_m ~ sqrt(B * bytes_per_weight_row / bytes_per_activation_row)
-// minimises the fetched bytes (cfg4, 128-tiles: 294 MB of fabric traffic per launch with row-major order).
-__device__ __forceinline__ void tile_coords(int bid, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
-  const int nwg = tiles_m * tiles_n;
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  const int per_group = group_m * tiles_n;
-  const int g = t / per_group, in_g = t - g * per_group;
-  const int rows = tiles_m - g * group_m < group_m ? tiles_m - g * group_m : group_m;
-  tn = in_g / rows;
-  tm = g * group_m + (in_g - tn * rows);
-}
 
 // f(integral_constant<int, 0>) ... f(integral_constant<int, R-1>): the weights-direct loop is unrolled over its ring slots
 template <int... Ps, class F>
@@ -597,7 +497,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   QH_LT_STAMP(6);
 }
 
-enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2, CFG_256_1X8 = 3 };
+enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2, CFG_256_1X8 = 3, CFG_256_MFMA32 = 4 /* qmm_mfma_large32.hip */ };
 
 template <int DT, int FMT, int BM, int BN, int WM, int WN, int WD = 0>
 static int launch_cfg(const Args& a, hipStream_t stream) {
@@ -647,6 +547,8 @@ static int launch(const Args& a, int cfg, hipStream_t stream) {
 }
 
 }  // namespace lt
+
+int qbytes_mm_mfma_large32(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, hipStream_t);
 
 bool qbytes_mfma_large_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
   const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2;
@@ -706,6 +608,7 @@ int qbytes_mm_mfma_large(const void* x, const void* w, const void* s, const void
   const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
   const int cfg = forced >= 0 ? forced : (tiles128 > 512 ? lt::CFG_256_8W : lt::CFG_128_4W);
   if (cfg != lt::CFG_128_4W) split = 1;  // the workspace is sized for 128-tiles
+  if (cfg == lt::CFG_256_MFMA32) return qbytes_mm_mfma_large32(x, w, s, bias, y, M, N, K, b_dtype, out_dtype, stream);
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
   lt::Args a{x, reinterpret_cast<const uint8_t*>(w), s, bias, y, (int)M, (int)N, (int)K, 1, split, reinterpret_cast<int*>(workspace),
              split > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + large_counter_bytes(M, N)) : nullptr};

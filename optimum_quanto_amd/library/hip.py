@@ -347,7 +347,7 @@ class QuantoHipExtension(NativeLibrary):
             "quanto_hip",
             root_dir=csrc,
             lib_path=os.path.join(_PKG_DIR, "lib", "libquanto_hip.so"),
-            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qmm_mfma_large.hip", "qbits_skinny.hip", "qbytes_skinny.hip", "qmm_native8.hip", "quantize.hip",
+            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qmm_mfma_large.hip", "qmm_mfma_large32.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbytes_skinny.hip", "qmm_native8.hip", "quantize.hip",
                      "qh_common.h", os.path.join("..", "..", "include", "quanto_hip.h")],
         )
         self._bindings = None

@@ -335,8 +335,11 @@ def qbytes_mm_ref(a, b, scales, dtype: str, fp8_kind: Optional[str] = None) -> n
 
 def qbytes_int_mm_ref(a_i8, b_i8, scales, dtype: str) -> np.ndarray:
     """library/qbytes_mm.py:36-50: int32 = A_i8 @ B_i8.T; (fp32(int32) * scales.T).to(dtype)."""
-    acc = np.matmul(a_i8.astype(np.int64), b_i8.astype(np.int64).T)
+    # float64 BLAS matmul of small integers is exact (every partial sum is an integer below 2^53) and, unlike numpy's integer
+    # matmul, multi-threaded: full BASELINE-size checks stay within seconds
+    acc = np.matmul(a_i8.astype(np.float64), b_i8.astype(np.float64).T)
     assert np.abs(acc).max() < 2**31
+    acc = acc.astype(np.int64)
     out = acc.astype(np.float32) * np.asarray(scales, np.float32).reshape(1, -1)
     return round_to(out, dtype)
 

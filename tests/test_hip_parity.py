@@ -406,18 +406,14 @@ def test_qbytes_golden_linear(golden):
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE sizes
-def _sample_rows_check(y, x, w_exact_fn, rows, dt, what):
-    want = w_exact_fn(x[rows])
-    assert_close_to_exact(y[rows], want, dt, what)
-
-
+# Every check below covers the WHOLE output: the float64 products run on the host's BLAS (seconds on the GPU box's cores), so a
+# ragged-edge or tile-raster bug confined to a few tiles cannot hide behind row sampling.
 def test_cfg2_bf16_int8_4096_cubed():
-    """BASELINE configs[1]: direct oracle check on 48 sampled rows + linearity over the full output."""
+    """BASELINE configs[1]: all 4096 x 4096 outputs against the float64 oracle + exact linearity."""
     p = make_qbytes_problem(4096, 4096, 4096, "bf16", None, seed=2)
     y = _run_qbytes(p, "auto")
     assert quanto_hip.lib.last_kernel() == "mfma_large"
-    rows = np.random.default_rng(0).choice(4096, 48, replace=False)
-    _sample_rows_check(y, p["x"], lambda xr: O.qbytes_mm_exact(xr, p["data"], p["scale"]), rows, "bf16", "cfg2")
+    assert_close_to_exact(y, O.qbytes_mm_exact(p["x"], p["data"], p["scale"]), "bf16", "cfg2 (all rows)")
     # size-independent property: y(2x) == 2 y(x) exactly (power-of-two scaling commutes with every rounding)
     p2 = dict(p, x=p["x"] * 2)
     np.testing.assert_array_equal(_run_qbytes(p2, "auto"), y * 2)
@@ -435,15 +431,15 @@ def test_cfg3_bf16_int4_decode(N, K):
 
 
 def test_cfg4_fp8_512x8192x8192():
+    """BASELINE configs[3] on one GPU: all 512 x 8192 outputs."""
     p = make_qbytes_problem(512, 8192, 8192, "bf16", "e4m3fn", seed=4)
     y = _run_qbytes(p, "auto")
-    rows = np.random.default_rng(1).choice(512, 32, replace=False)
-    _sample_rows_check(y, p["x"], lambda xr: O.qbytes_mm_exact(xr, p["data"], p["scale"], "e4m3fn"), rows, "bf16", "cfg4")
+    assert_close_to_exact(y, O.qbytes_mm_exact(p["x"], p["data"], p["scale"], "e4m3fn"), "bf16", "cfg4 (all rows)")
 
 
 def test_w8a8_int8_4096_cubed_bit_exact():
-    """bench workload w8a8 at full size: the i32 MFMA kernel is bit-identical to the exact integer reference on sampled rows
-    and, over the whole output, to the one-thread-per-output kernel of the same library."""
+    """bench workload w8a8 at full size: the i32 MFMA kernel is bit-identical to the exact integer reference over the whole
+    output (and therefore to the one-thread-per-output kernel of the same library)."""
     rng = np.random.default_rng(8)
     a = rng.integers(-128, 128, size=(4096, 4096), dtype=np.int8)
     b = rng.integers(-128, 128, size=(4096, 4096), dtype=np.int8)
@@ -451,33 +447,65 @@ def test_w8a8_int8_4096_cubed_bit_exact():
     ta, tb, ts = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), to_torch(s, "bf16", DEV)
     y = quanto_hip.lib.qbytes_mm(ta, tb, ts)
     assert quanto_hip.lib.last_kernel() == "mfma_native8"
-    rows = rng.choice(4096, 24, replace=False)
-    np.testing.assert_array_equal(to_numpy(y)[rows], O.qbytes_int_mm_ref(a[rows], b, s, "bf16"))
+    np.testing.assert_array_equal(to_numpy(y), O.qbytes_int_mm_ref(a, b, s, "bf16"))
     assert torch.equal(y, quanto_hip.lib.qbytes_mm(ta, tb, ts, kernel="naive"))
 
 
 def test_fp8a8_4096_cubed():
-    """bench workload fp8a8 at full size (K = 128 MX-format MFMA path): sampled rows against float64 math."""
+    """bench workload fp8a8 at full size (K = 128 MX-format MFMA path): every output against float64 math."""
     rng = np.random.default_rng(9)
     a = O.fp8_encode(rng.standard_normal((4096, 4096)).astype(np.float32), "e4m3fn")
     b = O.fp8_encode(rng.standard_normal((4096, 4096)).astype(np.float32), "e4m3fn")
     s = O.round_to(((rng.random((4096, 1)) + 0.5) / 1e2).astype(np.float32), "bf16")
     y = to_numpy(quanto_hip.lib.qbytes_mm(fp8_tensor(a, "e4m3fn", DEV), fp8_tensor(b, "e4m3fn", DEV), to_torch(s, "bf16", DEV)))
-    rows = rng.choice(4096, 24, replace=False)
-    want = np.matmul(O.fp8_decode(a[rows], "e4m3fn").astype(np.float64), O.fp8_decode(b, "e4m3fn").astype(np.float64).T)
-    assert_close_to_exact(y[rows], want * s.astype(np.float64).reshape(1, -1), "bf16", "fp8a8 4096^3")
+    want = np.matmul(O.fp8_decode(a, "e4m3fn").astype(np.float64), O.fp8_decode(b, "e4m3fn").astype(np.float64).T)
+    assert_close_to_exact(y, want * s.astype(np.float64).reshape(1, -1), "bf16", "fp8a8 4096^3 (all rows)")
 
 
 def test_int4_prefill_4096_cubed():
-    """bench workload int4_prefill at full size: dequantize + dense GEMM vs float64 math on the reference's rounded weight
-    (sampled rows), plus the power-of-two linearity property over the whole output."""
+    """bench workload int4_prefill at full size, whole output.  AUTO picks either the fused int4 GEMM (exact products of the
+    stored integers, scale / shift folded in fp32: gate = exact math) or dequantize + dense GEMM (multiplies the reference's
+    rounded weight: gate = float64 math on that weight); plus the power-of-two linearity property."""
     p = make_qbits_problem(4096, 4096, 4096, "bf16", seed=10)
     y = _run_qbits(p, "auto")
-    assert quanto_hip.lib.last_kernel() == "dequant_mfma"
-    rows = np.random.default_rng(2).choice(4096, 24, replace=False)
-    w = O.dequantize_qbits_ref(p["packed"], 4, p["scale"], p["shift"], 0, 128, (4096, 4096), "bf16").astype(np.float64)
-    assert_close_to_exact(y[rows], np.matmul(p["x"][rows].astype(np.float64), w.T), "bf16", "int4 prefill 4096^3")
+    kernel = quanto_hip.lib.last_kernel()
+    assert kernel in ("dequant_mfma", "mfma_fused4")
+    if kernel == "dequant_mfma":
+        w = O.dequantize_qbits_ref(p["packed"], 4, p["scale"], p["shift"], 0, 128, (4096, 4096), "bf16").astype(np.float64)
+        want = np.matmul(p["x"].astype(np.float64), w.T)
+    else:
+        want = _exact_qbits(p)
+    assert_close_to_exact(y, want, "bf16", f"int4 prefill 4096^3 via {kernel} (all rows)")
     np.testing.assert_array_equal(_run_qbits(dict(p, x=p["x"] * 2), "auto"), y * 2)
+
+
+@pytest.mark.parametrize("cfg", ["0", "2", "3", "4"])
+@pytest.mark.parametrize("shape", [(512, 512, 256), (300, 520, 192), (1024, 768, 4096), (257, 255, 128)])
+@pytest.mark.parametrize("kind,dt,bias", [(None, "bf16", False), ("e4m3fn", "bf16", True), (None, "fp16", True), ("e5m2", "fp16", False)])
+def test_large_tile_configurations(monkeypatch, cfg, shape, kind, dt, bias):
+    """Every tile configuration of the large-tile kernels, forced through the experiment knob (QUANTO_HIP_LARGE_CFG: 0 = 256^2 as
+    2x4 waves of 16x16x32 MFMAs, 2 = 128^2, 3 = 256^2 as 1x8, 4 = 256^2 on 32x32x16 MFMAs, qmm_mfma_large32.hip): ragged M / N,
+    short and long K, int8 / fp8 weights, both 16-bit dtypes, bias - whole output against the float64 oracle."""
+    monkeypatch.setenv("QUANTO_HIP_LARGE_CFG", cfg)
+    M, N, K = shape
+    p = make_qbytes_problem(M, N, K, dt, kind, seed=M + N + K)
+    b = O.round_to(np.random.default_rng(M).standard_normal(N).astype(np.float32), dt) if bias else None
+    y = _run_qbytes(p, "mfma_large", bias=b)
+    assert quanto_hip.lib.last_kernel() == "mfma_large"
+    exact = O.qbytes_mm_exact(p["x"], p["data"], p["scale"], kind)
+    if bias:
+        assert_close_with_bias(y, exact, b, dt, f"large cfg {cfg} {shape} {kind} {dt}")
+    else:
+        assert_close_to_exact(y, exact, dt, f"large cfg {cfg} {shape} {kind} {dt}")
+
+
+def test_cfg2_on_the_32x32x16_kernel(monkeypatch):
+    """The 4096^3 headline shape forced onto qmm_mfma_large32.hip: whole output + linearity."""
+    monkeypatch.setenv("QUANTO_HIP_LARGE_CFG", "4")
+    p = make_qbytes_problem(4096, 4096, 4096, "bf16", None, seed=12)
+    y = _run_qbytes(p, "mfma_large")
+    assert_close_to_exact(y, O.qbytes_mm_exact(p["x"], p["data"], p["scale"]), "bf16", "cfg2 on 32x32x16 (all rows)")
+    np.testing.assert_array_equal(_run_qbytes(dict(p, x=p["x"] * 2), "mfma_large"), y * 2)
 
 
 @pytest.mark.parametrize("M", [32, 160])
