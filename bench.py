@@ -63,6 +63,10 @@ WORKLOADS = {
     "fp8_4k": ("qbytes_f8", 4096, 4096, 4096, "bf16 x fp8-e4m3fn qbytes_mm, per-channel scale, (M,K,N)=(4096,4096,4096)"),
     "int8_decode": ("qbytes_i8", 1, 4096, 4096, "bf16 x int8 qbytes_mm, per-channel scale, decode (M,K,N)=(1,4096,4096)"),
     "int4_decode32": ("qbits_i4", 32, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,4096)"),
+    "int4_decode32_down": ("qbits_i4", 32, 14336, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,14336,4096)"),
+    "int4_decode8": ("qbits_i4", 8, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(8,4096,4096)"),
+    "int4_decode64": ("qbits_i4", 64, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(64,4096,4096)"),
+    "int8_decode32": ("qbytes_i8", 32, 4096, 4096, "bf16 x int8 qbytes_mm, per-channel scale, batched decode (M,K,N)=(32,4096,4096)"),
     "int4_decode32_up": ("qbits_i4", 32, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,14336)"),
 }
 DEFAULT_SUB = ["northstar", "cfg3", "qkv_fused", "gateup_fused"]

@@ -157,6 +157,10 @@ int64_t quanto_hip_qbits_mm_workspace_size(int64_t M, int64_t N, int64_t K, int 
                                            int kernel);
 /* The quanto_hip_kernel that QUANTO_HIP_KERNEL_AUTO resolves to for this problem when a sufficient workspace is given. */
 int quanto_hip_qbits_mm_pick(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype);
+/* Both answers in one call (a binding on the decode path makes one FFI round trip instead of two): resolves `kernel`
+ * (AUTO -> the kernel quanto_hip_qbits_mm_pick returns) into *kernel_out and its scratch bytes into *workspace_bytes_out. */
+int quanto_hip_qbits_mm_plan(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype, int kernel, int* kernel_out,
+                             int64_t* workspace_bytes_out);
 
 /*
  * quanto::qbytes_mm(Tensor A, Tensor B, Tensor scales) -> Tensor
@@ -182,6 +186,8 @@ int quanto_hip_qbytes_mm_ws(const void* a, const void* b, const void* scales, co
                             void* workspace, size_t workspace_bytes, void* stream);
 int64_t quanto_hip_qbytes_mm_workspace_size(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype, int kernel);
 int quanto_hip_qbytes_mm_pick(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype);
+int quanto_hip_qbytes_mm_plan(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype, int kernel, int* kernel_out,
+                              int64_t* workspace_bytes_out);
 
 /*
  * quanto::quantize_symmetric(Tensor base, ScalarType dtype, int? axis, Tensor scale) -> Tensor

@@ -172,6 +172,20 @@ int quanto_hip_qbits_mm_pick(int64_t M, int64_t N, int64_t K, int bits, int grou
   return pick_qbits_kernel(M, make_geom(N, K, bits, group_size), dtype, true);
 }
 
+int quanto_hip_qbits_mm_plan(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype, int kernel, int* kernel_out,
+                             int64_t* workspace_bytes_out) {
+  if (!kernel_out || !workspace_bytes_out) return QUANTO_HIP_EINVAL;
+  if (kernel == QUANTO_HIP_KERNEL_AUTO) {
+    kernel = quanto_hip_qbits_mm_pick(M, N, K, bits, group_size, dtype);
+    if (kernel < 0) return kernel;
+  }
+  const int64_t ws = quanto_hip_qbits_mm_workspace_size(M, N, K, bits, group_size, dtype, kernel);
+  if (ws < 0) return (int)ws;
+  *kernel_out = kernel;
+  *workspace_bytes_out = ws;
+  return QUANTO_HIP_OK;
+}
+
 int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t M,
                         int64_t N, int64_t K, int bits, int group_size, int dtype, int shift_dtype, int kernel, void* workspace,
                         size_t workspace_bytes, void* stream_) {
@@ -183,6 +197,12 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const PackedGeom g = make_geom(N, K, bits, group_size);
   if (kernel == QUANTO_HIP_KERNEL_AUTO) {
+    // the fast kernels need 16-byte aligned x / packed (views into larger buffers may not be): AUTO then takes the kernel that copes
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed)) % 16) {
+      const int r = qbits_mm_naive(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("naive");
+      return r;
+    }
     kernel = pick_qbits_kernel(M, g, dtype, workspace != nullptr);
     if (kernel == QUANTO_HIP_KERNEL_DEQUANT_MFMA && workspace_bytes < dequant_mfma_workspace(g))
       kernel = qbits_mfma_supported(M, g, dtype) ? QUANTO_HIP_KERNEL_MFMA : QUANTO_HIP_KERNEL_NAIVE;
@@ -283,6 +303,20 @@ int64_t quanto_hip_qbytes_mm_workspace_size(int64_t M, int64_t N, int64_t K, int
   return 0;
 }
 
+int quanto_hip_qbytes_mm_plan(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype, int kernel, int* kernel_out,
+                              int64_t* workspace_bytes_out) {
+  if (!kernel_out || !workspace_bytes_out) return QUANTO_HIP_EINVAL;
+  if (kernel == QUANTO_HIP_KERNEL_AUTO) {
+    kernel = quanto_hip_qbytes_mm_pick(M, N, K, a_dtype, b_dtype, out_dtype);
+    if (kernel < 0) return kernel;
+  }
+  const int64_t ws = quanto_hip_qbytes_mm_workspace_size(M, N, K, a_dtype, b_dtype, out_dtype, kernel);
+  if (ws < 0) return (int)ws;
+  *kernel_out = kernel;
+  *workspace_bytes_out = ws;
+  return QUANTO_HIP_OK;
+}
+
 int quanto_hip_qbytes_mm_ws(const void* a, const void* b, const void* scales, const void* bias, void* y, int64_t M, int64_t N, int64_t K,
                             int a_dtype, int b_dtype, int out_dtype, int kernel, void* workspace, size_t workspace_bytes, void* stream_) {
   if (M < 0 || N <= 0 || K <= 0) return QUANTO_HIP_EINVAL;
@@ -290,7 +324,11 @@ int quanto_hip_qbytes_mm_ws(const void* a, const void* b, const void* scales, co
   if (M == 0) return QUANTO_HIP_OK;
   if (!a || !b || !scales || !y) return QUANTO_HIP_EINVAL;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (kernel == QUANTO_HIP_KERNEL_AUTO) kernel = pick_qbytes_kernel(M, N, K, a_dtype, b_dtype, out_dtype);
+  if (kernel == QUANTO_HIP_KERNEL_AUTO) {
+    kernel = pick_qbytes_kernel(M, N, K, a_dtype, b_dtype, out_dtype);
+    // misaligned views: the kernel that has no alignment requirement
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16) kernel = QUANTO_HIP_KERNEL_NAIVE;
+  }
   int r;
   switch (kernel) {
     case QUANTO_HIP_KERNEL_NAIVE:

@@ -347,7 +347,9 @@ static int launch_s(const Args& a, hipStream_t stream) {
 // blocks budget for two (or three) blocks per CU.
 template <int DT, int TF, bool INT_SHIFT, int WAVES>
 static int launch(const Args& a, hipStream_t stream) {
-  const int budget = env_int("QUANTO_HIP_SKINNY_LDS_KB", WAVES == 4 ? 150 : 76) * 1024;  // experiments: smaller = more blocks per CU
+  // LDS budget per block: 50 KiB = three blocks per CU.  A deeper ring with the CU to itself is slower: (32,4096,4096) 11.5 us
+  // at 150 KiB, 11.0 at 76, 10.6 at 50; (32,4096,14336) split 2: 28.3 / 17.8 / 17.3 us
+  const int budget = env_int("QUANTO_HIP_SKINNY_LDS_KB", 50) * 1024;
   constexpr int per_tile = 1 + TF * 4 / WAVES;  // DMA instructions per wave and tile; vmcnt counts at most 63 of them
   if constexpr ((8 - 4) * per_tile <= 60)
     if (lds_bytes(TF, 8, a.G / a.S, WAVES) <= budget) return launch_s<DT, TF, 8, INT_SHIFT, WAVES>(a, stream);
@@ -359,15 +361,18 @@ static int launch(const Args& a, hipStream_t stream) {
 // waves per block: the widest that divides N.  Narrower blocks do not help small N (measured, N = 4096, M = 32: 4 waves
 // 21.9 us, 2 waves 21.8 us, 1 wave 26.1 us): the kernel is bound by the instruction stream of the single wave each SIMD gets,
 // not by the number of occupied CUs - what it lacks for N <= 4096 is K-parallelism.
-inline int pick_waves(int N) {
+inline int pick_waves(int N, int tf = 1) {
   const int forced = env_int("QUANTO_HIP_SKINNY_WAVES", 0);  // experiments
+  if (forced == 8 && tf >= 2 && N % 128 == 0) return 8;  // 128 features per block: half the activation traffic per weight byte
   if (forced == 1 || forced == 2 || forced == 4) return (N % (16 * forced)) == 0 ? forced : 1;
   return N % 64 == 0 ? 4 : (N % 32 == 0 ? 2 : 1);
 }
 
 template <int DT, bool INT_SHIFT, int TF>
 static int launch_waves(const Args& a, hipStream_t stream) {
-  const int w = pick_waves(a.N);
+  const int w = pick_waves(a.N, TF);
+  if constexpr (TF >= 2)
+    if (w == 8) return launch<DT, TF, INT_SHIFT, 8>(a, stream);
   if (w == 4) return launch<DT, TF, INT_SHIFT, 4>(a, stream);
   if (w == 2) return launch<DT, TF, INT_SHIFT, 2>(a, stream);
   return launch<DT, TF, INT_SHIFT, 1>(a, stream);
@@ -382,14 +387,18 @@ static int launch_tf(const Args& a, hipStream_t stream) {
 
 }  // namespace skinny
 
-// split factor: enough K-ranges that every SIMD of the chip gets a wave (N = 4096 alone gives 256 waves for 1024 SIMDs),
-// each range at least 4 groups long and the group count divisible by it
-static int skinny_split(const PackedGeom& g) {
+// Split factor.  r2 measurements (M = 32, K = 4096, us per launch, S = 1 / 2 / 4 / 8 with three blocks per CU): N = 4096
+// - / 13.6 / 10.6 / 12.3, N = 14336 22.4 (one block per CU) / 17.3 / 21.4 / 28.1: the best split gives the chip 250-500 blocks of
+// four waves (two to three co-resident blocks per CU hide each other's barrier and reduction stalls), never leaves a block
+// fewer than 8 groups (its DMA ring would barely fill) and must divide the group count.
+static int skinny_split(const PackedGeom& g, int64_t M) {
   const int forced = env_int("QUANTO_HIP_SKINNY_SPLIT", 0);  // experiments
-  const int waves = (int)(g.N / 16);
+  const int tf = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+  const int blocks = (int)(g.N / (16 * skinny::pick_waves((int)g.N, tf)));
   int s = 1;
-  while (s < 8 && waves * s * 2 <= 1024 && g.G % (s * 2) == 0 && g.G / (s * 2) >= 4) s *= 2;
+  while (s < 8 && blocks * s * 2 <= 512 && g.G % (s * 2) == 0 && g.G / (s * 2) >= 8) s *= 2;
   if (forced > 0 && g.G % forced == 0) s = forced;
+  if ((size_t)(g.N / 16) * 4 > QUANTO_HIP_WS_COUNTER_BYTES) s = 1;  // one counter per feature block of 16
   return s;
 }
 // The arrival counters of every split-K kernel of the library live in the same fixed-size region at the start of the
@@ -407,7 +416,7 @@ bool qbits_skinny_supported(int64_t M, const PackedGeom& g, int dtype) {
 
 // [counters (zero on entry, zero on exit) | fp32 partial sums]; 0 when the problem is not split
 size_t qbits_skinny_workspace(int64_t M, const PackedGeom& g) {
-  const int S = skinny_split(g);
+  const int S = skinny_split(g, M);
   if (S == 1) return 0;
   const int tf = M <= 16 ? 1 : (M <= 32 ? 2 : 4);  // M > 64 runs in passes of 64 rows, which reuse the workspace
   return skinny_counter_bytes(g) + (size_t)(g.N / 16) * S * 64 * tf * 16;
@@ -418,7 +427,7 @@ int qbits_mm_skinny(const void* x, const uint8_t* packed, const void* scale, con
   if (!qbits_skinny_supported(M, g, dtype)) return QUANTO_HIP_ENOTSUP;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed)) % 16) return QUANTO_HIP_EALIGN;
   // split-K only with a workspace (whose counter words the caller guarantees to be zero); without one: one block per feature block
-  int S = skinny_split(g);
+  int S = skinny_split(g, M > 64 ? 64 : M);
   if (S > 1 && (!workspace || workspace_bytes < qbits_skinny_workspace(M, g) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
   const size_t esize = 2;  // bf16 / fp16
   for (int64_t m0 = 0; m0 < M; m0 += 64) {  // passes of up to 64 rows (stream-ordered: each pass leaves the counters zero)

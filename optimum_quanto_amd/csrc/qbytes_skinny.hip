@@ -322,19 +322,21 @@ static int launch_s(const Args& a, hipStream_t stream) {
 
 template <int DT, int FMT>
 static int launch_tf(const Args& a, hipStream_t stream) {
-  // deepest ring within ~150 KiB: 8 stages of 12 / 16 KiB, 6 of 24 KiB
-  if (a.M <= 16) return launch_s<DT, FMT, 1, 8>(a, stream);
-  if (a.M <= 32) return launch_s<DT, FMT, 2, 8>(a, stream);
-  return launch_s<DT, FMT, 4, 6>(a, stream);
+  // ring depth: 4 stages (48 / 64 KiB: two to three blocks per CU, which hide each other's barrier and reduction stalls - see the
+  // measurements in qbits_skinny.hip) unless the experiment knob asks for the deep ring (8 stages, one block per CU)
+  const bool deep = env_int("QUANTO_HIP_SKINNY_LDS_KB", 50) >= 100;
+  if (a.M <= 16) return deep ? launch_s<DT, FMT, 1, 8>(a, stream) : launch_s<DT, FMT, 1, 4>(a, stream);
+  if (a.M <= 32) return deep ? launch_s<DT, FMT, 2, 8>(a, stream) : launch_s<DT, FMT, 2, 4>(a, stream);
+  return deep ? launch_s<DT, FMT, 4, 6>(a, stream) : launch_s<DT, FMT, 4, 4>(a, stream);
 }
 
 }  // namespace skinny8
 
 static int skinny8_split(int64_t N, int64_t K) {
   const int forced = env_int("QUANTO_HIP_SKINNY_SPLIT", 0);  // experiments
-  const int waves = (int)((N + 63) / 64) * 4, G = (int)(K / skinny8::BK);
-  int s = 1;
-  while (s < 8 && waves * s * 2 <= 1024 && G % (s * 2) == 0 && G / (s * 2) >= 4) s *= 2;
+  const int blocks = (int)((N + 63) / 64), G = (int)(K / skinny8::BK);
+  int s = 1;  // same rule as qbits_skinny.hip: 250-500 blocks, at least 8 tiles per block
+  while (s < 8 && blocks * s * 2 <= 512 && G % (s * 2) == 0 && G / (s * 2) >= 8) s *= 2;
   if (forced > 0 && G % forced == 0) s = forced;
   if ((size_t)((N + 63) / 64) * 4 > QUANTO_HIP_WS_COUNTER_BYTES) s = 1;  // one counter per feature block of 64
   return s;

@@ -73,6 +73,10 @@ class _Bindings:
                                                 ctypes.POINTER(vp), ctypes.POINTER(i64), i64, i64, ci, ci, ci, ci, vp]
         c.quanto_hip_qbits_mm_workspace_size.restype = i64
         c.quanto_hip_qbits_mm_workspace_size.argtypes = [i64, i64, i64, ci, ci, ci, ci]
+        c.quanto_hip_qbits_mm_plan.restype = ci
+        c.quanto_hip_qbits_mm_plan.argtypes = [i64, i64, i64, ci, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(i64)]
+        c.quanto_hip_qbytes_mm_plan.restype = ci
+        c.quanto_hip_qbytes_mm_plan.argtypes = [i64, i64, i64, ci, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(i64)]
         c.quanto_hip_qbits_mm_pick.restype = ci
         c.quanto_hip_qbits_mm_pick.argtypes = [i64, i64, i64, ci, ci, ci]
         c.quanto_hip_qbytes_mm.restype = ci
@@ -130,6 +134,20 @@ class _Bindings:
                     del cache[k]
             buf = torch.zeros((max(nbytes, 8 << 20),), dtype=torch.uint8, device=device)
             cache[key] = buf
+        return buf
+
+    def _scratch(self, device: torch.device, nbytes: int, stream) -> torch.Tensor:
+        """Uninitialised scratch (the dequantized weight of the prefill path, the row sums of the 128x128 kernel): one growing
+        buffer per (device, stream, capture) instead of an allocation per call; calls on one stream use it in stream order."""
+        cache = self.__dict__.setdefault("_scratch_ws", {})
+        capture = self._c.quanto_hip_stream_capture_id(ctypes.c_void_p(stream))
+        key = (device, stream, capture)
+        buf = cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if len(cache) > 64:
+                for k in [k for k in cache if k[2] != 0 and k != key]:
+                    del cache[k]
+            buf = cache[key] = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         return buf
 
     def last_kernel(self) -> str:
@@ -244,22 +262,19 @@ class _Bindings:
             bias = bias.to(scale.dtype).contiguous()
         M = x2.shape[0]
         y = torch.empty((M, out_features), dtype=scale.dtype, device=x.device)
-        k = KERNELS[kernel]
+        k_out, ws_out = ctypes.c_int(0), ctypes.c_int64(0)
         with torch.cuda.device(x.device):
-            if k == KERNEL_AUTO:
-                k = self._c.quanto_hip_qbits_mm_pick(M, out_features, in_features, bits, group_size or 0, _dt(scale))
-                if k < 0:
-                    self._check(k, "qbits_mm_pick")
-            ws_bytes = self._c.quanto_hip_qbits_mm_workspace_size(M, out_features, in_features, bits, group_size or 0,
-                                                                  _dt(scale), k)
-            if ws_bytes < 0:
-                self._check(int(ws_bytes), "qbits_mm_workspace_size")
+            st = self._c.quanto_hip_qbits_mm_plan(M, out_features, in_features, bits, group_size or 0, _dt(scale), KERNELS[kernel],
+                                                  ctypes.byref(k_out), ctypes.byref(ws_out))
+            if st != 0:
+                self._check(st, "qbits_mm_plan")
+            k, ws_bytes = k_out.value, ws_out.value
             if ws_bytes == 0:
                 ws = None
             elif k == KERNEL_SKINNY:
                 ws = self._zeroed_workspace(x.device, ws_bytes, self._stream(x).value)  # split-K arrival counters: zero on entry, left zero by the kernel
             else:
-                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+                ws = self._scratch(x.device, ws_bytes, self._stream(x).value)
             st = self._c.quanto_hip_qbits_mm(
                 _ptr(x2), _ptr(packed), _ptr(scale), _ptr(shift), _ptr(bias), _ptr(y), M, out_features, in_features,
                 bits, group_size or 0, _dt(scale), _dt(shift), k, _ptr(ws), ws_bytes, self._stream(x))
@@ -321,17 +336,15 @@ class _Bindings:
             bias = bias.to(scales.dtype).contiguous()
         M = a2.shape[0]
         y = torch.empty((M, N), dtype=scales.dtype, device=a.device)
-        k = KERNELS[kernel]
+        k_out, ws_out = ctypes.c_int(0), ctypes.c_int64(0)
         with torch.cuda.device(a.device):
-            if k == KERNEL_AUTO:
-                k = self._c.quanto_hip_qbytes_mm_pick(M, N, K, _dt(a2), _dt(b), _dt(s))
-                if k < 0:
-                    self._check(k, "qbytes_mm_pick")
-            ws, ws_bytes = None, 0
-            if k in (KERNEL_SKINNY, KERNEL_MFMA_LARGE):
-                ws_bytes = self._c.quanto_hip_qbytes_mm_workspace_size(M, N, K, _dt(a2), _dt(b), _dt(s), k)
-                if ws_bytes > 0:
-                    ws = self._zeroed_workspace(a.device, ws_bytes, self._stream(a).value)  # split-K arrival counters: zero on entry, left zero
+            st = self._c.quanto_hip_qbytes_mm_plan(M, N, K, _dt(a2), _dt(b), _dt(s), KERNELS[kernel], ctypes.byref(k_out), ctypes.byref(ws_out))
+            if st != 0:
+                self._check(st, "qbytes_mm_plan")
+            k, ws_bytes = k_out.value, ws_out.value
+            ws = None
+            if ws_bytes > 0:
+                ws = self._zeroed_workspace(a.device, ws_bytes, self._stream(a).value)  # split-K arrival counters: zero on entry, left zero
             st = self._c.quanto_hip_qbytes_mm_ws(_ptr(a2), _ptr(b), _ptr(s), _ptr(bias), _ptr(y), M, N, K, _dt(a2), _dt(b),
                                                  _dt(s), k, _ptr(ws), max(ws_bytes, 0), self._stream(a))
         self._check(st, "qbytes_mm")

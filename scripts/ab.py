@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--steps", type=int, default=0)
     ap.add_argument("--ramp-ms", type=float, default=200.0)
+    ap.add_argument("--sequential", action="store_true",
+                    help="each variant alone: ramp on its own graph, then all its rounds (its own steady clock / power state); default is "
+                         "interleaved rounds, where the variants share one clock state")
     args = ap.parse_args()
     name, values = args.env.split("=")
     values = values.split(",")
@@ -71,7 +74,20 @@ def main():
                 g.replay()
             torch.cuda.synchronize()
         times = {v: [] for v in values}
-        for _ in range(args.rounds):
+        if args.sequential:
+            for v in values:
+                t0 = time.perf_counter()
+                while (time.perf_counter() - t0) * 1e3 < args.ramp_ms:
+                    graphs[v].replay()
+                    torch.cuda.synchronize()
+                for _ in range(args.rounds):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    graphs[v].replay()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    times[v].append(e0.elapsed_time(e1) * 1e3 / steps)
+        for _ in range(0 if args.sequential else args.rounds):
             for v in values:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -82,7 +98,7 @@ def main():
         for v in values:
             med, mn = float(np.median(times[v])), float(np.min(times[v]))
             print(json.dumps({"workload": wl, name: v, "kernel": kernels[v], "us_median": round(med, 3), "us_min": round(mn, 3),
-                              "tflops": round(flops / med / 1e6, 1), "gbps": round(nbytes / med / 1e3, 1), "rounds": args.rounds, "steps": steps}), flush=True)
+                              "tflops": round(flops / med / 1e6, 1), "gbps": round(nbytes / med / 1e3, 1), "rounds": args.rounds, "steps": steps, "mode": "sequential" if args.sequential else "interleaved"}), flush=True)
         del graphs, sets
         torch.cuda.empty_cache()
 

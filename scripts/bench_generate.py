@@ -3,11 +3,15 @@
 
     python scripts/bench_generate.py [--layers 32] [--batch 1 32] [--prompt 512] [--new 128] [--weights qint4]
 
-Method follows the reference's bench/generation/metrics/latency.py:24-105 (greedy, fixed number of new tokens, device
-events) with two decode drivers:
-  * "eager": one Python-issued forward per token (what `generate()` does; host-bound at batch 1);
-  * "graph": the single-token forward (static KV cache) captured once in a hipGraph and replayed per token.
-Prints one JSON line per (batch, driver).  No network: the model is created from a config.
+Three drivers:
+  * "reference": the reference's own method, bench/generation/metrics/latency.py:24-94, call for call - ``model.generate`` with
+    ``GenerationConfig(max_new_tokens = min_new_tokens = 512, use_cache, num_beams=1, do_sample=False, eos_token_id=None)`` on a
+    random prompt of 512 tokens and an all-ones attention mask, device events around the whole call, mean over ``--iterations``
+    calls divided by the number of new tokens (so the prefill is inside the figure, as in the reference);
+  * "eager": one Python-issued forward per token on a static KV cache (decode only; host-bound at batch 1);
+  * "graph": the single-token forward (static KV cache) captured once in a hipGraph and replayed per token (decode only).
+``--fuse`` links sibling projections (q/k/v, gate/up) so that a decode step issues ONE ``quanto::qbits_mm_multi`` launch for them
+(optimum_quanto_amd.fuse_decode_projections).  Prints one JSON line per (batch, driver).  No network: the model is created from a config.
 """
 import argparse
 import json
@@ -40,6 +44,31 @@ def build_model(layers, weights, device):
     print(f"# model built in {t1 - t0:.1f}s, quantized in {time.time() - t1:.1f}s, "
           f"{torch.cuda.memory_allocated() / 2**30:.1f} GiB allocated", file=sys.stderr)
     return model, cfg
+
+
+@torch.no_grad()
+def run_reference_method(model, cfg, batch, prompt, new, iterations, device):
+    """bench/generation/metrics/latency.py:24-94 (tokenizer-free: pad_token_id only matters with an eos token, which is disabled)."""
+    from transformers import GenerationConfig
+
+    gen = GenerationConfig(max_new_tokens=new, min_new_tokens=new, use_cache=True, pad_token_id=0, num_beams=1, do_sample=False,
+                           eos_token_id=None)
+    if getattr(model, "generation_config", None) is not None:
+        model.generation_config.eos_token_id = None
+    torch.cuda.synchronize()
+    ids = torch.randint(1, cfg.vocab_size - 1, size=(batch, prompt)).to(device)
+    masks = torch.ones(batch, prompt, dtype=torch.int32).to(device)
+    lat = []
+    for _ in range(iterations):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        out = model.generate(ids, attention_mask=masks, generation_config=gen)
+        e1.record()
+        torch.cuda.synchronize()
+        assert out.shape[1] == prompt + new
+        lat.append(e0.elapsed_time(e1))
+    return lat
 
 
 @torch.no_grad()
@@ -88,18 +117,34 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--batch", type=int, nargs="+", default=[1, 32])
     ap.add_argument("--prompt", type=int, default=512)
-    ap.add_argument("--new", type=int, default=128)
+    ap.add_argument("--new", type=int, default=512)
     ap.add_argument("--weights", default="qint4")
-    ap.add_argument("--drivers", nargs="+", default=["eager", "graph"])
+    ap.add_argument("--drivers", nargs="+", default=["reference", "graph"])
+    ap.add_argument("--iterations", type=int, default=3, help="generate() calls per batch size for the reference method (the reference uses 10)")
+    ap.add_argument("--fuse", action="store_true", help="one launch for q/k/v and for gate/up at decode time")
     args = ap.parse_args()
     device = torch.device("cuda", 0)
     model, cfg = build_model(args.layers, args.weights, device)
+    linked = 0
+    if args.fuse:
+        import optimum_quanto_amd as Q
+
+        linked = Q.fuse_decode_projections(model)
     for b in args.batch:
         for d in args.drivers:
             try:
+                if d == "reference":
+                    lat = run_reference_method(model, cfg, b, args.prompt, args.new, args.iterations, device)
+                    mean_ms = sum(lat) / len(lat)
+                    print(json.dumps({"config": "Llama-3-8B random-init bf16", "layers": args.layers, "weights": args.weights, "batch": b,
+                                      "prompt": args.prompt, "new_tokens": args.new, "driver": "reference method (model.generate, prefill included)",
+                                      "fused_projection_groups": linked, "iterations": len(lat),
+                                      "latency_per_token_ms": round(mean_ms / args.new, 3),
+                                      "tokens_per_s": round(b * args.new / (mean_ms * 1e-3), 1)}), flush=True)
+                    continue
                 prefill_ms, decode_ms = run(model, cfg, b, args.prompt, args.new, d, device)
                 print(json.dumps({"config": "Llama-3-8B random-init bf16", "layers": args.layers, "weights": args.weights,
-                                  "batch": b, "prompt": args.prompt, "new_tokens": args.new, "driver": d,
+                                  "batch": b, "prompt": args.prompt, "new_tokens": args.new, "driver": d, "fused_projection_groups": linked,
                                   "prefill_ms": round(prefill_ms, 2), "ms_per_token": round(decode_ms / args.new, 3),
                                   "decode_tokens_per_s": round(b * args.new / (decode_ms * 1e-3), 1)}), flush=True)
             except Exception as e:  # keep going: one driver failing must not hide the other's number

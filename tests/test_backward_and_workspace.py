@@ -159,3 +159,27 @@ def test_split_k_inside_a_graph_capture_then_eager():
     torch.cuda.synchronize()
     for y in ys:
         assert_close_to_exact(to_numpy(y), want, "bf16", "graph replay")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 40])
+def test_auto_dispatch_accepts_misaligned_views(M):
+    """the fast kernels want 16-byte aligned x / weights; a view into a larger buffer may start anywhere.  AUTO must
+    then run the kernel without an alignment requirement instead of surfacing QUANTO_HIP_EALIGN."""
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    lib, dev = quanto_hip.lib, "cuda"
+    p = make_qbits_problem(M, 256, 512, "bf16", seed=M)
+    xbuf = torch.zeros(M * 512 + 8, dtype=torch.bfloat16, device=dev)
+    x = xbuf[1:1 + M * 512].view(M, 512)  # 2 bytes past a 16-byte boundary
+    x.copy_(to_torch(p["x"], "bf16", dev))
+    assert x.data_ptr() % 16 != 0
+    y = lib.qbits_mm(x, torch.from_numpy(p["packed"]).to(dev), to_torch(p["scale"], "bf16", dev), to_torch(p["shift"], "bf16", dev), None,
+                     4, 128, 256, 512)
+    assert lib.last_kernel() == "naive"
+    assert_close_to_exact(to_numpy(y), O.qbits_mm_exact(p["x"], p["packed"], 4, p["scale"], p["shift"], 128, 256, 512), "bf16", "misaligned qbits")
+    q = make_qbytes_problem(M, 256, 512, "bf16", None, seed=M)
+    x.copy_(to_torch(q["x"], "bf16", dev))
+    y = lib.qbytes_mm(x, torch.from_numpy(q["data"]).to(dev), to_torch(q["scale"], "bf16", dev))
+    assert lib.last_kernel() == "naive"
+    assert_close_to_exact(to_numpy(y), O.qbytes_mm_exact(q["x"], q["data"], q["scale"]), "bf16", "misaligned qbytes")

@@ -52,7 +52,9 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.quanto_hip_qbits_mm_workspace_size(40, 256, 512, 4, 64, 2, 0) == 8 * 128 * 4  # group size 64, small M: 128x128 kernel (row sums of x)
     # streaming MFMA kernel, N = 4096: 256 waves -> K split 4 ways; the fixed 4 KiB counter region (QUANTO_HIP_WS_COUNTER_BYTES) + fp32 partials (TF = 4)
     assert lib.quanto_hip_qbits_mm_workspace_size(64, 4096, 4096, 4, 128, 2, 0) == 4096 + 256 * 4 * 64 * 4 * 16
-    assert lib.quanto_hip_qbits_mm_workspace_size(64, 14336, 4096, 4, 128, 2, 0) == 0  # wide enough: not split
+    # N = 14336: 224 blocks of 64 features -> split 2 (448 blocks, two to three per CU)
+    assert lib.quanto_hip_qbits_mm_workspace_size(64, 14336, 4096, 4, 128, 2, 0) == 4096 + 896 * 2 * 64 * 4 * 16
+    assert lib.quanto_hip_qbits_mm_workspace_size(64, 32768, 4096, 4, 128, 2, 0) == 0  # wide enough: not split
     lib.quanto_hip_qbits_mm_pick.restype = ctypes.c_int
     lib.quanto_hip_qbits_mm_pick.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 3
     assert lib.quanto_hip_qbits_mm_pick(64, 4096, 4096, 4, 128, 2) == 5 and lib.quanto_hip_qbits_mm_pick(1, 4096, 4096, 4, 128, 2) == 2
@@ -85,7 +87,8 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.quanto_hip_qbytes_mm_ws(None, None, None, None, None, 0, 4, 64, 2, 3, 2, 0, None, 0, None) == 0   # M == 0
     lib.quanto_hip_qbytes_mm_workspace_size.restype = i64
     lib.quanto_hip_qbytes_mm_workspace_size.argtypes = [i64] * 3 + [ci] * 4
-    assert lib.quanto_hip_qbytes_mm_workspace_size(32, 14336, 4096, 2, 3, 2, 0) == 0           # wide N: not split
+    assert lib.quanto_hip_qbytes_mm_workspace_size(32, 14336, 4096, 2, 3, 2, 0) == 4096 + 224 * 2 * 256 * 2 * 16  # 224 blocks -> split 2
+    assert lib.quanto_hip_qbytes_mm_workspace_size(32, 32768, 4096, 2, 3, 2, 0) == 0           # wide N: not split
     assert lib.quanto_hip_qbytes_mm_workspace_size(32, 4096, 4096, 2, 3, 2, 0) == 4096 + 64 * 4 * 256 * 2 * 16  # fixed counter region, split 4, TF = 2
     assert lib.quanto_hip_qbytes_mm_workspace_size(4096, 4096, 4096, 2, 3, 2, 0) == 0          # 256-tiles: no workspace
     lib.quanto_hip_qbytes_mm_pick.argtypes = [i64] * 3 + [ci] * 3
