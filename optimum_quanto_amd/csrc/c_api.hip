@@ -243,7 +243,7 @@ int quanto_hip_qbits_mm_multi(const void* x, int count, const uint8_t* const* pa
                               const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int bits, int group_size,
                               int dtype, int shift_dtype, void* stream_) {
   if (count < 1 || count > QUANTO_HIP_MAX_MULTI || !packed || !scale || !shift || !y || !N) return QUANTO_HIP_EINVAL;
-  bool int_shift = false, one_launch = M >= 1 && M <= 4;
+  bool int_shift = false, one_launch = M >= 1 && M <= 4 && group_size == 128 && bits == 4;  // the fused launch serves int4 g128
   for (int i = 0; i < count; ++i) {
     const int st = check_qbits(M, N[i], K, bits, group_size, dtype, shift_dtype, &int_shift);
     if (st != QUANTO_HIP_OK) return st;

@@ -101,13 +101,25 @@ struct GemvSegs {
 template <int DT, int MT, int ITERS, bool INT_SHIFT, int VARIANT = 0, bool MULTI = false>
 __global__ void __launch_bounds__(256)
     qbits_gemv_g128_kernel(const uint16_t* __restrict__ x, const GemvSegs segs, int K,
-                           int wpr_log2 /* log2 of the waves cooperating on one row group: 0, 1 or 2 */) {
+                           int wpr_log2 /* log2 of the waves cooperating on one row group: 0, 1 or 2 */,
+                           int gshift /* VARIANT & 8 only: group of byte-column k = k >> gshift, or (k >> 5) / 3 when gshift < 0 */) {
   using E = Elem<DT>;
   using T = typename E::T;
   using D2 = Dot2<DT>;
-  __shared__ float red[4][RR][2][MT];
+  // bit 4 (with bit 3): qint2 weights - four planes per byte (byte (p,k) = W[p,k] | W[p+N/4,k] << 2 | W[p+N/2,k] << 4 |
+  // W[p+3N/4,k] << 6), 0x4300 | q is still exactly 128 + q: the same kernel with PL = 4 planes and a 2-bit mask
+  constexpr bool INT2 = (VARIANT & 16) != 0;
+  constexpr int BITS = INT2 ? 2 : 4, PL = 8 / BITS;
+  static_assert(!INT2 || (VARIANT & 8) != 0, "the int2 variant uses the per-lane scale fetch");
+  __shared__ float red[4][RR][PL][MT];
   constexpr bool EARLY_X = (VARIANT & 1) != 0, NT = (VARIANT & 2) != 0;
   constexpr bool ABLATE = (VARIANT & 4) != 0;  // measurement only (WRONG results): 1/4 of the arithmetic, all of the loads
+  // bit 3: any group size the reference's QModuleMixin selects (nn/qmodule.py:121-129: 128, else 96 / 64 / 32 when in_features
+  // is not a multiple of 128) and per-channel scales (group_size=None).  The packed layout is the same P[N/2][K] for every
+  // group size (tensor/packed.py + tensor/grouped.py: grouped row n*G + kg, byte offset n*K + k); only the scale / shift index
+  // changes: every lane fetches the entries of its own 16 byte-columns (16 divides every group size) for the block's RR rows,
+  // instead of the quad-shared fetch that needs 64-byte-aligned groups.
+  constexpr bool GEN_GS = (VARIANT & 8) != 0;
 
   // Prologue discipline: the call lasts a few microseconds, so nothing slow may sit in front of the first load - shifts
   // instead of divisions, and for the plain op (MULTI = false: segment 0, known at compile time) ONE round of scalar loads
@@ -127,14 +139,15 @@ __global__ void __launch_bounds__(256)
   uint16_t* __restrict__ y = segs.y[seg];
   const int N = segs.N[seg];
   const int seg_first = MULTI ? segs.first_block[seg] : 0;
-  const int P = N >> 1;
-  const int G = K >> 7;
+  const int P = INT2 ? N >> 2 : N >> 1;
+  auto group_of = [&](int k) -> int { return gshift >= 0 ? (k >> gshift) : (int)(((uint32_t)(k >> 5) * 0xAAABu) >> 17); };
+  const int G = GEN_GS ? group_of(K - 1) + 1 : K >> 7;
   const int p0 = (((bid - seg_first) << (2 - wpr_log2)) + rgroup) * RR;
   // ---- 1. request everything this wave will touch: weights, scales/shifts, x slice ---------------
   int k0[ITERS];
   bool valid[ITERS];
   uint4 W[RR][ITERS];
-  float sq[ITERS][2], zq[ITERS][2];
+  float sq[ITERS][2], zq[ITERS][2];  // quad-shared fetch (int4, group size 128)
   uint4 xa[ITERS][MT], xb[ITERS][MT];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
@@ -160,19 +173,40 @@ __global__ void __launch_bounds__(256)
       }
     }
   };
+  float sg[GEN_GS ? ITERS : 1][RR][PL], zg[GEN_GS ? ITERS : 1][RR][PL];  // GEN_GS: this lane's own entries per row
   auto load_small = [&]() {
-    // lane l fetches the entries of row (l & 3), group of its 16 bytes, both planes
-    const int rq = p0 + (lane & 3) < P ? p0 + (lane & 3) : P - 1;
+    if constexpr (GEN_GS) {
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
+      for (int it = 0; it < ITERS; ++it) {
+        const int grp = group_of(k0[it]);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const size_t idx = (size_t)(rq + h * P) * G + (k0[it] >> 7);
-        sq[it][h] = E::to_f32(__builtin_bit_cast(T, scale[idx]));
-        if constexpr (INT_SHIFT)
-          zq[it][h] = sq[it][h] * (float)(int8_t) reinterpret_cast<const uint8_t*>(shift_)[idx];
-        else
-          zq[it][h] = E::to_f32(__builtin_bit_cast(T, reinterpret_cast<const uint16_t*>(shift_)[idx]));
+        for (int r = 0; r < RR; ++r) {
+          const int pr = p0 + r < P ? p0 + r : P - 1;
+#pragma unroll
+          for (int h = 0; h < PL; ++h) {
+            const size_t idx = (size_t)(pr + h * P) * G + grp;
+            sg[it][r][h] = E::to_f32(__builtin_bit_cast(T, scale[idx]));
+            if constexpr (INT_SHIFT)
+              zg[it][r][h] = sg[it][r][h] * (float)(int8_t) reinterpret_cast<const uint8_t*>(shift_)[idx];
+            else
+              zg[it][r][h] = E::to_f32(__builtin_bit_cast(T, reinterpret_cast<const uint16_t*>(shift_)[idx]));
+          }
+        }
+      }
+    } else {
+      // lane l fetches the entries of row (l & 3), group of its 16 bytes, both planes
+      const int rq = p0 + (lane & 3) < P ? p0 + (lane & 3) : P - 1;
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const size_t idx = (size_t)(rq + h * P) * G + (k0[it] >> 7);
+          sq[it][h] = E::to_f32(__builtin_bit_cast(T, scale[idx]));
+          if constexpr (INT_SHIFT)
+            zq[it][h] = sq[it][h] * (float)(int8_t) reinterpret_cast<const uint8_t*>(shift_)[idx];
+          else
+            zq[it][h] = E::to_f32(__builtin_bit_cast(T, reinterpret_cast<const uint16_t*>(shift_)[idx]));
+        }
       }
     }
 #pragma unroll
@@ -217,55 +251,69 @@ __global__ void __launch_bounds__(256)
   // ---- 2. per row: dot products, scale, shift ------------------------------------------------------
   // v_and_or_b32 is VOP3: no literal operands on gfx9, at most one SGPR.  Keep the mask in an SGPR and the magic
   // exponent in a VGPR, opaque to the constant folder, so that (w & mask) | magic is ONE instruction.
-  uint32_t kmask = 0x000F000Fu, kmagic = D2::MAGIC;
+  uint32_t kmask = INT2 ? 0x00030003u : 0x000F000Fu, kmagic = D2::MAGIC;
   asm volatile("" : "+s"(kmask));
   asm volatile("" : "+v"(kmagic));
-  float acc[RR][2][MT];
+  float acc[RR][PL][MT];
 #pragma unroll
   for (int r = 0; r < RR; ++r)
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < PL; ++h)
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[r][h][m] = 0.f;
 
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    float s_r[RR][2], z_r[RR][2];
+    float s_r[RR][PL], z_r[RR][PL];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      s_r[0][h] = quad_bcast<0>(sq[it][h]);
-      s_r[1][h] = quad_bcast<1>(sq[it][h]);
-      s_r[2][h] = quad_bcast<2>(sq[it][h]);
-      s_r[3][h] = quad_bcast<3>(sq[it][h]);
-      z_r[0][h] = quad_bcast<0>(zq[it][h]);
-      z_r[1][h] = quad_bcast<1>(zq[it][h]);
-      z_r[2][h] = quad_bcast<2>(zq[it][h]);
-      z_r[3][h] = quad_bcast<3>(zq[it][h]);
+    for (int h = 0; h < PL; ++h) {
+      if constexpr (GEN_GS) {
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+          s_r[r][h] = sg[it][r][h];
+          z_r[r][h] = zg[it][r][h];
+        }
+      } else {
+        s_r[0][h] = quad_bcast<0>(sq[it][h]);
+        s_r[1][h] = quad_bcast<1>(sq[it][h]);
+        s_r[2][h] = quad_bcast<2>(sq[it][h]);
+        s_r[3][h] = quad_bcast<3>(sq[it][h]);
+        z_r[0][h] = quad_bcast<0>(zq[it][h]);
+        z_r[1][h] = quad_bcast<1>(zq[it][h]);
+        z_r[2][h] = quad_bcast<2>(zq[it][h]);
+        z_r[3][h] = quad_bcast<3>(zq[it][h]);
+      }
     }
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
-      float dot[2][MT];
+      float dot[PL][MT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) dot[0][m] = dot[1][m] = -D2::OFFSET * xs[it][m];
+      for (int h = 0; h < PL; ++h)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) dot[h][m] = -D2::OFFSET * xs[it][m];
       const uint32_t w4[4] = {W[r][it].x, W[r][it].y, W[r][it].z, W[r][it].w};
       if constexpr (ABLATE) asm volatile("" ::"v"(w4[1]), "v"(w4[2]), "v"(w4[3]));
 #pragma unroll
       for (int d = 0; d < (ABLATE ? 1 : 4); ++d) {
         const uint32_t w = w4[d];
-        const uint32_t lo02 = (w & kmask) | kmagic;
-        const uint32_t hi02 = ((w >> 4) & kmask) | kmagic;
-        const uint32_t lo13 = ((w >> 8) & kmask) | kmagic;
-        const uint32_t hi13 = ((w >> 12) & kmask) | kmagic;
+        // plane h of bytes 0 / 2 and of bytes 1 / 3 as (128 + q_a, 128 + q_b) pairs: one shift + one v_and_or each
+        uint32_t a02[PL], a13[PL];
+#pragma unroll
+        for (int h = 0; h < PL; ++h) {
+          a02[h] = ((h == 0 ? w : w >> (BITS * h)) & kmask) | kmagic;
+          a13[h] = ((w >> (8 + BITS * h)) & kmask) | kmagic;
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          dot[0][m] = D2::dot(lo02, X02[it][m][d], dot[0][m]);
-          dot[1][m] = D2::dot(hi02, X02[it][m][d], dot[1][m]);
-          dot[0][m] = D2::dot(lo13, X13[it][m][d], dot[0][m]);
-          dot[1][m] = D2::dot(hi13, X13[it][m][d], dot[1][m]);
+#pragma unroll
+          for (int h = 0; h < PL; ++h) {
+            dot[h][m] = D2::dot(a02[h], X02[it][m][d], dot[h][m]);
+            dot[h][m] = D2::dot(a13[h], X13[it][m][d], dot[h][m]);
+          }
         }
       }
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < PL; ++h)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
           acc[r][h][m] += s_r[r][h] * dot[h][m] - z_r[r][h] * xs[it][m];
@@ -276,20 +324,21 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
   for (int r = 0; r < RR; ++r)
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < PL; ++h)
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[r][h][m] = wave_sum_lane63(acc[r][h][m]);
   if (lane == 63) {
 #pragma unroll
     for (int r = 0; r < RR; ++r)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < PL; ++h)
 #pragma unroll
         for (int m = 0; m < MT; ++m) red[wave][r][h][m] = acc[r][h][m];
   }
   __syncthreads();
-  if (slab0 == 0 && lane < RR * 2 * MT) {
-    const int r = lane / (2 * MT), h = (lane / MT) & 1, m = lane % MT;
+  static_assert(RR * PL * MT <= 64, "one lane per output of the block's row group");
+  if (slab0 == 0 && lane < RR * PL * MT) {
+    const int r = lane / (PL * MT), h = (lane / MT) % PL, m = lane % MT;
     const int p = p0 + r;
     if (p < P) {
       float v = 0.f;
@@ -311,6 +360,8 @@ struct GemvProblem {
   const void* bias[MAX_SEGS];
   void* y[MAX_SEGS];
   int N[MAX_SEGS];
+  int gs;    // group size: 128 (quad-shared scale fetch), 32 / 64 / 96, or 0 = per-channel
+  int bits;  // 4, or 2 (always on the per-lane scale fetch)
 };
 
 static int gemv_variant() {
@@ -339,11 +390,13 @@ static int gemv_launch_iters(const void* x, const GemvProblem& pb, int m0, int K
     segs.y[i] = reinterpret_cast<uint16_t*>(pb.y[j]) + (size_t)m0 * pb.N[j];
     segs.N[i] = pb.N[j];
     segs.first_block[i] = i < pb.nseg ? grid : 0x7FFFFFFF;
-    if (i < pb.nseg) grid += (pb.N[i] / 2 + rows_per_block - 1) / rows_per_block;
+    if (i < pb.nseg) grid += (pb.N[i] / (8 / pb.bits) + rows_per_block - 1) / rows_per_block;
   }
   auto xs = reinterpret_cast<const uint16_t*>(x) + (size_t)m0 * K;
+  // group -> shift: 32 -> 5, 64 -> 6, 128 -> 7, per-channel -> 30 (always group 0), 96 -> -1 ((k >> 5) / 3)
+  const int gshift = pb.gs == 0 ? 30 : pb.gs == 96 ? -1 : pb.gs == 32 ? 5 : pb.gs == 64 ? 6 : 7;
 #define QH_LAUNCH_VM(IT, V, MULTI) \
-  hipLaunchKernelGGL((qbits_gemv_g128_kernel<DT, MT, IT, INT_SHIFT, V, MULTI>), dim3(grid), dim3(256), 0, stream, xs, segs, K, wpr_log2)
+  hipLaunchKernelGGL((qbits_gemv_g128_kernel<DT, MT, IT, INT_SHIFT, V, MULTI>), dim3(grid), dim3(256), 0, stream, xs, segs, K, wpr_log2, gshift)
 #define QH_LAUNCH_V(IT, V)                    \
   do {                                        \
     if constexpr (MT <= 4) {                  \
@@ -359,7 +412,11 @@ static int gemv_launch_iters(const void* x, const GemvProblem& pb, int m0, int K
   constexpr bool HAS_VARIANTS = DT == QUANTO_HIP_BF16 && MT == 1 && !INT_SHIFT;
 #define QH_LAUNCH(IT)                           \
   do {                                          \
-    if constexpr (HAS_VARIANTS) {               \
+    if (pb.bits == 2) {                         \
+      if constexpr (MT <= 4) QH_LAUNCH_VM(IT, 24, false); \
+    } else if (pb.gs != 128) {                  \
+      if constexpr (MT <= 4) QH_LAUNCH_VM(IT, 8, false); \
+    } else if constexpr (HAS_VARIANTS) {        \
       switch (gemv_variant()) {                 \
         case 1: QH_LAUNCH_V(IT, 1); break;      \
         case 2: QH_LAUNCH_V(IT, 2); break;      \
@@ -389,7 +446,7 @@ static int gemv_launch_iters(const void* x, const GemvProblem& pb, int m0, int K
 #undef QH_LAUNCH
 #undef QH_LAUNCH_V
 #undef QH_LAUNCH_VM
-  if (pb.nseg > 1 && MT > 4) return QUANTO_HIP_ENOTSUP;  // not reachable: the multi entry point is limited to M <= 4
+  if ((pb.nseg > 1 || pb.gs != 128 || pb.bits != 4) && MT > 4) return QUANTO_HIP_ENOTSUP;  // not reachable: those calls are limited to M <= 4
   return launch_status();
 }
 
@@ -421,8 +478,11 @@ static int gemv_launch_m(const void* x, const GemvProblem& pb, int M, int K, hip
 }
 
 bool qbits_gemv_supported(int64_t M, const PackedGeom& g, int dtype) {
-  return g.bits == 4 && g.C == 128 && (g.N % 2 == 0) && (g.K % 128 == 0) && g.K <= 16384 && M >= 1 &&
-         M <= QUANTO_HIP_GEMV_MAX_M_QBITS && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30);
+  const bool common = (g.N % g.vpi == 0) && g.K <= 16384 && M >= 1 && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30);
+  if (g.bits == 4 && g.C == 128) return common && (g.K % 128 == 0) && M <= QUANTO_HIP_GEMV_MAX_M_QBITS;
+  // the other group sizes of nn/qmodule.py:121-129 and per-channel scales: decode-sized calls only (M <= 4)
+  const bool other = g.C == 32 || g.C == 64 || g.C == 96 || g.C == 128 || (g.C == g.K && g.K % 16 == 0);
+  return common && other && (g.K % g.C == 0) && M <= 4;
 }
 
 static int gemv_dispatch(const void* x, const GemvProblem& pb, int M, int K, int dtype, bool int_shift, hipStream_t stream) {
@@ -443,6 +503,8 @@ int qbits_mm_gemv(const void* x, const uint8_t* packed, const void* scale, const
   pb.bias[0] = bias;
   pb.y[0] = y;
   pb.N[0] = (int)g.N;
+  pb.gs = g.C == g.K && g.C != 128 ? 0 : (int)g.C;
+  pb.bits = g.bits;
   return gemv_dispatch(x, pb, (int)M, (int)g.K, dtype, int_shift, stream);
 }
 
@@ -454,6 +516,8 @@ int qbits_mm_gemv_multi(const void* x, int nseg, const uint8_t* const* packed, c
   if (nseg < 1 || nseg > MAX_SEGS) return QUANTO_HIP_EINVAL;
   GemvProblem pb{};
   pb.nseg = nseg;
+  pb.gs = 128;
+  pb.bits = 4;
   uintptr_t align = reinterpret_cast<uintptr_t>(x);
   for (int i = 0; i < nseg; ++i) {
     pb.packed[i] = packed[i];

@@ -269,6 +269,8 @@ class _Bindings:
             if st != 0:
                 self._check(st, "qbits_mm_plan")
             k, ws_bytes = k_out.value, ws_out.value
+            if kernel == "auto" and (x2.data_ptr() | packed.data_ptr()) % 16:
+                k, ws_bytes = KERNEL_NAIVE, 0  # misaligned view: the kernel without an alignment requirement (what AUTO does in C)
             if ws_bytes == 0:
                 ws = None
             elif k == KERNEL_SKINNY:
@@ -342,6 +344,8 @@ class _Bindings:
             if st != 0:
                 self._check(st, "qbytes_mm_plan")
             k, ws_bytes = k_out.value, ws_out.value
+            if kernel == "auto" and (a2.data_ptr() | b.data_ptr()) % 16:
+                k, ws_bytes = KERNEL_NAIVE, 0  # misaligned view: the kernel without an alignment requirement (what AUTO does in C)
             ws = None
             if ws_bytes > 0:
                 ws = self._zeroed_workspace(a.device, ws_bytes, self._stream(a).value)  # split-K arrival counters: zero on entry, left zero

@@ -189,6 +189,35 @@ def test_qbits_naive_any_shape(dt, bits, gs, M, N, K, zp):
     assert_close_to_exact(y, want, dt, "auto")
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("zp", [False, True])
+@pytest.mark.parametrize("M,N,K,gs", [(1, 256, 1024, 64), (2, 130, 2048, 32), (3, 64, 1152, 96), (4, 512, 4096, 64), (1, 1024, 4128, 32),
+                                      (1, 256, 960, 96), (1, 64, 160, None), (4, 200, 4096, None), (1, 4096, 4096, 64)])
+def test_qbits_gemv_other_group_sizes(dt, zp, M, N, K, gs):
+    """The decode GEMV for the group sizes the reference's QModuleMixin falls back to when in_features is not a multiple of 128
+    (nn/qmodule.py:121-129: 96 / 64 / 32) and for per-channel int4 (group_size=None): exact-math gate, AUTO must pick it."""
+    p = make_qbits_problem(M, N, K, dt, group_size=gs, zeropoint=zp, seed=N + K)
+    y = _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "gemv"
+    assert_close_to_exact(y, _exact_qbits(p), dt, f"gemv group_size={gs} {M}x{K}x{N}")
+    bias = O.round_to(np.random.default_rng(5).standard_normal(N).astype(np.float32), dt)
+    assert_close_with_bias(_run_qbits(p, "gemv", bias), _exact_qbits(p), bias, dt, f"gemv group_size={gs} + bias")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("zp", [False, True])
+@pytest.mark.parametrize("M,N,K,gs", [(1, 256, 1024, 128), (2, 132, 2048, 64), (4, 512, 4096, 128), (1, 64, 160, None), (3, 1024, 1152, 96),
+                                      (1, 4096, 4096, 128)])
+def test_qbits_gemv_int2(dt, zp, M, N, K, gs):
+    """qint2 weights (four planes per byte) on the same decode kernel: exact-math gate."""
+    p = make_qbits_problem(M, N, K, dt, bits=2, group_size=gs, zeropoint=zp, seed=N + K + 2)
+    y = _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "gemv"
+    assert_close_to_exact(y, _exact_qbits(p), dt, f"gemv int2 group_size={gs} {M}x{K}x{N}")
+    bias = O.round_to(np.random.default_rng(6).standard_normal(N).astype(np.float32), dt)
+    assert_close_with_bias(_run_qbits(p, "gemv", bias), _exact_qbits(p), bias, dt, f"gemv int2 group_size={gs} + bias")
+
+
 def test_qbits_auto_picks_fast_kernels():
     p = make_qbits_problem(1, 256, 1024, "bf16")
     _run_qbits(p, "auto")
