@@ -61,7 +61,8 @@ typedef enum {
   QUANTO_HIP_KERNEL_MFMA_LARGE = 4, /* 256x256 tile, LDS-DMA pipeline (prefill-sized M and N)    */
   QUANTO_HIP_KERNEL_SKINNY = 5, /* qbits_mm: weight-streaming MFMA kernel for M <= QUANTO_HIP_SKINNY_MAX_M */
   QUANTO_HIP_KERNEL_NATIVE8 = 6, /* qbytes_mm with quantized activations: int8 x int8 (i32 MFMA) / fp8 x fp8 (fp8 MFMA) */
-  QUANTO_HIP_KERNEL_DEQUANT_MFMA = 7 /* qbits_mm, prefill-sized M: fused dequantize into the workspace + 256x256 dense MFMA GEMM */
+  QUANTO_HIP_KERNEL_DEQUANT_MFMA = 7, /* qbits_mm, large M: fused dequantize into the workspace + 256x256 dense MFMA GEMM */
+  QUANTO_HIP_KERNEL_MFMA_FUSED4 = 8   /* qbits_mm, prefill-sized M: packed int4 -> MFMA operands in registers, per-group fp32 fold */
 } quanto_hip_kernel;
 
 /* Split-K workspaces (SKINNY and MFMA_LARGE kernels) all share ONE layout: the first QUANTO_HIP_WS_COUNTER_BYTES bytes are
@@ -120,8 +121,10 @@ int quanto_hip_dequantize_qbits(const uint8_t* packed, const void* scale, const 
  *   The reference has no such op; its CUDA analogs are gemm_f16i4_awq / gemm_f16i4_marlin
  *   (library/extensions/cuda/__init__.py:82-121,170-202).
  * x: dtype[M, K]; packed/scale/shift as in quanto_hip_dequantize_qbits; bias: dtype[N] or NULL;
- * y: dtype[M, N].  dtype in {F32, F16, BF16}.  Accumulation is fp32; the dequantized weight is
- * never materialised in HBM.
+ * y: dtype[M, N].  dtype in {F32, F16, BF16}.  Accumulation is fp32.  Every kernel except DEQUANT_MFMA multiplies the stored
+ * integers exactly and applies scale / shift to the fp32 accumulator (the dequantized weight exists nowhere); DEQUANT_MFMA - what
+ * AUTO takes for large M, where one dequantize pass is amortised over thousands of rows - writes the reference's dequantized weight
+ * (bit-identical to QBitsDequantizer) into the caller's workspace and multiplies that, exactly as the reference does per call.
  */
 int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale, const void* shift,
                         const void* bias, void* y, int64_t M, int64_t N, int64_t K, int bits, int group_size,
@@ -146,7 +149,7 @@ int quanto_hip_qbits_mm_multi(const void* x, int count, const uint8_t* const* pa
  * Scratch bytes quanto_hip_qbits_mm needs for this problem (0 when the selected kernel needs none).
  * The caller allocates it (16-byte aligned), passes it as `workspace` and may reuse it for any later
  * call on the same stream.  The MFMA kernel stores the per-group row sums of x there
- * (fp32 [K/group_size][roundup(M,128)]); the DEQUANT_MFMA path stores the dequantized weight (dtype[N, K]).
+ * (fp32 [K/group_size][roundup(M,128)]; MFMA_FUSED4 needs no scratch); the DEQUANT_MFMA path stores the dequantized weight (dtype[N, K]).
  * The SKINNY kernel splits K across workgroups when N alone cannot occupy the chip: its workspace starts with
  * QUANTO_HIP_WS_COUNTER_BYTES bytes of arrival counters that MUST BE ZERO on entry (the kernel leaves them zero), followed by
  * fp32 partial sums; without a workspace it runs unsplit.  quanto_hip_qbits_mm_pick tells which kernel AUTO selects, so

@@ -48,6 +48,11 @@ size_t qbits_mfma_workspace(int64_t, const PackedGeom&);
 int qbits_mm_mfma(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, void*,
                   size_t, hipStream_t);
 
+bool qbits_mfma_fused_supported(int64_t, const PackedGeom&, int);
+size_t qbits_mfma_fused_workspace(int64_t, const PackedGeom&);
+int qbits_mm_mfma_fused(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, void*,
+                        size_t, hipStream_t);
+
 static bool is_float_dtype(int dt) { return dt == QUANTO_HIP_F32 || dt == QUANTO_HIP_F16 || dt == QUANTO_HIP_BF16; }
 
 static int check_qbits(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype, int shift_dtype, bool* int_shift) {
@@ -79,8 +84,20 @@ static bool prefer_gemv(int64_t M) { return M <= QUANTO_HIP_GEMV_MAX_M; }
 static bool dequant_mfma_supported(int64_t M, const PackedGeom& g, int dtype) { return dense_mm_large_supported(M, g.N, g.K, dtype); }
 static size_t dequant_mfma_workspace(const PackedGeom& g) { return (size_t)g.N * g.K * 2; }
 
+// Fused int4 GEMM (qbits_mfma_fused.hip) vs dequantize + dense GEMM, r2 measurements (us, fused / dequantize + dense):
+//   N = K = 4096:        M = 256 49 / 53, 512 51 / 53, 1024 54 / 54, 2048 102 / 83, 4096 227 / 112
+//   N = 14336, K = 4096: M = 256 53 / 68, 512 102 / 97, 1024 229 / 122
+// The fused kernel is bound by the bytes its workgroup pulls into the CU per tile (32 KiB of activations for 8 KiB of packed
+// weights), so it wins while its 128 x 128 tiles fit the chip in one round (<= 256 workgroups) and loses once the dequantize
+// pass is amortised over several rounds.  QUANTO_HIP_FUSED4_MAX_WGS overrides the round limit in experiments.
+static bool fused4_wins(int64_t M, const PackedGeom& g) {
+  const int64_t wgs = ((M + 127) / 128) * ((g.N + 127) / 128);
+  return M > 192 && wgs <= env_int("QUANTO_HIP_FUSED4_MAX_WGS", 256);
+}
+
 static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {
   if (M <= 4 && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
+  if (fused4_wins(M, g) && qbits_mfma_fused_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MFMA_FUSED4;
   // the streaming kernel's time grows with M (passes of 64 rows), dequantize + dense GEMM is flat in M up to 1024 rows:
   // (M, 4096, 4096) us streaming / dequantize + GEMM: M = 128 34 / 56, M = 256 66 / 54; (256, 14336, 4096) 116 / 79; but
   // (256, 4096, 14336) 127 / 167
@@ -162,6 +179,7 @@ int64_t quanto_hip_qbits_mm_workspace_size(int64_t M, int64_t N, int64_t K, int 
   if (kernel == QUANTO_HIP_KERNEL_SKINNY) return qbits_skinny_supported(M, g, dtype) ? (int64_t)qbits_skinny_workspace(M, g) : 0;
   if (kernel == QUANTO_HIP_KERNEL_MFMA) return qbits_mfma_supported(M, g, dtype) ? (int64_t)qbits_mfma_workspace(M, g) : 0;
   if (kernel == QUANTO_HIP_KERNEL_DEQUANT_MFMA) return dequant_mfma_supported(M, g, dtype) ? (int64_t)dequant_mfma_workspace(g) : 0;
+  if (kernel == QUANTO_HIP_KERNEL_MFMA_FUSED4) return qbits_mfma_fused_supported(M, g, dtype) ? (int64_t)qbits_mfma_fused_workspace(M, g) : 0;
   return 0;
 }
 
@@ -234,6 +252,10 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
     case QUANTO_HIP_KERNEL_SKINNY:
       r = qbits_mm_skinny(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, workspace, workspace_bytes, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("skinny");
+      return r;
+    case QUANTO_HIP_KERNEL_MFMA_FUSED4:
+      r = qbits_mm_mfma_fused(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, workspace, workspace_bytes, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("mfma_fused4");
       return r;
   }
   return QUANTO_HIP_EINVAL;

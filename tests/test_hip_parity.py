@@ -170,6 +170,35 @@ def test_qbits_dequant_mfma(dt, M, N, K, bits, gs, zp):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K,zp", [(200, 256, 512, False), (96, 128, 256, True), (300, 520, 384, False), (65, 8, 128, False),
+                                      (513, 1024, 1152, True), (1000, 2048, 2048, False)])
+def test_qbits_mfma_fused4(dt, M, N, K, zp):
+    """Fused int4 GEMM (qbits_mfma_fused.hip): packed nibbles -> MFMA operands in registers, scale / shift folded per group in
+    fp32; ragged M / N, short K (fewer tiles than the prefetch depth), zero-points, bias.  Oracle = exact math on the stored
+    integers (NOT the reference's rounded weight): this kernel never rounds a weight."""
+    p = make_qbits_problem(M, N, K, dt, zeropoint=zp, seed=M + N)
+    assert_close_to_exact(_run_qbits(p, "mfma_fused4"), _exact_qbits(p), dt, f"mfma_fused4 {M}x{K}x{N}")
+    # bias: the product rounded to the output dtype, the bias added, rounded again (the reference's order) - checked bit for bit
+    # against the kernel's own bias-free output, which the line above gates against exact math
+    bias = O.round_to(np.random.default_rng(4).standard_normal(N).astype(np.float32), dt)
+    y0 = _run_qbits(p, "mfma_fused4")
+    np.testing.assert_array_equal(_run_qbits(p, "mfma_fused4", bias), O.round_to((y0 + bias).astype(np.float32), dt))
+
+
+def test_qbits_mfma_fused4_llama_prefill():
+    """What AUTO picks for short prefills of a Llama-3-8B layer (one round of 128 x 128 tiles): the fused kernel; whole output
+    against exact math."""
+    for M, N, K in ((512, 4096, 4096), (256, 14336, 4096), (1024, 4096, 4096)):
+        p = make_qbits_problem(M, N, K, "bf16", seed=N + K)
+        y = _run_qbits(p, "auto")
+        assert quanto_hip.lib.last_kernel() == "mfma_fused4"
+        assert_close_to_exact(y, _exact_qbits(p), "bf16", f"auto -> mfma_fused4 {M}x{K}x{N}")
+    p = make_qbits_problem(512, 4096, 14336, "bf16", seed=7)  # K = 14336: the scale table does not fit the LDS next to the ring
+    y = _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "dequant_mfma"
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_qbits_mfma_zeropoint_and_bias(dt):
     p = make_qbits_problem(40, 256, 512, dt, zeropoint=True, seed=12)
     bias = O.round_to(np.random.default_rng(2).standard_normal(256).astype(np.float32), dt)

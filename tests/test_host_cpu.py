@@ -48,7 +48,10 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     lib.quanto_hip_qbits_mm_workspace_size.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 4
     assert lib.quanto_hip_qbits_mm_workspace_size(4096, 4096, 4096, 4, 128, 2, 0) == 4096 * 4096 * 2  # prefill: dequantized weight
     assert lib.quanto_hip_qbits_mm_workspace_size(4096, 4096, 4096, 4, 128, 2, 3) == 32 * 4096 * 4  # kernel MFMA: per-group row sums of x
-    assert lib.quanto_hip_qbits_mm_workspace_size(300, 256, 4096, 4, 128, 2, 0) == 256 * 4096 * 2  # above the streaming kernel's range
+    # above the streaming kernel's range, while one round of 128 x 128 tiles covers the problem: the fused int4 GEMM, no scratch at all
+    assert lib.quanto_hip_qbits_mm_workspace_size(300, 256, 4096, 4, 128, 2, 0) == 0
+    assert lib.quanto_hip_qbits_mm_pick(300, 256, 4096, 4, 128, 2) == 8
+    assert lib.quanto_hip_qbits_mm_workspace_size(300, 256, 4096, 4, 128, 2, 7) == 256 * 4096 * 2  # DEQUANT_MFMA: the dequantized weight
     assert lib.quanto_hip_qbits_mm_workspace_size(40, 256, 512, 4, 64, 2, 0) == 8 * 128 * 4  # group size 64, small M: 128x128 kernel (row sums of x)
     # streaming MFMA kernel, N = 4096: 256 waves -> K split 4 ways; the fixed 4 KiB counter region (QUANTO_HIP_WS_COUNTER_BYTES) + fp32 partials (TF = 4)
     assert lib.quanto_hip_qbits_mm_workspace_size(64, 4096, 4096, 4, 128, 2, 0) == 4096 + 256 * 4 * 64 * 4 * 16
@@ -59,9 +62,10 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     lib.quanto_hip_qbits_mm_pick.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 3
     assert lib.quanto_hip_qbits_mm_pick(64, 4096, 4096, 4, 128, 2) == 5 and lib.quanto_hip_qbits_mm_pick(1, 4096, 4096, 4, 128, 2) == 2
     # streaming kernel up to 192 rows (256 for long K, where one dequantize pass costs more than its extra passes), flat path above
-    assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 4, 128, 2) for m in (192, 256, 1024)] == [5, 7, 7]
-    assert lib.quanto_hip_qbits_mm_pick(256, 4096, 14336, 4, 128, 2) == 5
-    assert lib.quanto_hip_qbits_mm_workspace_size(256, 4096, 4096, 4, 128, 2, 0) == 4096 * 4096 * 2
+    # streaming kernel up to 192 rows, fused int4 GEMM while one round of tiles covers the problem, dequantize + dense GEMM beyond
+    assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 4, 128, 2) for m in (192, 256, 1024, 2048)] == [5, 8, 8, 7]
+    assert lib.quanto_hip_qbits_mm_pick(256, 4096, 14336, 4, 128, 2) == 5  # K = 14336: no room for the fused kernel's scale table
+    assert lib.quanto_hip_qbits_mm_workspace_size(2048, 4096, 4096, 4, 128, 2, 0) == 4096 * 4096 * 2
     assert lib.quanto_hip_qbits_mm_workspace_size(4, 4096, 4096, 4, 128, 2, 0) == 0
     assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 4, 128, 2, 0) == 0  # GEMV needs none
     assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 3, 128, 2, 0) == -1
