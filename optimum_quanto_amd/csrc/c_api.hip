@@ -89,10 +89,10 @@ static size_t dequant_mfma_workspace(const PackedGeom& g) { return (size_t)g.N *
 //   N = 14336, K = 4096: M = 256 53 / 68, 512 102 / 97, 1024 229 / 122
 // The fused kernel is bound by the bytes its workgroup pulls into the CU per tile (32 KiB of activations for 8 KiB of packed
 // weights), so it wins while its 128 x 128 tiles fit the chip in one round (<= 256 workgroups) and loses once the dequantize
-// pass is amortised over several rounds.  QUANTO_HIP_FUSED4_MAX_WGS overrides the round limit in experiments.
+// pass is amortised over several rounds or over thousands of rows (M <= 1024 measured).  QUANTO_HIP_FUSED4_MAX_WGS overrides the round limit in experiments.
 static bool fused4_wins(int64_t M, const PackedGeom& g) {
   const int64_t wgs = ((M + 127) / 128) * ((g.N + 127) / 128);
-  return M > 192 && wgs <= env_int("QUANTO_HIP_FUSED4_MAX_WGS", 256);
+  return M > 192 && M <= 1024 && wgs <= env_int("QUANTO_HIP_FUSED4_MAX_WGS", 256);
 }
 
 static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {
