@@ -69,7 +69,7 @@ def shard_bias(bias: Optional[torch.Tensor], qweight, rank: int, world_size: int
 
 def gather_columns(y_local: torch.Tensor, planes: int, group=None) -> torch.Tensor:
     """all_gather the ``[..., N/G]`` partial outputs and restore the global feature order."""
-    world_size = dist.get_world_size(group)
+    world_size = dist.get_world_size(group) if dist.is_initialized() else 1  # a single process needs no process group
     if world_size == 1:
         return y_local
     parts = [torch.empty_like(y_local) for _ in range(world_size)]
