@@ -104,6 +104,9 @@ struct Args {
   int* counters;    // [N / (16*WAVES)]
   float* partials;  // [blocks][WAVES*64 lanes][TF] float4
   int nt;           // non-temporal weight DMA (single-pass calls: M <= 64)
+  // QUANTO_HIP_SKINNY_ABLATE (timing experiments, WRONG results): 1 no split-K reduction, 2 no MFMA/LDS-read work,
+  // 4 no activation DMA, 8 no weight DMA, 16 no scale/shift table
+  int ablate;
 };
 
 // WAVES per block: 4 (64 features per block), 2 or 1 (16 features) - so that any N that is a multiple of 16 is served.
@@ -151,12 +154,14 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
   auto issue = [&](int kt, int stage) {
     const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
+    // ablations keep the instruction count per tile (vmcnt arithmetic) and re-read tile 0 instead: L2 hits
+    const int ktw = (a.ablate & 8) ? 0 : kt, ktx = (a.ablate & 4) ? 0 : kt;
     if (a.nt)
-      glds16_nt(wsrc + (size_t)kt * BK, st + wave * 1024);
+      glds16_nt(wsrc + (size_t)ktw * BK, st + wave * 1024);
     else
-      glds16(wsrc + (size_t)kt * BK, st + wave * 1024);
+      glds16(wsrc + (size_t)ktw * BK, st + wave * 1024);
 #pragma unroll
-    for (int u = 0; u < XP; ++u) glds16(xsrc[u] + (size_t)kt * (BK * 2), st + W_BYTES + (wave * XP + u) * 1024);
+    for (int u = 0; u < XP; ++u) glds16(xsrc[u] + (size_t)ktx * (BK * 2), st + W_BYTES + (wave * XP + u) * 1024);
   };
 #pragma unroll
   for (int t = 0; t < STAGES - 2; ++t)
@@ -166,7 +171,7 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
   // sz[g][0][f] = scale, sz[g][1][f] = shift (zero-points converted to T: small integers are exact),
   // f = plane*ROWS + local packed row; kept in the 16-bit storage type so that K = 14336 (112 groups) fits
   constexpr int NF = 2 * ROWS;  // features per block
-  for (int e = tid; e < NF * G; e += WAVES * 64) {
+  for (int e = tid; e < ((a.ablate & 16) ? 0 : NF * G); e += WAVES * 64) {
     const int f = e / G, g = e - f * G;
     const size_t idx = (size_t)(p0 + (f % ROWS) + (f / ROWS) * P) * a.G + kt0 + g;
     sz[(g * 2 + 0) * NF + f] = reinterpret_cast<const T*>(a.scale)[idx];
@@ -269,8 +274,10 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
       if (kt + STAGES - 2 < nk) issue(kt + STAGES - 2, s0);
       if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, s1);
     }
-    compute_tile(smem + cur * STAGE_BYTES, kt);
-    if (pair) compute_tile(smem + nxt * STAGE_BYTES, kt + 1);
+    if (!(a.ablate & 2)) {
+      compute_tile(smem + cur * STAGE_BYTES, kt);
+      if (pair) compute_tile(smem + nxt * STAGE_BYTES, kt + 1);
+    }
     cur = nxt + 1 == STAGES ? 0 : nxt + 1;
   }
 
@@ -279,7 +286,9 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
   // fence would be correct but writes back / invalidates a whole L2 (measured: 23 -> 57 us); instead the few KiB of partials
   // travel with system-coherent (sc0 sc1) 16-byte stores and loads and the only
   // ordering needed is "my stores are acknowledged (vmcnt(0)) before my workgroup's arrival is counted".
-  if (S > 1) {
+  if (S > 1 && (a.ablate & 1)) {
+    if (sp != 0) return;
+  } else if (S > 1) {
     float* mine = a.partials + ((size_t)blockIdx.x * (WAVES * 64) + tid) * (TF * 4);
 #pragma unroll
     for (int tf = 0; tf < TF; ++tf)  // s_nop: gfx9 hazard "VMEM store of > 64 bits, then VALU write of its data VGPRs" - hipcc cannot see into the asm
@@ -437,7 +446,7 @@ int qbits_mm_skinny(const void* x, const uint8_t* packed, const void* scale, con
                    reinterpret_cast<int*>(workspace),
                    S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr,
                    // later passes of a multi-pass call re-read the weights from the Infinity Cache: keep them cacheable there
-                   env_int("QUANTO_HIP_SKINNY_NT", M <= 64 ? 1 : 0)};
+                   env_int("QUANTO_HIP_SKINNY_NT", M <= 64 ? 1 : 0), env_int("QUANTO_HIP_SKINNY_ABLATE", 0)};
     int r;
     if (dtype == QUANTO_HIP_BF16)
       r = int_shift ? skinny::launch_tf<QUANTO_HIP_BF16, true>(a, stream) : skinny::launch_tf<QUANTO_HIP_BF16, false>(a, stream);
