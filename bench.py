@@ -65,6 +65,14 @@ WORKLOADS = {
     "int4_decode32": ("qbits_i4", 32, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,4096)"),
     "int4_decode32_down": ("qbits_i4", 32, 14336, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,14336,4096)"),
     "int4_decode8": ("qbits_i4", 8, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(8,4096,4096)"),
+    "int4_decode16": ("qbits_i4", 16, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(16,4096,4096)"),
+    "int4_decode8_up": ("qbits_i4", 8, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(8,4096,14336)"),
+    "int4_decode8_down": ("qbits_i4", 8, 14336, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(8,14336,4096)"),
+    "int4_decode16_up": ("qbits_i4", 16, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(16,4096,14336)"),
+    "int4_decode16_down": ("qbits_i4", 16, 14336, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(16,14336,4096)"),
+    "int4_decode8_kv": ("qbits_i4", 8, 4096, 1024, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(8,4096,1024)"),
+    "int4_decode8_13b": ("qbits_i4", 8, 5120, 5120, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(8,5120,5120)"),
+    "int4_decode8_70b": ("qbits_i4", 8, 8192, 8192, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(8,8192,8192)"),
     "int4_decode64": ("qbits_i4", 64, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(64,4096,4096)"),
     "int8_decode32": ("qbytes_i8", 32, 4096, 4096, "bf16 x int8 qbytes_mm, per-channel scale, batched decode (M,K,N)=(32,4096,4096)"),
     "int4_decode32_up": ("qbits_i4", 32, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,14336)"),

@@ -39,6 +39,8 @@ bool dense_mm_wd_supported(int64_t, int64_t, int64_t, int);
 int dense_mm_wd(const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, hipStream_t);
 bool qbytes_native8_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_native8(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
+bool qbits_mmv_supported(int64_t, const PackedGeom&, int);
+int qbits_mm_mmv(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, hipStream_t);
 bool qbits_skinny_supported(int64_t, const PackedGeom&, int);
 size_t qbits_skinny_workspace(int64_t, const PackedGeom&);
 int qbits_mm_skinny(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, void*,
@@ -95,8 +97,17 @@ static bool fused4_wins(int64_t M, const PackedGeom& g) {
   return M > 192 && M <= 1024 && wgs <= env_int("QUANTO_HIP_FUSED4_MAX_WGS", 256);
 }
 
+// The register-streaming kernel (K split inside the block, no split-K tail) against the LDS-streaming one, us per launch:
+// (8,4096,4096) 7.67 / 9.17, (16,4096,4096) 8.89 / 9.13, (8,4096,1024) 7.61 / 8.14; but every block re-reads all of x, so it
+// loses once the grid exceeds one block per CU or K grows: (8,5120,5120) 13.2 / 10.6, (8,8192,8192) 19.4 / 14.8,
+// (8,4096,14336) 15.9 / 13.9, (8,14336,4096) 19.5 / 15.0, (32,4096,4096) 12.2 / 10.7
+static bool mmv_wins(int64_t M, const PackedGeom& g) {
+  return M <= env_int("QUANTO_HIP_MMV_MAX_M", 16) && g.N <= env_int("QUANTO_HIP_MMV_MAX_N", 4096) && g.K <= 4096;
+}
+
 static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {
   if (M <= 4 && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
+  if (mmv_wins(M, g) && qbits_mmv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MMV;
   if (fused4_wins(M, g) && qbits_mfma_fused_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MFMA_FUSED4;
   // the streaming kernel's time grows with M (passes of 64 rows), dequantize + dense GEMM is flat in M up to 1024 rows:
   // (M, 4096, 4096) us streaming / dequantize + GEMM: M = 128 34 / 56, M = 256 66 / 54; (256, 14336, 4096) 116 / 79; but
@@ -252,6 +263,10 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
     case QUANTO_HIP_KERNEL_SKINNY:
       r = qbits_mm_skinny(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, workspace, workspace_bytes, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("skinny");
+      return r;
+    case QUANTO_HIP_KERNEL_MMV:
+      r = qbits_mm_mmv(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("mmv");
       return r;
     case QUANTO_HIP_KERNEL_MFMA_FUSED4:
       r = qbits_mm_mfma_fused(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, workspace, workspace_bytes, stream);

@@ -107,6 +107,9 @@ struct Args {
   // QUANTO_HIP_SKINNY_ABLATE (timing experiments, WRONG results): 1 no split-K reduction, 2 no MFMA/LDS-read work,
   // 4 no activation DMA, 8 no weight DMA, 16 no scale/shift table
   int ablate;
+  // QUANTO_HIP_SKINNY_TIMELINE=<device address of 32 x uint64 per block>: thread 0 of every block stamps s_memtime at the
+  // phase boundaries (scripts/skinny_timeline.py); null in production
+  unsigned long long* tl;
 };
 
 // WAVES per block: 4 (64 features per block), 2 or 1 (16 features) - so that any N that is a multiple of 16 is served.
@@ -126,6 +129,11 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto probe = [&](int slot) {
+    if (a.tl && tid == 0) a.tl[blockIdx.x * 32 + slot] = __builtin_readcyclecounter();
+  };
+  probe(0);
+  if (a.tl && tid == 0) a.tl[blockIdx.x * 32 + 30] = wall_clock64();
   const int M = a.M, N = a.N, K = a.K;
   const int P = N >> 1;
   const int S = a.S;
@@ -260,6 +268,7 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
   // Tiles are consumed in PAIRS per barrier: twice the work between synchronisations and two independent MFMA/LDS
   // chains for the scheduler to interleave.  Ring of STAGES (even) stages; tiles kt.. are in flight up to kt+STAGES-1.
   int cur = 0;
+  probe(1);
   for (int kt = 0; kt < nk; kt += 2) {
     const bool pair = kt + 1 < nk;
     // tiles kt (and kt+1) have landed when at most the DMA of the tiles younger than them is outstanding
@@ -268,6 +277,7 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
     wait_vmcnt<(STAGES - 4) * (1 + XP), 1 + XP>(younger);
     __builtin_amdgcn_s_barrier();  // both tiles visible to all; everybody is done with the previous pair (and the tables are written)
     asm volatile("" ::: "memory");
+    if (kt < 32) probe(3 + (kt >> 1));
     const int nxt = cur + 1 == STAGES ? 0 : cur + 1;
     {  // refill the two stages the previous pair occupied
       const int s0 = cur >= 2 ? cur - 2 : cur + STAGES - 2, s1 = s0 + 1 == STAGES ? 0 : s0 + 1;
@@ -286,6 +296,7 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
   // fence would be correct but writes back / invalidates a whole L2 (measured: 23 -> 57 us); instead the few KiB of partials
   // travel with system-coherent (sc0 sc1) 16-byte stores and loads and the only
   // ordering needed is "my stores are acknowledged (vmcnt(0)) before my workgroup's arrival is counted".
+  probe(20);
   if (S > 1 && (a.ablate & 1)) {
     if (sp != 0) return;
   } else if (S > 1) {
@@ -294,26 +305,41 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
     for (int tf = 0; tf < TF; ++tf)  // s_nop: gfx9 hazard "VMEM store of > 64 bits, then VALU write of its data VGPRs" - hipcc cannot see into the asm
       asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + tf * 4), "v"(acc[tf]) : "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    probe(21);
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem);
     if (tid == 0) *flag = __hip_atomic_fetch_add(a.counters + fb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
+    probe(22);
     if (*flag != S - 1) return;
     if (tid == 0) __hip_atomic_store(a.counters + fb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // leave the workspace as found
 #pragma unroll
     for (int tf = 0; tf < TF; ++tf) acc[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int q = 0; q < S; ++q) {  // fixed order: the result does not depend on which block arrived last
-      const float* theirs = a.partials + ((size_t)(fb * S + q) * (WAVES * 64) + tid) * (TF * 4);
-      f32x4 v[TF];
+    // fixed order: the result does not depend on which block arrived last.  The loads of up to four splits are in flight
+    // together (one fabric round trip per four splits instead of one per split)
+    for (int q0 = 0; q0 < S; q0 += 4) {
+      f32x4 v[4][TF];
 #pragma unroll
-      for (int tf = 0; tf < TF; ++tf) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[tf]) : "v"(theirs + tf * 4) : "memory");
+      for (int j = 0; j < 4; ++j) {
+        const int q = q0 + j < S ? q0 + j : S - 1;
+        const float* theirs = a.partials + ((size_t)(fb * S + q) * (WAVES * 64) + tid) * (TF * 4);
 #pragma unroll
-      for (int tf = 0; tf < TF; ++tf) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[tf])::"memory");  // ties the uses below to the wait
+        for (int tf = 0; tf < TF; ++tf) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[j][tf]) : "v"(theirs + tf * 4) : "memory");
+      }
 #pragma unroll
-      for (int tf = 0; tf < TF; ++tf)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[tf][r] += v[tf][r];
+        for (int tf = 0; tf < TF; ++tf) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[j][tf])::"memory");  // ties the uses below to the wait
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (q0 + j < S) {
+#pragma unroll
+          for (int tf = 0; tf < TF; ++tf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[tf][r] += v[j][tf][r];
+        }
     }
+    probe(23);
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------------
@@ -339,6 +365,8 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
       *reinterpret_cast<uint2*>(yg + (size_t)m * N + n0) = *reinterpret_cast<const uint2*>(out);
     }
   }
+  probe(24);
+  if (a.tl && tid == 0) a.tl[blockIdx.x * 32 + 31] = wall_clock64();
 }
 
 constexpr int lds_bytes(int tf, int stages, int G, int waves) { return stages * (waves * 8 * BK + tf * 16 * BK * 2) + G * 2 * (16 * waves) * 2; }
@@ -446,7 +474,8 @@ int qbits_mm_skinny(const void* x, const uint8_t* packed, const void* scale, con
                    reinterpret_cast<int*>(workspace),
                    S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr,
                    // later passes of a multi-pass call re-read the weights from the Infinity Cache: keep them cacheable there
-                   env_int("QUANTO_HIP_SKINNY_NT", M <= 64 ? 1 : 0), env_int("QUANTO_HIP_SKINNY_ABLATE", 0)};
+                   env_int("QUANTO_HIP_SKINNY_NT", M <= 64 ? 1 : 0), env_int("QUANTO_HIP_SKINNY_ABLATE", 0),
+                   reinterpret_cast<unsigned long long*>(env_ptr("QUANTO_HIP_SKINNY_TIMELINE"))};
     int r;
     if (dtype == QUANTO_HIP_BF16)
       r = int_shift ? skinny::launch_tf<QUANTO_HIP_BF16, true>(a, stream) : skinny::launch_tf<QUANTO_HIP_BF16, false>(a, stream);

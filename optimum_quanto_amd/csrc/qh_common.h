@@ -113,6 +113,11 @@ inline int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
+// debugging aid: a device address handed over as text (scripts/skinny_timeline.py), null when unset
+inline void* env_ptr(const char* name) {
+  const char* e = getenv(name);
+  return e ? reinterpret_cast<void*>(strtoull(e, nullptr, 0)) : nullptr;
+}
 
 int launch_status();  // hipGetLastError() -> quanto_hip_status (defined in c_api.hip)
 void set_last_kernel(const char* name);

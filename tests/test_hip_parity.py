@@ -134,6 +134,38 @@ def test_qbits_skinny(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M", [1, 5, 8, 16, 17, 31, 32])
+@pytest.mark.parametrize("N,K", [(64, 128), (256, 256), (128, 384), (512, 4096), (192, 14336), (1024, 1024), (48, 512), (80, 640)])
+def test_qbits_mmv(dt, M, N, K):
+    """Register-streaming MFMA kernel (GEMV structure, K split over the four waves of a block): one and two token fragments,
+    1..112 k-tiles (waves with no tile at all: K = 128, 384), ring prologue / refill / tail paths, ragged
+    M (clamped rows), N = 48 .. 1024."""
+    p = make_qbits_problem(M, N, K, dt, seed=M * 5 + N + K)
+    assert_close_to_exact(_run_qbits(p, "mmv"), _exact_qbits(p), dt, f"mmv {M}x{K}x{N}")
+    assert quanto_hip.lib.last_kernel() == "mmv"
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M", [7, 16, 29])
+def test_qbits_mmv_two_feature_groups_zeropoint_bias_and_dispatch(dt, M, monkeypatch):
+    """32 features per block (what wide N selects), integer zero-points, bias (exact bias-add sequence), and
+    that AUTO picks this kernel for decode batches up to 16."""
+    monkeypatch.setenv("QUANTO_HIP_MMV_FG", "2")
+    p = make_qbits_problem(M, 320, 1536, dt, zeropoint=True, seed=M)
+    bias = O.round_to(np.random.default_rng(2).standard_normal(320).astype(np.float32), dt)
+    y0 = _run_qbits(p, "mmv")
+    assert_close_to_exact(y0, _exact_qbits(p), dt, f"mmv fg2 {M}")
+    yb = _run_qbits(p, "mmv", bias)
+    want = O.round_to(O.round_to(y0.astype(np.float32), dt) + bias[None, :], dt)
+    np.testing.assert_array_equal(yb, want)
+    monkeypatch.delenv("QUANTO_HIP_MMV_FG")
+    p = make_qbits_problem(M, 256, 1024, dt, seed=M + 1)
+    y = _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == ("mmv" if M <= 16 else "skinny")
+    assert_close_to_exact(y, _exact_qbits(p), dt, f"auto {M}")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_qbits_skinny_zeropoint_and_bias(dt):
     p = make_qbits_problem(24, 256, 512, dt, zeropoint=True, seed=13)
     bias = O.round_to(np.random.default_rng(3).standard_normal(256).astype(np.float32), dt)

@@ -65,6 +65,9 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     # streaming kernel up to 192 rows, fused int4 GEMM while one round of tiles covers the problem, dequantize + dense GEMM beyond
     assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 4, 128, 2) for m in (192, 256, 1024, 2048)] == [5, 8, 8, 7]
     assert lib.quanto_hip_qbits_mm_pick(256, 4096, 14336, 4, 128, 2) == 5  # K = 14336: no room for the fused kernel's scale table
+    # small decode batches: the register-streaming kernel where one block per CU covers N, the LDS-streaming one elsewhere
+    assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 4, 128, 2) for m in (4, 5, 16, 17)] == [2, 9, 9, 5]
+    assert [lib.quanto_hip_qbits_mm_pick(8, n, k, 4, 128, 2) for n, k in ((1024, 4096), (14336, 4096), (4096, 14336), (5120, 5120))] == [9, 5, 5, 5]
     assert lib.quanto_hip_qbits_mm_workspace_size(2048, 4096, 4096, 4, 128, 2, 0) == 4096 * 4096 * 2
     assert lib.quanto_hip_qbits_mm_workspace_size(4, 4096, 4096, 4, 128, 2, 0) == 0
     assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 4, 128, 2, 0) == 0  # GEMV needs none
