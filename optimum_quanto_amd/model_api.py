@@ -64,18 +64,31 @@ def requantize(model: torch.nn.Module, state_dict: Dict[str, Any], quantization_
         weights = None if qconfig["weights"] == "none" else qconfig["weights"]
         activations = None if qconfig["activations"] == "none" else qconfig["activations"]
         _quantize_submodule(model, name, module, weights=weights, activations=activations)
-    # materialise parameters/buffers still on the meta device, then load
+    # Materialise what is still on the meta device, then load.  The float ``weight`` of a module whose quantized weight is in the
+    # state dict is never materialised (the reference stages everything on the CPU, quantize.py:123-137; on the device that would
+    # cost the full float model next to the quantized one): it stays on meta until ``load_state_dict(assign=True)`` replaces it.
+    def serialized(prefix: str) -> bool:
+        return any(k.startswith(prefix + "weight._") for k in state_dict)
+
     for name, m in model.named_modules():
         def move(t):
             if t.device.type == "meta":
                 return torch.empty_like(t, device=device)
             return t.to(device)
 
+        skip_weight = isinstance(m, QModuleMixin) and serialized(name + "." if name else "")
         for pname, p in list(m.named_parameters(recurse=False)):
+            if skip_weight and pname == "weight" and p.device.type == "meta":
+                continue
             setattr(m, pname, torch.nn.Parameter(move(p), requires_grad=p.requires_grad))
         for bname, b in list(m.named_buffers(recurse=False)):
             setattr(m, bname, move(b))
+    # dtype of the model's own (non-quantized) parameters wins over the checkpoint's, as with a copying load_state_dict
+    want = {k: v.dtype for k, v in list(model.named_parameters()) + list(model.named_buffers()) if v.device.type != "meta"}
     model.load_state_dict(state_dict, strict=False, assign=True)
+    for k, v in list(model.named_parameters()) + list(model.named_buffers()):
+        if k in want and type(v.data) is torch.Tensor and v.is_floating_point() and v.dtype != want[k]:
+            v.data = v.data.to(want[k])
     model.to(device)
 
 

@@ -221,6 +221,27 @@ def test_qlinear_quantize_freeze_state_dict_roundtrip():
     fresh = torch.nn.Sequential(torch.nn.Linear(256, 128), torch.nn.ReLU(), torch.nn.Linear(128, 64, bias=False))
     Q.requantize(fresh, sd, qmap)
     assert torch.equal(fresh(x), y)
+    # from the meta device (how a large checkpoint is opened): the float weight of a quantized module is never materialised
+    # - it goes from meta straight to the quantized tensor -, and a bf16 model keeps its dtype for what is not quantized
+    allocated = []
+    real_empty_like = torch.empty_like
+
+    def spy(t, *a, **kw):
+        out = real_empty_like(t, *a, **kw)
+        if out.device.type != "meta":
+            allocated.append(tuple(t.shape))
+        return out
+
+    with torch.device("meta"):
+        lazy = torch.nn.Sequential(torch.nn.Linear(256, 128), torch.nn.ReLU(), torch.nn.Linear(128, 64, bias=False)).to(torch.bfloat16)
+    torch.empty_like = spy
+    try:
+        Q.requantize(lazy, sd, qmap, device=torch.device("cpu"))
+    finally:
+        torch.empty_like = real_empty_like
+    assert (128, 256) not in allocated and (64, 128) in allocated, allocated
+    assert isinstance(lazy[0].weight, Q.WeightQBitsTensor) and lazy[2].weight.dtype == torch.bfloat16 and lazy[0].bias.dtype == torch.bfloat16
+    assert not any(p.device.type == "meta" for p in lazy.parameters())
 
 
 def test_group_size_selection_follows_reference():
