@@ -1,12 +1,12 @@
-"""Quantized module mixin (API of optimum/quanto/nn/qmodule.py:38-308) for the QLinear path.
+"""The quantized-module protocol of the QLinear path (public surface of optimum/quanto/nn/qmodule.py:38-308).
 
-``QModuleMixin`` keeps the float weight until ``freeze()`` replaces it by a ``WeightQBytesTensor`` /
-``WeightQBitsTensor`` parameter; ``qweight`` quantizes dynamically while unfrozen so gradients reach the float
-weight.  Group size selection (128, stepping down by 32 until it divides in_features) and the default scale
-optimizers are the reference's (qmodule.py:121-137) because they decide the layout the kernels read.
+A quantized module keeps its float ``weight`` until ``freeze()`` swaps in a ``WeightQBytesTensor`` / ``WeightQBitsTensor``
+parameter; before that ``qweight`` quantizes on the fly, so gradients still reach the float weight.  Two policies are taken
+over from the reference unchanged because they decide the byte layout the kernels read: the group size of sub-byte weights
+(qmodule.py:121-129) and the default scale search per bit width (qmodule.py:135-137).
 """
 from abc import ABC
-from typing import Optional, Union
+from typing import Dict, Optional, Type, Union
 
 import torch
 
@@ -15,165 +15,180 @@ from ..tensor import (AbsmaxOptimizer, ActivationQBytesTensor, MaxOptimizer, Opt
 
 __all__ = ["QModuleMixin", "register_qmodule", "quantize_module"]
 
-_QMODULE_TABLE = {}
+# float module class -> its quantized counterpart
+_counterparts: Dict[Type[torch.nn.Module], type] = {}
 
 
 def register_qmodule(module_cls):
-    """Class decorator: declare the quantized counterpart of ``module_cls`` (qmodule.py:44-78)."""
+    """``@register_qmodule(torch.nn.Linear)`` on a class declares it the quantized form of ``module_cls``."""
 
-    def wrapper(cls):
-        _QMODULE_TABLE[module_cls] = cls
-        return cls
+    def remember(qcls):
+        _counterparts[module_cls] = qcls
+        return qcls
 
-    return wrapper
+    return remember
 
 
 def quantize_module(module, weights=None, activations=None, optimizer: Optional[Optimizer] = None):
-    """Return the quantized version of ``module`` or None when its class has no registered counterpart."""
-    for cls, qcls in _QMODULE_TABLE.items():
-        if isinstance(module, cls):
-            return qcls.from_module(module, weights=weights, activations=activations, optimizer=optimizer)
-    return None
+    """The quantized twin of ``module`` (sharing its parameters), or None for a class nobody registered."""
+    qcls = next((q for base, q in _counterparts.items() if isinstance(module, base)), None)
+    return None if qcls is None else qcls.from_module(module, weights=weights, activations=activations, optimizer=optimizer)
 
 
-def _as_qtype(q: Optional[Union[qtype, str]]):
-    return q if (q is None or isinstance(q, qtype)) else qtypes[q]
+def _resolve(q: Optional[Union[qtype, str]]):
+    return qtypes[q] if isinstance(q, str) else q
 
 
 def select_group_size(in_features: int) -> Optional[int]:
-    """128 if possible, else the largest of 96/64/32 dividing ``in_features``; None -> per-channel (qmodule.py:121-129)."""
-    group_size = 128
-    if in_features <= group_size:
+    """Largest of 128 / 96 / 64 / 32 that divides ``in_features`` (strictly larger rows only); None means per-channel."""
+    if in_features <= 128:
         return None
-    while in_features % group_size != 0 and group_size > 32:
-        group_size -= 32
-    return group_size if in_features % group_size == 0 else None
+    return next((g for g in (128, 96, 64, 32) if in_features % g == 0), None)
+
+
+def _flat_weight_prefix(prefix: str) -> str:
+    return prefix + "weight."
 
 
 class QModuleMixin(ABC):
+    """Mix in FRONT of the torch.nn.Module class being quantized: ``class QLinear(QModuleMixin, torch.nn.Linear)``."""
+
     def __init__(self, *args, weights=None, activations=None, optimizer: Optional[Optimizer] = None,
                  quantize_input: Optional[bool] = False, device: Optional[torch.device] = None, **kwargs):
-        mro = self.__class__.__mro__
-        if torch.nn.Module not in mro:
-            raise TypeError("Quantized modules must inherit from a torch.nn.Module class")
-        if mro.index(__class__) > mro.index(torch.nn.Module):
-            raise TypeError("QModuleMixin must be placed before any torch.nn.Module class in quantized module inheritance.")
-        super().__init__(*args, device=device, **kwargs)
-        weights, activations = _as_qtype(weights), _as_qtype(activations)
-        self.weight_qtype = weights
-        self.weight_group_size = None
-        if weights in (qint2, qint4):
-            out_features = self.weight.shape[0]
-            self.weight_group_size = select_group_size(self.weight.numel() // out_features)
-        self.activation_qtype = activations
+        self._require_module_base()
+        super().__init__(*args, device=device, **kwargs)  # the torch.nn.Module constructor
+        self.weight_qtype = _resolve(weights)
+        self.activation_qtype = _resolve(activations)
+        self.weight_group_size = self._pick_group_size()
+        self.optimizer = optimizer if optimizer is not None else self._default_optimizer()
         self._quantize_hooks = {}
-        if activations is not None:
-            # inputs are quantized with `input_scale` before forward, outputs with `output_scale` after it
-            # (qmodule.py:131-134); both scales come from a Calibration pass
-            if quantize_input:
-                self._quantize_hooks["input"] = self.register_forward_pre_hook(self.quantize_input)
-            self._quantize_hooks["output"] = self.register_forward_hook(self.quantize_output)
-        if optimizer is None and weights is not None:
-            optimizer = AbsmaxOptimizer() if weights.bits == 8 else MaxOptimizer()
-        self.optimizer = optimizer
-        scale_dtype = torch.float32 if self.weight is None else self.weight.dtype
-        self.register_buffer("input_scale", torch.ones((), dtype=scale_dtype, device=device))
-        self.register_buffer("output_scale", torch.ones((), dtype=scale_dtype, device=device))
+        if self.activation_qtype is not None:
+            self._hook_activations(quantize_input)
+        # calibrated by a Calibration pass; scalars in the weight's dtype
+        dtype = self.weight.dtype if self.weight is not None else torch.float32
+        for name in ("input_scale", "output_scale"):
+            self.register_buffer(name, torch.ones((), dtype=dtype, device=device))
+
+    # -- construction helpers ----------------------------------------------------------------------------------------
+    def _require_module_base(self):
+        order = type(self).__mro__
+        if torch.nn.Module not in order:
+            raise TypeError("Quantized modules must inherit from a torch.nn.Module class")
+        if order.index(QModuleMixin) > order.index(torch.nn.Module):
+            raise TypeError("QModuleMixin must be placed before any torch.nn.Module class in quantized module inheritance.")
+
+    def _pick_group_size(self) -> Optional[int]:
+        if self.weight_qtype not in (qint2, qint4):
+            return None
+        rows = self.weight.shape[0]
+        return select_group_size(self.weight.numel() // rows)
+
+    def _default_optimizer(self) -> Optional[Optimizer]:
+        if self.weight_qtype is None:
+            return None
+        return AbsmaxOptimizer() if self.weight_qtype.bits == 8 else MaxOptimizer()
+
+    def _hook_activations(self, also_inputs: bool):
+        # outputs are always re-quantized with `output_scale`; inputs only on request (the first quantized module of a chain)
+        if also_inputs:
+            self._quantize_hooks["input"] = self.register_forward_pre_hook(self.quantize_input)
+        self._quantize_hooks["output"] = self.register_forward_hook(self.quantize_output)
 
     def disable_output_quantization(self):
-        hook = self._quantize_hooks.pop("output", None)
-        if hook is not None:
-            hook.remove()
+        handle = self._quantize_hooks.pop("output", None)
+        if handle is not None:
+            handle.remove()
 
-    # -- state dict: frozen weights are stored flattened (weight._data, weight._scale, ...) ------------
-    def _save_to_state_dict(self, destination, prefix, keep_vars):
-        if self.weight_qtype is None or not self.frozen:
-            destination[prefix + "weight"] = self.weight if (self.weight is None or keep_vars) else self.weight.detach()
-        else:
-            self.weight.save_to_state_dict(destination, prefix + "weight.", keep_vars)
-        if self.bias is not None:
-            destination[prefix + "bias"] = self.bias if keep_vars else self.bias.detach()
-        for name in ("input_scale", "output_scale"):
-            buf = getattr(self, name)
-            destination[prefix + name] = buf if keep_vars else buf.detach()
-
-    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
-        weight_name = prefix + "weight"
-        if self.weight_qtype is not None and weight_name not in state_dict:
-            # a frozen checkpoint: rebuild the QTensor from its flattened inner tensors (qmodule.py:161-207)
-            if self.weight_qtype.bits == 8:
-                qw = WeightQBytesTensor.load_from_state_dict(
-                    state_dict, weight_name + ".", qtype=self.weight_qtype, axis=0, size=self.weight.size(),
-                    stride=self.weight.stride(), activation_qtype=self.activation_qtype, missing_keys=missing_keys)
-            else:
-                qw = WeightQBitsTensor.load_from_state_dict(
-                    state_dict, weight_name + ".", qtype=self.weight_qtype, axis=0, group_size=self.weight_group_size,
-                    size=self.weight.size(), stride=self.weight.stride(), missing_keys=missing_keys)
-            if qw is not None:
-                qw = qw.optimize()
-                if local_metadata.get("assign_to_params_buffers", False):
-                    self.weight = torch.nn.Parameter(qw)
-                else:
-                    self.weight = torch.nn.Parameter(qw.to(self.weight.device))
-        super()._load_from_state_dict(state_dict, prefix, local_metadata, False, missing_keys, unexpected_keys, error_msgs)
-
-    # -- construction ---------------------------------------------------------------------------------
     @classmethod
     def from_module(cls, module: torch.nn.Module, weights=None, activations=None, optimizer: Optional[Optimizer] = None):
-        """Build on the meta device, then alias the float parameters of ``module`` (no copy) - qmodule.py:209-232."""
-        qmodule = cls.qcreate(module, weights, activations, optimizer, device="meta")
-        if qmodule is None:
+        """Quantized twin of ``module``: created without storage, then pointed at ``module``'s own parameters (no copy)."""
+        twin = cls.qcreate(module, weights, activations, optimizer, device="meta")
+        if twin is None:
             return None
-        device = torch.device("cpu") if module.weight is None else module.weight.device
-        qmodule = qmodule.to_empty(device=device)
-        qmodule.input_scale = torch.ones_like(qmodule.input_scale)
-        qmodule.output_scale = torch.ones_like(qmodule.output_scale)
+        where = module.weight.device if module.weight is not None else torch.device("cpu")
+        twin = twin.to_empty(device=where)
+        for name in ("input_scale", "output_scale"):  # to_empty left them uninitialised
+            setattr(twin, name, torch.ones_like(getattr(twin, name)))
         with torch.no_grad():
-            qmodule.weight = module.weight
+            twin.weight = module.weight
             if module.bias is not None:
-                qmodule.bias = module.bias
-        return qmodule.to(device)
+                twin.bias = module.bias
+        return twin.to(where)
 
     @classmethod
     def qcreate(cls, module, weights, activations=None, optimizer=None, device=None):
         raise NotImplementedError
 
-    # -- quantized weight -----------------------------------------------------------------------------
-    @property
-    def qweight(self):
-        """Frozen: the stored QTensor.  Unfrozen: quantize the float weight on the fly (qmodule.py:245-279)."""
-        if self.weight_qtype is None:
-            return None
-        if isinstance(self.weight, QTensor):
-            return self.weight
-        if isinstance(self.optimizer, SymmetricOptimizer):
-            scale, shift = self.optimizer(self.weight, qtype=self.weight_qtype, axis=0), None
-        else:
-            scale, shift = self.optimizer(self.weight, qtype=self.weight_qtype, axis=0, group_size=self.weight_group_size)
-        return quantize_weight(self.weight, qtype=self.weight_qtype, axis=0, scale=scale, shift=shift,
-                               group_size=self.weight_group_size, activation_qtype=self.activation_qtype)
-
     def qforward(self, input: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
 
-    # -- quantized activations (qmodule.py:281-299) -----------------------------------------------------
+    # -- weights ------------------------------------------------------------------------------------------------------------
+    @property
+    def frozen(self) -> bool:
+        return isinstance(self.weight, QTensor)
+
+    @property
+    def qweight(self):
+        """The weight as the kernels see it: the stored QTensor once frozen, a fresh quantization of the float weight before."""
+        if self.weight_qtype is None:
+            return None
+        if self.frozen:
+            return self.weight
+        search = dict(qtype=self.weight_qtype, axis=0)
+        if isinstance(self.optimizer, SymmetricOptimizer):
+            scale, shift = self.optimizer(self.weight, **search), None
+        else:
+            scale, shift = self.optimizer(self.weight, group_size=self.weight_group_size, **search)
+        return quantize_weight(self.weight, scale=scale, shift=shift, group_size=self.weight_group_size,
+                               activation_qtype=self.activation_qtype, **search)
+
+    def freeze(self):
+        quantized = self.qweight
+        if quantized is not None:
+            self.weight = torch.nn.Parameter(quantized)
+
+    # -- activations ----------------------------------------------------------------------------------------------------------
     def quantize_input(self, module: torch.nn.Module, input: torch.Tensor) -> torch.Tensor:
-        input = input[0]
-        if isinstance(input, ActivationQBytesTensor):
-            if input.qtype != self.activation_qtype:
-                raise ValueError("Models with heterogeneous quantized activations are not supported:"
-                                 f" expected {self.activation_qtype.name} input but got {input.qtype.name} instead.")
-            return input
-        return quantize_activation(input, qtype=self.activation_qtype, scale=self.input_scale)
+        (first,) = input[:1]
+        if not isinstance(first, ActivationQBytesTensor):
+            return quantize_activation(first, qtype=self.activation_qtype, scale=self.input_scale)
+        if first.qtype != self.activation_qtype:
+            raise ValueError("Models with heterogeneous quantized activations are not supported:"
+                             f" expected {self.activation_qtype.name} input but got {first.qtype.name} instead.")
+        return first
 
     def quantize_output(self, module: torch.nn.Module, input: torch.Tensor, output: torch.Tensor) -> torch.Tensor:
         return quantize_activation(output, qtype=self.activation_qtype, scale=self.output_scale)
 
-    def freeze(self):
-        qweight = self.qweight
-        if qweight is not None:
-            self.weight = torch.nn.Parameter(qweight)
+    # -- serialisation: a frozen weight travels as its inner tensors (weight._data, weight._scale, ...) -----------------------
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        def put(key, tensor):
+            destination[prefix + key] = tensor if (tensor is None or keep_vars) else tensor.detach()
 
-    @property
-    def frozen(self) -> bool:
-        return isinstance(self.weight, QTensor)
+        if self.frozen and self.weight_qtype is not None:
+            self.weight.save_to_state_dict(destination, _flat_weight_prefix(prefix), keep_vars)
+        else:
+            put("weight", self.weight)
+        if self.bias is not None:
+            put("bias", self.bias)
+        put("input_scale", self.input_scale)
+        put("output_scale", self.output_scale)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        flattened = self.weight_qtype is not None and (prefix + "weight") not in state_dict
+        if flattened:
+            rebuilt = self._weight_from_flat(state_dict, _flat_weight_prefix(prefix), missing_keys)
+            if rebuilt is not None:
+                rebuilt = rebuilt.optimize()  # the device-specific subclass, if one applies
+                if not local_metadata.get("assign_to_params_buffers", False):
+                    rebuilt = rebuilt.to(self.weight.device)
+                self.weight = torch.nn.Parameter(rebuilt)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, False, missing_keys, unexpected_keys, error_msgs)
+
+    def _weight_from_flat(self, state_dict, flat_prefix, missing_keys):
+        shape = dict(size=self.weight.size(), stride=self.weight.stride())
+        if self.weight_qtype.bits == 8:
+            return WeightQBytesTensor.load_from_state_dict(state_dict, flat_prefix, qtype=self.weight_qtype, axis=0,
+                                                           activation_qtype=self.activation_qtype, missing_keys=missing_keys, **shape)
+        return WeightQBitsTensor.load_from_state_dict(state_dict, flat_prefix, qtype=self.weight_qtype, axis=0,
+                                                      group_size=self.weight_group_size, missing_keys=missing_keys, **shape)
