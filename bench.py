@@ -54,6 +54,10 @@ WORKLOADS = {
     "cfg4": ("qbytes_f8", 512, 8192, 8192, "bf16 x fp8-e4m3fn qbytes_mm, per-channel scale, (M,K,N)=(512,8192,8192)"),
     "qkv_fused": ("qbits_i4_multi", 1, 4096, LLAMA3_QKV, "bf16 x int4 qbits_mm_multi, Llama-3-8B q/k/v in one launch, M=1, K=4096, N=4096+1024+1024"),
     "gateup_fused": ("qbits_i4_multi", 1, 4096, LLAMA3_GATE_UP, "bf16 x int4 qbits_mm_multi, Llama-3-8B gate/up in one launch, M=1, K=4096, N=2x14336"),
+    "qkv_fused8": ("qbits_i4_multi", 8, 4096, LLAMA3_QKV, "bf16 x int4 qbits_mm_multi, Llama-3-8B q/k/v in one launch, batched decode M=8"),
+    "qkv_fused32": ("qbits_i4_multi", 32, 4096, LLAMA3_QKV, "bf16 x int4 qbits_mm_multi, Llama-3-8B q/k/v in one launch, batched decode M=32"),
+    "gateup_fused8": ("qbits_i4_multi", 8, 4096, LLAMA3_GATE_UP, "bf16 x int4 qbits_mm_multi, Llama-3-8B gate/up in one launch, batched decode M=8"),
+    "gateup_fused32": ("qbits_i4_multi", 32, 4096, LLAMA3_GATE_UP, "bf16 x int4 qbits_mm_multi, Llama-3-8B gate/up in one launch, batched decode M=32"),
     # SURVEY.md 8f rank 1 (quantized activations) and the int4 prefill / batched-decode shapes of the same layer size
     "w8a8": ("qbytes_i8i8", 4096, 4096, 4096, "int8 x int8 qbytes_mm (quantized activations), int32 accumulate, (M,K,N)=(4096,4096,4096)"),
     "fp8a8": ("qbytes_f8f8", 4096, 4096, 4096, "fp8-e4m3fn x fp8-e4m3fn qbytes_mm (quantized activations), (M,K,N)=(4096,4096,4096)"),
@@ -77,7 +81,7 @@ WORKLOADS = {
     "int8_decode32": ("qbytes_i8", 32, 4096, 4096, "bf16 x int8 qbytes_mm, per-channel scale, batched decode (M,K,N)=(32,4096,4096)"),
     "int4_decode32_up": ("qbits_i4", 32, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,14336)"),
 }
-DEFAULT_SUB = ["northstar", "cfg3", "qkv_fused", "gateup_fused"]
+DEFAULT_SUB = ["northstar", "cfg3", "qkv_fused", "gateup_fused", "int4_decode32", "qkv_fused32"]
 ARITH_DTYPE = {"qbytes_i8": "bf16", "qbytes_f8": "bf16", "qbits_i4": "bf16", "qbits_i4_multi": "bf16", "qbytes_i8i8": "int8", "qbytes_f8f8": "fp8"}
 
 

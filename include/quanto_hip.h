@@ -138,13 +138,27 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
  * output features.  The reference issues one F.linear per module (nn/qlinear.py:49-50); its CUDA GEMV analog processes one
  * weight per launch as well (library/extensions/cuda/awq/v2/gemv_cuda.cu:220-308).  A decode-shaped (M <= 4) call is mostly
  * launch + first-byte latency, so when every W[i] is eligible for the GEMV kernel (quanto_hip_qbits_mm_pick says GEMV) all
- * products run in ONE kernel launch; otherwise this is exactly `count` quanto_hip_qbits_mm calls with KERNEL_AUTO and no
- * workspace.  Results are bit-identical to the separate calls.  The pointer arrays are HOST arrays of device pointers;
- * `bias` may be NULL or hold NULL entries.
+ * products run in ONE kernel launch, bit-identical to the separate calls.  Batched decode (4 < M <= 64, int4 group 128, every
+ * N[i] a multiple of 64) runs ONE launch of the streaming MFMA kernel over the feature blocks of all members: launch, first-byte
+ * latency and the split-K tail are paid once, and the wider grid needs a smaller split (results within the same exact-math gate
+ * as the separate calls; the summation order over K may differ).  Otherwise this is exactly `count` quanto_hip_qbits_mm calls
+ * with KERNEL_AUTO sharing the workspace.  The pointer arrays are HOST arrays of device pointers; `bias` may be NULL or hold
+ * NULL entries.  `_ws` takes the scratch buffer quanto_hip_qbits_mm_multi_workspace_size asks for (same contract as
+ * quanto_hip_qbits_mm's); the form without it never splits K.
  */
 int quanto_hip_qbits_mm_multi(const void* x, int count, const uint8_t* const* packed, const void* const* scale,
                               const void* const* shift, const void* const* bias, void* const* y, const int64_t* N, int64_t M,
                               int64_t K, int bits, int group_size, int dtype, int shift_dtype, void* stream);
+int quanto_hip_qbits_mm_multi_ws(const void* x, int count, const uint8_t* const* packed, const void* const* scale,
+                                 const void* const* shift, const void* const* bias, void* const* y, const int64_t* N, int64_t M,
+                                 int64_t K, int bits, int group_size, int dtype, int shift_dtype, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+int64_t quanto_hip_qbits_mm_multi_workspace_size(int count, const int64_t* N, int64_t M, int64_t K, int bits, int group_size,
+                                                 int dtype);
+/* What quanto_hip_qbits_mm_multi_ws will do: *kernel_out = QUANTO_HIP_KERNEL_GEMV or _SKINNY when all products run in one launch
+ * of that kernel (with *workspace_bytes_out of zeroed-counter scratch for the latter), QUANTO_HIP_KERNEL_AUTO for separate calls. */
+int quanto_hip_qbits_mm_multi_plan(int count, const int64_t* N, int64_t M, int64_t K, int bits, int group_size, int dtype,
+                                   int* kernel_out, int64_t* workspace_bytes_out);
 
 /*
  * Scratch bytes quanto_hip_qbits_mm needs for this problem (0 when the selected kernel needs none).

@@ -39,6 +39,10 @@ bool dense_mm_wd_supported(int64_t, int64_t, int64_t, int);
 int dense_mm_wd(const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, hipStream_t);
 bool qbytes_native8_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_native8(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
+bool qbits_skinny_multi_supported(int, const int64_t*, int64_t, int64_t, int);
+size_t qbits_skinny_multi_workspace(int, const int64_t*, int64_t, int64_t);
+int qbits_mm_skinny_multi(const void*, int, const uint8_t* const*, const void* const*, const void* const*, const void* const*, void* const*,
+                          const int64_t*, int64_t, int64_t, int, bool, void*, size_t, hipStream_t);
 bool qbits_mmv_supported(int64_t, const PackedGeom&, int);
 int qbits_mm_mmv(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, hipStream_t);
 bool qbits_skinny_supported(int64_t, const PackedGeom&, int);
@@ -276,9 +280,43 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
   return QUANTO_HIP_EINVAL;
 }
 
-int quanto_hip_qbits_mm_multi(const void* x, int count, const uint8_t* const* packed, const void* const* scale, const void* const* shift,
-                              const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int bits, int group_size,
-                              int dtype, int shift_dtype, void* stream_) {
+// one streaming-MFMA launch for the whole group pays when the members are small enough to be dominated by per-call costs
+static bool skinny_multi_applies(int count, const int64_t* N, int64_t M, int64_t K, int bits, int group_size, int dtype) {
+  return count >= 2 && bits == 4 && group_size == 128 && M > 4 && M <= env_int("QUANTO_HIP_SKINNY_MULTI_MAX_M", 64) &&
+         qbits_skinny_multi_supported(count, N, M, K, dtype);
+}
+
+int64_t quanto_hip_qbits_mm_multi_workspace_size(int count, const int64_t* N, int64_t M, int64_t K, int bits, int group_size, int dtype) {
+  if (count < 1 || count > QUANTO_HIP_MAX_MULTI || !N) return QUANTO_HIP_EINVAL;
+  if (skinny_multi_applies(count, N, M, K, bits, group_size, dtype)) return (int64_t)qbits_skinny_multi_workspace(count, N, M, K);
+  int64_t need = 0;  // separate calls, one after the other on the stream: they share the buffer
+  for (int i = 0; i < count; ++i) {
+    const int64_t w = quanto_hip_qbits_mm_workspace_size(M, N[i], K, bits, group_size, dtype, QUANTO_HIP_KERNEL_AUTO);
+    if (w < 0) return w;
+    need = w > need ? w : need;
+  }
+  return need;
+}
+
+int quanto_hip_qbits_mm_multi_plan(int count, const int64_t* N, int64_t M, int64_t K, int bits, int group_size, int dtype, int* kernel_out,
+                                   int64_t* workspace_bytes_out) {
+  if (count < 1 || count > QUANTO_HIP_MAX_MULTI || !N || !kernel_out || !workspace_bytes_out) return QUANTO_HIP_EINVAL;
+  bool gemv = M >= 1 && M <= 4 && group_size == 128 && bits == 4;
+  for (int i = 0; i < count; ++i) {
+    bool int_shift = false;
+    const int st = check_qbits(M, N[i], K, bits, group_size, dtype, dtype, &int_shift);
+    if (st != QUANTO_HIP_OK) return st;
+    gemv = gemv && qbits_gemv_supported(M, make_geom(N[i], K, bits, group_size), dtype);
+  }
+  const bool skinny = !gemv && skinny_multi_applies(count, N, M, K, bits, group_size, dtype);
+  *kernel_out = gemv ? QUANTO_HIP_KERNEL_GEMV : (skinny ? QUANTO_HIP_KERNEL_SKINNY : QUANTO_HIP_KERNEL_AUTO);
+  *workspace_bytes_out = skinny ? (int64_t)qbits_skinny_multi_workspace(count, N, M, K) : 0;
+  return QUANTO_HIP_OK;
+}
+
+int quanto_hip_qbits_mm_multi_ws(const void* x, int count, const uint8_t* const* packed, const void* const* scale, const void* const* shift,
+                                 const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int bits, int group_size,
+                                 int dtype, int shift_dtype, void* workspace, size_t workspace_bytes, void* stream_) {
   if (count < 1 || count > QUANTO_HIP_MAX_MULTI || !packed || !scale || !shift || !y || !N) return QUANTO_HIP_EINVAL;
   bool int_shift = false, one_launch = M >= 1 && M <= 4 && group_size == 128 && bits == 4;  // the fused launch serves int4 g128
   for (int i = 0; i < count; ++i) {
@@ -293,13 +331,23 @@ int quanto_hip_qbits_mm_multi(const void* x, int count, const uint8_t* const* pa
     const int r = qbits_mm_gemv_multi(x, count, packed, scale, shift, bias, y, N, M, K, dtype, int_shift, stream);
     if (r == QUANTO_HIP_OK) set_last_kernel("gemv_multi");
     if (r != QUANTO_HIP_EALIGN) return r;  // misaligned views: the separate calls below pick a kernel that copes
+  } else if (skinny_multi_applies(count, N, M, K, bits, group_size, dtype)) {
+    const int r = qbits_mm_skinny_multi(x, count, packed, scale, shift, bias, y, N, M, K, dtype, int_shift, workspace, workspace_bytes, stream);
+    if (r == QUANTO_HIP_OK) set_last_kernel("skinny_multi");
+    if (r != QUANTO_HIP_EALIGN) return r;
   }
   for (int i = 0; i < count; ++i) {
     const int r = quanto_hip_qbits_mm(x, packed[i], scale[i], shift[i], bias ? bias[i] : nullptr, y[i], M, N[i], K, bits, group_size, dtype,
-                                      shift_dtype, QUANTO_HIP_KERNEL_AUTO, nullptr, 0, stream_);
+                                      shift_dtype, QUANTO_HIP_KERNEL_AUTO, workspace, workspace_bytes, stream_);
     if (r != QUANTO_HIP_OK) return r;
   }
   return QUANTO_HIP_OK;
+}
+
+int quanto_hip_qbits_mm_multi(const void* x, int count, const uint8_t* const* packed, const void* const* scale, const void* const* shift,
+                              const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int bits, int group_size,
+                              int dtype, int shift_dtype, void* stream) {
+  return quanto_hip_qbits_mm_multi_ws(x, count, packed, scale, shift, bias, y, N, M, K, bits, group_size, dtype, shift_dtype, nullptr, 0, stream);
 }
 
 // qbytes_mm kernel choice (measured with bf16 x int8, hipGraph replay, N = K = 4096 unless noted):

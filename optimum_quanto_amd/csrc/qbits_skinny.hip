@@ -112,9 +112,23 @@ struct Args {
   unsigned long long* tl;
 };
 
+// Several Linears that share their input (q/k/v, gate/up) in ONE launch (MULTI): the feature blocks of all segments form one
+// grid, a block looks its segment up and takes weight / scale / shift / bias / output pointers and N from it.  x, M, K, the
+// split and the workspace are common; counters are indexed by the global feature block.
+constexpr int MAX_SEGS = QUANTO_HIP_MAX_MULTI;
+struct Segs {
+  const uint8_t* w[MAX_SEGS];
+  const void* scale[MAX_SEGS];
+  const void* shift[MAX_SEGS];
+  const void* bias[MAX_SEGS];
+  void* y[MAX_SEGS];
+  int N[MAX_SEGS];
+  int first_fb[MAX_SEGS];  // first feature block of each segment (INT_MAX for unused slots)
+};
+
 // WAVES per block: 4 (64 features per block), 2 or 1 (16 features) - so that any N that is a multiple of 16 is served.
-template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) {
+template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI = false>
+__global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(Args a, const Segs segs) {
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
@@ -134,10 +148,23 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
   };
   probe(0);
   if (a.tl && tid == 0) a.tl[blockIdx.x * 32 + 30] = wall_clock64();
+  const int S = a.S;
+  const int fbg = S > 1 ? blockIdx.x / S : blockIdx.x, sp = S > 1 ? blockIdx.x - fbg * S : 0;  // global feature block
+  int fb = fbg;
+  if constexpr (MULTI) {
+    int seg = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_SEGS; ++i) seg += fbg >= segs.first_fb[i];
+    fb = fbg - segs.first_fb[seg];
+    a.w = segs.w[seg];
+    a.scale = segs.scale[seg];
+    a.shift = segs.shift[seg];
+    a.bias = segs.bias[seg];
+    a.y = segs.y[seg];
+    a.N = segs.N[seg];
+  }
   const int M = a.M, N = a.N, K = a.K;
   const int P = N >> 1;
-  const int S = a.S;
-  const int fb = S > 1 ? blockIdx.x / S : blockIdx.x, sp = S > 1 ? blockIdx.x - fb * S : 0;
   const int p0 = fb * ROWS;
   const int nk = K / BK / S;   // tiles (= groups) of this block's K-range
   const int kt0 = sp * nk;     // first global tile / group index
@@ -308,11 +335,11 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
     probe(21);
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem);
-    if (tid == 0) *flag = __hip_atomic_fetch_add(a.counters + fb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) *flag = __hip_atomic_fetch_add(a.counters + fbg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
     probe(22);
     if (*flag != S - 1) return;
-    if (tid == 0) __hip_atomic_store(a.counters + fb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // leave the workspace as found
+    if (tid == 0) __hip_atomic_store(a.counters + fbg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // leave the workspace as found
 #pragma unroll
     for (int tf = 0; tf < TF; ++tf) acc[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
     // fixed order: the result does not depend on which block arrived last.  The loads of up to four splits are in flight
@@ -322,7 +349,7 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int q = q0 + j < S ? q0 + j : S - 1;
-        const float* theirs = a.partials + ((size_t)(fb * S + q) * (WAVES * 64) + tid) * (TF * 4);
+        const float* theirs = a.partials + ((size_t)(fbg * S + q) * (WAVES * 64) + tid) * (TF * 4);
 #pragma unroll
         for (int tf = 0; tf < TF; ++tf) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[j][tf]) : "v"(theirs + tf * 4) : "memory");
       }
@@ -371,28 +398,37 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(const Args a) 
 
 constexpr int lds_bytes(int tf, int stages, int G, int waves) { return stages * (waves * 8 * BK + tf * 16 * BK * 2) + G * 2 * (16 * waves) * 2; }
 
+// `segs` (with the total number of feature blocks) selects the multi-Linear launch; 4-wave blocks only
 template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES>
-static int launch_s(const Args& a, hipStream_t stream) {
+static int launch_s(const Args& a, hipStream_t stream, const Segs* segs = nullptr, int total_fb = 0) {
   const int lds = lds_bytes(TF, STAGES, a.G / a.S, WAVES);
+  if constexpr (WAVES == 4) {
+    if (segs) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, 4, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, 4, true>), dim3(total_fb * a.S), dim3(256), lds, stream, a, *segs);
+      return launch_status();
+    }
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES>), dim3(a.N / (16 * WAVES) * a.S), dim3(WAVES * 64), lds, stream, a);
+  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES>), dim3(a.N / (16 * WAVES) * a.S), dim3(WAVES * 64), lds, stream, a, Segs{});
   return launch_status();
 }
 
 // Deepest DMA pipeline that fits: the kernel is latency-bound per block (bytes in flight = stages x tile bytes).  Narrow
 // blocks budget for two (or three) blocks per CU.
 template <int DT, int TF, bool INT_SHIFT, int WAVES>
-static int launch(const Args& a, hipStream_t stream) {
+static int launch(const Args& a, hipStream_t stream, const Segs* segs = nullptr, int total_fb = 0) {
   // LDS budget per block: 50 KiB = three blocks per CU.  A deeper ring with the CU to itself is slower: (32,4096,4096) 11.5 us
   // at 150 KiB, 11.0 at 76, 10.6 at 50; (32,4096,14336) split 2: 28.3 / 17.8 / 17.3 us
   const int budget = env_int("QUANTO_HIP_SKINNY_LDS_KB", 50) * 1024;
   constexpr int per_tile = 1 + TF * 4 / WAVES;  // DMA instructions per wave and tile; vmcnt counts at most 63 of them
   if constexpr ((8 - 4) * per_tile <= 60)
-    if (lds_bytes(TF, 8, a.G / a.S, WAVES) <= budget) return launch_s<DT, TF, 8, INT_SHIFT, WAVES>(a, stream);
+    if (lds_bytes(TF, 8, a.G / a.S, WAVES) <= budget) return launch_s<DT, TF, 8, INT_SHIFT, WAVES>(a, stream, segs, total_fb);
   if constexpr ((6 - 4) * per_tile <= 60)
-    if (lds_bytes(TF, 6, a.G / a.S, WAVES) <= budget) return launch_s<DT, TF, 6, INT_SHIFT, WAVES>(a, stream);
-  return launch_s<DT, TF, 4, INT_SHIFT, WAVES>(a, stream);
+    if (lds_bytes(TF, 6, a.G / a.S, WAVES) <= budget) return launch_s<DT, TF, 6, INT_SHIFT, WAVES>(a, stream, segs, total_fb);
+  return launch_s<DT, TF, 4, INT_SHIFT, WAVES>(a, stream, segs, total_fb);
 }
 
 // waves per block: the widest that divides N.  Narrower blocks do not help small N (measured, N = 4096, M = 32: 4 waves
@@ -406,7 +442,8 @@ inline int pick_waves(int N, int tf = 1) {
 }
 
 template <int DT, bool INT_SHIFT, int TF>
-static int launch_waves(const Args& a, hipStream_t stream) {
+static int launch_waves(const Args& a, hipStream_t stream, const Segs* segs = nullptr, int total_fb = 0) {
+  if (segs) return launch<DT, TF, INT_SHIFT, 4>(a, stream, segs, total_fb);
   const int w = pick_waves(a.N, TF);
   if constexpr (TF >= 2)
     if (w == 8) return launch<DT, TF, INT_SHIFT, 8>(a, stream);
@@ -416,10 +453,10 @@ static int launch_waves(const Args& a, hipStream_t stream) {
 }
 
 template <int DT, bool INT_SHIFT>
-static int launch_tf(const Args& a, hipStream_t stream) {
-  if (a.M <= 16) return launch_waves<DT, INT_SHIFT, 1>(a, stream);
-  if (a.M <= 32) return launch_waves<DT, INT_SHIFT, 2>(a, stream);
-  return launch_waves<DT, INT_SHIFT, 4>(a, stream);
+static int launch_tf(const Args& a, hipStream_t stream, const Segs* segs = nullptr, int total_fb = 0) {
+  if (a.M <= 16) return launch_waves<DT, INT_SHIFT, 1>(a, stream, segs, total_fb);
+  if (a.M <= 32) return launch_waves<DT, INT_SHIFT, 2>(a, stream, segs, total_fb);
+  return launch_waves<DT, INT_SHIFT, 4>(a, stream, segs, total_fb);
 }
 
 }  // namespace skinny
@@ -435,7 +472,7 @@ static int skinny_split(const PackedGeom& g, int64_t M) {
   int s = 1;
   while (s < 8 && blocks * s * 2 <= 512 && g.G % (s * 2) == 0 && g.G / (s * 2) >= 8) s *= 2;
   if (forced > 0 && g.G % forced == 0) s = forced;
-  if ((size_t)(g.N / 16) * 4 > QUANTO_HIP_WS_COUNTER_BYTES) s = 1;  // one counter per feature block of 16
+  if ((size_t)blocks * 4 > QUANTO_HIP_WS_COUNTER_BYTES) s = 1;  // one counter per feature block
   return s;
 }
 // The arrival counters of every split-K kernel of the library live in the same fixed-size region at the start of the
@@ -484,6 +521,59 @@ int qbits_mm_skinny(const void* x, const uint8_t* packed, const void* scale, con
     if (r != QUANTO_HIP_OK) return r;
   }
   return QUANTO_HIP_OK;
+}
+
+// ---- several Linears with a shared input in one launch (5 <= M <= 64) --------------------------------------------------------
+// Per-call fixed costs of the streaming kernel (launch, first-byte latency, split-K tail: ~7.7 of the 10.6 us of a
+// (32,4096,4096) call) are paid once for q/k/v or gate/up, and the wider grid needs a smaller split (gate+up of
+// Llama-3-8B: 448 feature blocks -> no split at all).
+static PackedGeom multi_geom(int nseg, const int64_t* N, int64_t K) {
+  int64_t total = 0;
+  for (int i = 0; i < nseg; ++i) total += N[i];
+  return make_geom(total, K, 4, 128);
+}
+
+bool qbits_skinny_multi_supported(int nseg, const int64_t* N, int64_t M, int64_t K, int dtype) {
+  if (nseg < 1 || nseg > skinny::MAX_SEGS || M < 1 || M > 64) return false;
+  for (int i = 0; i < nseg; ++i)
+    if (N[i] <= 0 || N[i] % 64) return false;  // 4-wave blocks only
+  return qbits_skinny_supported(M, multi_geom(nseg, N, K), dtype);
+}
+
+size_t qbits_skinny_multi_workspace(int nseg, const int64_t* N, int64_t M, int64_t K) { return qbits_skinny_workspace(M, multi_geom(nseg, N, K)); }
+
+int qbits_mm_skinny_multi(const void* x, int nseg, const uint8_t* const* packed, const void* const* scale, const void* const* shift,
+                          const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int dtype, bool int_shift,
+                          void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!qbits_skinny_multi_supported(nseg, N, M, K, dtype)) return QUANTO_HIP_ENOTSUP;
+  const PackedGeom g = multi_geom(nseg, N, K);
+  uintptr_t align = reinterpret_cast<uintptr_t>(x);
+  skinny::Segs segs;
+  int fb = 0;
+  for (int i = 0; i < skinny::MAX_SEGS; ++i) {
+    const int j = i < nseg ? i : 0;  // unused slots repeat segment 0 and are never selected
+    segs.w[i] = packed[j];
+    segs.scale[i] = scale[j];
+    segs.shift[i] = shift[j];
+    segs.bias[i] = bias ? bias[j] : nullptr;
+    segs.y[i] = y[j];
+    segs.N[i] = (int)N[j];
+    segs.first_fb[i] = i < nseg ? fb : 0x7FFFFFFF;
+    if (i < nseg) {
+      fb += (int)(N[i] / 64);
+      align |= reinterpret_cast<uintptr_t>(packed[i]);
+    }
+  }
+  if (align % 16) return QUANTO_HIP_EALIGN;
+  int S = skinny_split(g, M);
+  if (S > 1 && (!workspace || workspace_bytes < qbits_skinny_workspace(M, g) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
+  skinny::Args a{x, packed[0], scale[0], shift[0], bias ? bias[0] : nullptr, y[0], (int)M, (int)N[0], (int)K, (int)g.G, S,
+                 reinterpret_cast<int*>(workspace),
+                 S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr,
+                 env_int("QUANTO_HIP_SKINNY_NT", 1), 0, nullptr};
+  if (dtype == QUANTO_HIP_BF16)
+    return int_shift ? skinny::launch_tf<QUANTO_HIP_BF16, true>(a, stream, &segs, fb) : skinny::launch_tf<QUANTO_HIP_BF16, false>(a, stream, &segs, fb);
+  return int_shift ? skinny::launch_tf<QUANTO_HIP_F16, true>(a, stream, &segs, fb) : skinny::launch_tf<QUANTO_HIP_F16, false>(a, stream, &segs, fb);
 }
 
 }  // namespace qh

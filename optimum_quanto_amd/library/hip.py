@@ -71,6 +71,11 @@ class _Bindings:
         c.quanto_hip_qbits_mm_multi.restype = ci
         c.quanto_hip_qbits_mm_multi.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                                 ctypes.POINTER(vp), ctypes.POINTER(i64), i64, i64, ci, ci, ci, ci, vp]
+        c.quanto_hip_qbits_mm_multi_ws.restype = ci
+        c.quanto_hip_qbits_mm_multi_ws.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                                   ctypes.POINTER(vp), ctypes.POINTER(i64), i64, i64, ci, ci, ci, ci, vp, sz, vp]
+        c.quanto_hip_qbits_mm_multi_plan.restype = ci
+        c.quanto_hip_qbits_mm_multi_plan.argtypes = [ci, ctypes.POINTER(i64), i64, i64, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(i64)]
         c.quanto_hip_qbits_mm_workspace_size.restype = i64
         c.quanto_hip_qbits_mm_workspace_size.argtypes = [i64, i64, i64, ci, ci, ci, ci]
         c.quanto_hip_qbits_mm_plan.restype = ci
@@ -288,8 +293,9 @@ class _Bindings:
 
     def qbits_mm_multi(self, x, packed, scale, shift, bias, bits: int, group_size, out_features, in_features: int):
         """Several qbits_mm products sharing ``x`` (q/k/v, gate/up).  One kernel launch when every product is eligible for
-        the decode GEMV (M <= 4, int4, group size 128); otherwise the separate ops (each with its own kernel choice and
-        workspace).  Returns the list of outputs; bit-identical to the separate calls either way."""
+        the decode GEMV (M <= 4, int4, group size 128: bit-identical to the separate calls) or, for batched decode (4 < M <= 64,
+        every out_features a multiple of 64), for one launch of the streaming MFMA kernel over all members; otherwise the
+        separate ops (each with its own kernel choice and workspace).  Returns the list of outputs."""
         n = len(packed)
         bias = list(bias) if bias is not None else [None] * n
         if not (len(scale) == len(shift) == len(bias) == len(out_features) == n) or n < 1:
@@ -301,13 +307,16 @@ class _Bindings:
         lead = x.shape[:-1]
         x2 = x.reshape(-1, in_features).contiguous()
         M = x2.shape[0]
-        one_launch = 1 <= M <= 4 and n <= self.MAX_MULTI and all(s.dtype == sdt for s in scale) and \
-            len({sh.dtype for sh in shift}) == 1
-        if one_launch:
+        kernel, ws_bytes = KERNEL_AUTO, 0
+        nfs = (ctypes.c_int64 * n)(*out_features)
+        if 1 <= M <= 64 and n <= self.MAX_MULTI and all(s.dtype == sdt for s in scale) and len({sh.dtype for sh in shift}) == 1:
+            k_out, ws_out = ctypes.c_int(0), ctypes.c_int64(0)
             with torch.cuda.device(x.device):
-                one_launch = all(self._c.quanto_hip_qbits_mm_pick(M, nf, in_features, bits, group_size or 0, _dt(scale[0])) == KERNEL_GEMV
-                                 for nf in out_features)
-        if not one_launch:
+                st = self._c.quanto_hip_qbits_mm_multi_plan(n, nfs, M, in_features, bits, group_size or 0, _dt(scale[0]), ctypes.byref(k_out),
+                                                            ctypes.byref(ws_out))
+            if st == 0:
+                kernel, ws_bytes = k_out.value, ws_out.value
+        if kernel == KERNEL_AUTO:
             return [self.qbits_mm(x, packed[i], scale[i], shift[i], bias[i], bits, group_size, out_features[i], in_features)
                     for i in range(n)]
         packed = [t.contiguous() for t in packed]
@@ -316,10 +325,10 @@ class _Bindings:
         bias = [None if b is None else b.to(sdt).contiguous() for b in bias]
         ys = [torch.empty((M, nf), dtype=sdt, device=x.device) for nf in out_features]
         arr = lambda ts: (ctypes.c_void_p * n)(*[0 if t is None else t.data_ptr() for t in ts])  # noqa: E731
-        nfs = (ctypes.c_int64 * n)(*out_features)
         with torch.cuda.device(x.device):
-            st = self._c.quanto_hip_qbits_mm_multi(_ptr(x2), n, arr(packed), arr(scale), arr(shift), arr(bias), arr(ys), nfs, M, in_features,
-                                                   bits, group_size or 0, _dt(scale[0]), _dt(shift[0]), self._stream(x))
+            ws = self._zeroed_workspace(x.device, ws_bytes, self._stream(x).value) if ws_bytes else None  # split-K arrival counters
+            st = self._c.quanto_hip_qbits_mm_multi_ws(_ptr(x2), n, arr(packed), arr(scale), arr(shift), arr(bias), arr(ys), nfs, M, in_features,
+                                                      bits, group_size or 0, _dt(scale[0]), _dt(shift[0]), _ptr(ws), ws_bytes, self._stream(x))
         self._check(st, "qbits_mm_multi")
         return [y.reshape(*lead, nf) for y, nf in zip(ys, out_features)]
 

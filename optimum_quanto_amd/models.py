@@ -113,7 +113,7 @@ class _SiblingGroup:
     The model code is left alone (it still calls ``q_proj(h)``, ``k_proj(h)``, ``v_proj(h)`` one after the other): the first
     sibling called with a decode-shaped input runs ``quanto::qbits_mm_multi`` for all of them and parks the other outputs,
     which the following calls pick up when they arrive with the very same tensor object.  Anything else - another input, a
-    larger batch, an unfrozen weight, gradients - takes the module's normal forward."""
+    prefill-sized input, an unfrozen weight, gradients - takes the module's normal forward."""
 
     def __init__(self, modules):
         self.modules = modules
@@ -121,7 +121,7 @@ class _SiblingGroup:
         self.outputs = {}
 
     def eligible(self, x) -> bool:
-        if type(x) is not torch.Tensor or not x.is_cuda or x.numel() // x.shape[-1] > 4 or torch.is_grad_enabled() and x.requires_grad:
+        if type(x) is not torch.Tensor or not x.is_cuda or x.numel() // x.shape[-1] > 64 or torch.is_grad_enabled() and x.requires_grad:
             return False
         from .tensor import WeightQBitsTensor
 
@@ -152,7 +152,7 @@ class _SiblingGroup:
 
 
 def fuse_decode_projections(model, groups=(("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"))):
-    """Opt-in: make sibling QLinears (same parent, same input) share one kernel launch at decode time (M <= 4).
+    """Opt-in: make sibling QLinears (same parent, same input) share one kernel launch at decode time (up to 64 rows).
 
     Weights, state dict and module tree are untouched; only ``forward`` of the listed children is wrapped.  Returns the
     number of groups that were linked."""
