@@ -74,6 +74,10 @@ WORKLOADS = {
     "int4_decode8_down": ("qbits_i4", 8, 14336, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(8,14336,4096)"),
     "int4_decode16_up": ("qbits_i4", 16, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(16,4096,14336)"),
     "int4_decode16_down": ("qbits_i4", 16, 14336, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(16,14336,4096)"),
+    "int8_qkv_fused": ("qbytes_i8_multi", 1, 4096, LLAMA3_QKV, "bf16 x int8 qbytes_mm_multi, Llama-3-8B q/k/v in one launch, M=1"),
+    "int8_gateup_fused": ("qbytes_i8_multi", 1, 4096, LLAMA3_GATE_UP, "bf16 x int8 qbytes_mm_multi, Llama-3-8B gate/up in one launch, M=1"),
+    "int8_qkv_fused32": ("qbytes_i8_multi", 32, 4096, LLAMA3_QKV, "bf16 x int8 qbytes_mm_multi, Llama-3-8B q/k/v in one launch, batched decode M=32"),
+    "int8_gateup_fused32": ("qbytes_i8_multi", 32, 4096, LLAMA3_GATE_UP, "bf16 x int8 qbytes_mm_multi, Llama-3-8B gate/up in one launch, batched decode M=32"),
     "int4_decode8_kv": ("qbits_i4", 8, 4096, 1024, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(8,4096,1024)"),
     "int4_decode8_13b": ("qbits_i4", 8, 5120, 5120, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(8,5120,5120)"),
     "int4_decode8_70b": ("qbits_i4", 8, 8192, 8192, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(8,8192,8192)"),
@@ -82,7 +86,7 @@ WORKLOADS = {
     "int4_decode32_up": ("qbits_i4", 32, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,14336)"),
 }
 DEFAULT_SUB = ["northstar", "cfg3", "qkv_fused", "gateup_fused", "int4_decode32", "qkv_fused32"]
-ARITH_DTYPE = {"qbytes_i8": "bf16", "qbytes_f8": "bf16", "qbits_i4": "bf16", "qbits_i4_multi": "bf16", "qbytes_i8i8": "int8", "qbytes_f8f8": "fp8"}
+ARITH_DTYPE = {"qbytes_i8": "bf16", "qbytes_f8": "bf16", "qbits_i4": "bf16", "qbits_i4_multi": "bf16", "qbytes_i8_multi": "bf16", "qbytes_i8i8": "int8", "qbytes_f8f8": "fp8"}
 
 
 def algorithmic_work(kind, M, K, N):
@@ -142,6 +146,9 @@ def build_inputs(kind, M, K, N, device, n_weights, seed):
         if kind == "qbits_i4_multi":
             sets.append([quantize_int4((randn(n, K) * 0.02).to(torch.bfloat16).float()) for n in N])
             continue
+        if kind == "qbytes_i8_multi":
+            sets.append([absmax_quantize((randn(n, K) * 0.02).to(torch.bfloat16).float(), 127, torch.int8) for n in N])
+            continue
         w = (randn(N, K) * 0.02).to(torch.bfloat16).float()
         if kind == "qbits_i4":
             sets.append(quantize_int4(w))
@@ -175,6 +182,14 @@ def make_step(kind, x, sets, K, N):
             p, sc, sh = packs[state["i"] % len(packs)]
             state["i"] += 1
             return torch.ops.quanto.qbits_mm_multi(x, p, sc, sh, none, 4, 128, Ns, K)
+    elif kind == "qbytes_i8_multi":
+        packs = [([q.contiguous() for q, _ in s], [sc for _, sc in s]) for s in sets]
+        none = [None] * len(N)
+
+        def step():
+            ws, sc = packs[state["i"] % len(packs)]
+            state["i"] += 1
+            return torch.ops.quanto.qbytes_mm_multi(x, ws, sc, none)
     else:
         def step():
             w, scale = sets[state["i"] % len(sets)]
@@ -206,11 +221,11 @@ def cpu_baseline(kind, M, K, N, x, wset, budget_s):
                                    "(tensor/weights/tinygemm/qbits.py:51-58); lossy shift repack at load time",
                            "seconds_per_call": round(t_tiny["median_s"], 6), "iqr_s": round(t_tiny["iqr_s"], 6), "calls": t_tiny["calls"]}
     else:
-        w, scale = wset
-        wc, sc = w.cpu(), scale.cpu()
-        fn = lambda: R.qbytes_mm_cpu(xc, wc, sc)  # noqa: E731
+        parts = [(w.cpu(), sc.cpu()) for w, sc in (wset if kind == "qbytes_i8_multi" else [wset])]
+        fn = lambda: [R.qbytes_mm_cpu(xc, wc, sc) for wc, sc in parts]  # noqa: E731
         t = R.time_call(fn, budget_s)
         out["path"] = {"qbytes_i8": "torch._weight_int8pack_mm (library/qbytes_mm.py:91-105, bf16 x int8 branch)",
+                       "qbytes_i8_multi": "torch._weight_int8pack_mm per member (library/qbytes_mm.py:91-105, bf16 x int8 branch)",
                        "qbytes_i8i8": "torch._int_mm + fp32 rescale (library/qbytes_mm.py:36-50)"}.get(
                            kind, "generic: cast fp8 -> bf16, scale the weight, matmul (library/qbytes_mm.py:25-33)")
     flops, nbytes = algorithmic_work(kind, M, K, N)

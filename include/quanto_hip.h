@@ -194,6 +194,21 @@ int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const
                          void* stream);
 
 /*
+ * `count` (1..QUANTO_HIP_MAX_MULTI) qbytes_mm products that share the activation `a` and K and the dtypes - q/k/v or gate/up of an
+ * int8 / fp8 model (WeightQBytesLinearFunction.forward issues one quanto::qbytes_mm per module, tensor/weights/qbytes.py:68-82) - in
+ * one call, the counterpart of quanto_hip_qbits_mm_multi: ONE launch of the GEMV (M <= 2) or of the streaming MFMA kernel
+ * (M <= 64, every N[i] a multiple of 64; `workspace` as quanto_hip_qbytes_mm_multi_plan asks), otherwise `count` separate
+ * quanto_hip_qbytes_mm_ws calls without scratch.  HOST arrays of device pointers; `bias` may be NULL or hold NULL entries.
+ */
+int quanto_hip_qbytes_mm_multi_ws(const void* a, int count, const void* const* b, const void* const* scales,
+                                  const void* const* bias, void* const* y, const int64_t* N, int64_t M, int64_t K, int a_dtype,
+                                  int b_dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* *kernel_out = QUANTO_HIP_KERNEL_GEMV / _SKINNY (one launch, *workspace_bytes_out of zeroed-counter scratch for the latter) or
+ * QUANTO_HIP_KERNEL_AUTO (separate calls). */
+int quanto_hip_qbytes_mm_multi_plan(int count, const int64_t* N, int64_t M, int64_t K, int a_dtype, int b_dtype, int out_dtype,
+                                    int* kernel_out, int64_t* workspace_bytes_out);
+
+/*
  * Same, with a caller-provided scratch buffer.  Only the SKINNY kernel (float activations, 8 < M <= QUANTO_HIP_SKINNY_MAX_M)
  * uses it, to split K across workgroups when N alone cannot occupy the chip: the buffer starts with arrival counters that MUST
  * BE ZERO on entry (the kernel leaves them zero), followed by fp32 partial sums - the contract of quanto_hip_qbits_mm's SKINNY

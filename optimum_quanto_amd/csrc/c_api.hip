@@ -30,6 +30,12 @@ int quantize_symmetric(const void*, const void*, void*, int64_t, int64_t, int, i
 int quantize_affine(const void*, const void*, const void*, void*, int64_t, int64_t, int, int, bool, hipStream_t);
 int quantize_affine_packed(const void*, const void*, const void*, void*, int64_t, int64_t, int, int, bool, hipStream_t);
 int pack_weights(const uint8_t*, uint8_t*, int64_t, int64_t, int, hipStream_t);
+int qbytes_mm_gemv_multi(const void*, int, const void* const*, const void* const*, const void* const*, void* const*, const int64_t*, int64_t,
+                         int64_t, int, int, hipStream_t);
+bool qbytes_skinny_multi_supported(int, const int64_t*, int64_t, int64_t, int, int, int);
+size_t qbytes_skinny_multi_workspace(int, const int64_t*, int64_t, int64_t);
+int qbytes_mm_skinny_multi(const void*, int, const void* const*, const void* const*, const void* const*, void* const*, const int64_t*, int64_t,
+                           int64_t, int, int, int, void*, size_t, hipStream_t);
 bool qbytes_skinny_supported(int64_t, int64_t, int64_t, int, int, int);
 size_t qbytes_skinny_workspace(int64_t, int64_t, int64_t);
 int qbytes_mm_skinny(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, void*, size_t, hipStream_t);
@@ -442,6 +448,59 @@ int quanto_hip_qbytes_mm_ws(const void* a, const void* b, const void* scales, co
       return r;
   }
   return QUANTO_HIP_EINVAL;
+}
+
+// ---- several qbytes_mm products that share the activation (q/k/v, gate/up of an int8 / fp8 model), see quanto_hip_qbits_mm_multi -----
+// which single launch serves the group: GEMV (M <= 2, 16-bit activations), the streaming MFMA kernel (M <= 64, every N a multiple
+// of 64), or none (KERNEL_AUTO: separate calls)
+static int qbytes_multi_kernel(int count, const int64_t* N, int64_t M, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
+  if (count < 2) return QUANTO_HIP_KERNEL_AUTO;
+  bool gemv = M >= 1 && M <= 2, lone_skinny = true;
+  for (int i = 0; i < count; ++i) {
+    gemv = gemv && qbytes_gemv_supported(M, N[i], K, a_dtype, b_dtype, out_dtype);
+    lone_skinny = lone_skinny && pick_qbytes_kernel(M, N[i], K, a_dtype, b_dtype, out_dtype) == QUANTO_HIP_KERNEL_SKINNY;
+  }
+  if (gemv) return QUANTO_HIP_KERNEL_GEMV;
+  if (lone_skinny && M <= env_int("QUANTO_HIP_SKINNY_MULTI_MAX_M", 64) && qbytes_skinny_multi_supported(count, N, M, K, a_dtype, b_dtype, out_dtype))
+    return QUANTO_HIP_KERNEL_SKINNY;
+  return QUANTO_HIP_KERNEL_AUTO;
+}
+
+int quanto_hip_qbytes_mm_multi_plan(int count, const int64_t* N, int64_t M, int64_t K, int a_dtype, int b_dtype, int out_dtype, int* kernel_out,
+                                    int64_t* workspace_bytes_out) {
+  if (count < 1 || count > QUANTO_HIP_MAX_MULTI || !N || !kernel_out || !workspace_bytes_out || M < 0 || K <= 0) return QUANTO_HIP_EINVAL;
+  for (int i = 0; i < count; ++i)
+    if (N[i] <= 0) return QUANTO_HIP_EINVAL;
+  *kernel_out = qbytes_multi_kernel(count, N, M, K, a_dtype, b_dtype, out_dtype);
+  *workspace_bytes_out = *kernel_out == QUANTO_HIP_KERNEL_SKINNY ? (int64_t)qbytes_skinny_multi_workspace(count, N, M, K) : 0;
+  return QUANTO_HIP_OK;
+}
+
+int quanto_hip_qbytes_mm_multi_ws(const void* a, int count, const void* const* b, const void* const* scales, const void* const* bias,
+                                  void* const* y, const int64_t* N, int64_t M, int64_t K, int a_dtype, int b_dtype, int out_dtype,
+                                  void* workspace, size_t workspace_bytes, void* stream_) {
+  if (count < 1 || count > QUANTO_HIP_MAX_MULTI || !b || !scales || !y || !N || M < 0 || K <= 0) return QUANTO_HIP_EINVAL;
+  if (!is_float_dtype(out_dtype)) return QUANTO_HIP_ENOTSUP;
+  for (int i = 0; i < count; ++i)
+    if (N[i] <= 0 || (M > 0 && (!a || !b[i] || !scales[i] || !y[i]))) return QUANTO_HIP_EINVAL;
+  if (M == 0) return QUANTO_HIP_OK;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int kernel = qbytes_multi_kernel(count, N, M, K, a_dtype, b_dtype, out_dtype);
+  if (kernel == QUANTO_HIP_KERNEL_GEMV) {
+    const int r = qbytes_mm_gemv_multi(a, count, b, scales, bias, y, N, M, K, b_dtype, out_dtype, stream);
+    if (r == QUANTO_HIP_OK) set_last_kernel("gemv_multi");
+    if (r != QUANTO_HIP_EALIGN) return r;  // misaligned views: the separate calls below cope
+  } else if (kernel == QUANTO_HIP_KERNEL_SKINNY) {
+    const int r = qbytes_mm_skinny_multi(a, count, b, scales, bias, y, N, M, K, a_dtype, b_dtype, out_dtype, workspace, workspace_bytes, stream);
+    if (r == QUANTO_HIP_OK) set_last_kernel("skinny_multi");
+    if (r != QUANTO_HIP_EALIGN) return r;
+  }
+  for (int i = 0; i < count; ++i) {  // separate calls (no shared scratch: kernels that split K run unsplit)
+    const int r = quanto_hip_qbytes_mm_ws(a, b[i], scales[i], bias ? bias[i] : nullptr, y[i], M, N[i], K, a_dtype, b_dtype, out_dtype,
+                                          QUANTO_HIP_KERNEL_AUTO, nullptr, 0, stream_);
+    if (r != QUANTO_HIP_OK) return r;
+  }
+  return QUANTO_HIP_OK;
 }
 
 int quanto_hip_qbytes_mm(const void* a, const void* b, const void* scales, const void* bias, void* y, int64_t M, int64_t N, int64_t K,

@@ -51,10 +51,20 @@ constexpr int RR8 = 4;  // weight rows per wave pass
 // requested in its first instructions.  A wave owns K-slabs of 1024 k (slab = wave % wpr, stride wpr, at most ITERS of
 // them), keeps that slice of x in registers as fp32 and streams RR8 weight rows at a time: RR8 * ITERS 16-byte loads per
 // lane in flight.  Per-slab partial sums are reduced with DPP adds and combined across the wpr waves through LDS.
-template <int DT, int BDT, int MT, int ITERS>
-__global__ void __launch_bounds__(256)
-    qbytes_gemv_kernel(const uint16_t* __restrict__ x, const uint8_t* __restrict__ w, const uint16_t* __restrict__ scales,
-                       const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int N, int K, int wpr) {
+// Several Linears that share x (q/k/v, gate/up) in one launch: slot 0 is the plain op (MULTI = false: compile-time slot, one
+// round of scalar loads); with MULTI a block finds its segment by its first workgroup (qbits_gemv.hip).
+constexpr int MAX_SEGS8 = QUANTO_HIP_MAX_MULTI;
+struct GemvSegs8 {
+  const uint8_t* w[MAX_SEGS8];
+  const uint16_t* scales[MAX_SEGS8];
+  const uint16_t* bias[MAX_SEGS8];
+  uint16_t* y[MAX_SEGS8];
+  int N[MAX_SEGS8];
+  int first_block[MAX_SEGS8];  // INT_MAX for unused slots
+};
+
+template <int DT, int BDT, int MT, int ITERS, bool MULTI = false>
+__global__ void __launch_bounds__(256) qbytes_gemv_kernel(const uint16_t* __restrict__ x, const GemvSegs8 segs, int K, int wpr) {
   using E = Elem<DT>;
   using T = typename E::T;
   __shared__ float red[4][RR8][MT];
@@ -62,7 +72,18 @@ __global__ void __launch_bounds__(256)
   const int wave = threadIdx.x >> 6;
   const int slab0 = wave % wpr;
   const int rgroup = wave / wpr;
-  const int n0 = (blockIdx.x * (4 / wpr) + rgroup) * RR8;
+  int seg = 0, block = blockIdx.x;
+  if constexpr (MULTI) {
+#pragma unroll
+    for (int i = 1; i < MAX_SEGS8; ++i) seg += (int)blockIdx.x >= segs.first_block[i];
+    block -= segs.first_block[seg];
+  }
+  const uint8_t* __restrict__ w = segs.w[seg];
+  const uint16_t* __restrict__ scales = segs.scales[seg];
+  const uint16_t* __restrict__ bias = segs.bias[seg];
+  uint16_t* __restrict__ y = segs.y[seg];
+  const int N = segs.N[seg];
+  const int n0 = (block * (4 / wpr) + rgroup) * RR8;
 
   // ---- 1. request everything: weights first, then the x slice ----------------------------------------------------------
   int k0[ITERS];
@@ -138,27 +159,47 @@ __global__ void __launch_bounds__(256)
       float v = 0.f;
       for (int s = 0; s < wpr; ++s) v += red[wave + s][r][m];
       v *= E::to_f32(__builtin_bit_cast(T, scales[n]));
+      asm volatile("" : "+v"(v));  // product rounded to fp32 first, with and without bias (no single-rounding v_fma_mixlo_f16)
       if (bias) v = E::to_f32(E::from_f32(v)) + E::to_f32(__builtin_bit_cast(T, bias[n]));
       y[(size_t)m * N + n] = __builtin_bit_cast(uint16_t, E::from_f32(v));
     }
   }
 }
 
+struct GemvProblem8 {
+  int nseg;
+  const void* w[MAX_SEGS8];
+  const void* s[MAX_SEGS8];
+  const void* bias[MAX_SEGS8];
+  void* y[MAX_SEGS8];
+  int N[MAX_SEGS8];
+};
+
 template <int DT, int BDT, int MT>
-static int launch_iters(const void* x, const void* w, const void* s, const void* bias, void* y, int N, int K, hipStream_t stream) {
+static int launch_iters(const void* x, const GemvProblem8& pb, int m0, int K, hipStream_t stream) {
   const int nslab = (K + 1023) / 1024;
   const int wpr = nslab >= 3 ? 4 : nslab;  // 1, 2 or 4 waves per row group
   const int iters = (nslab + wpr - 1) / wpr;
   if (iters > 4) return QUANTO_HIP_ENOTSUP;
   const int rows_per_block = RR8 * (4 / wpr);
-  const int grid = (N + rows_per_block - 1) / rows_per_block;
-  auto xs = reinterpret_cast<const uint16_t*>(x);
-  auto ws = reinterpret_cast<const uint8_t*>(w);
-  auto ss = reinterpret_cast<const uint16_t*>(s);
-  auto bs = reinterpret_cast<const uint16_t*>(bias);
-  auto ys = reinterpret_cast<uint16_t*>(y);
-#define QH_LAUNCH(IT) \
-  hipLaunchKernelGGL((qbytes_gemv_kernel<DT, BDT, MT, IT>), dim3(grid), dim3(256), 0, stream, xs, ws, ss, bs, ys, N, K, wpr)
+  GemvSegs8 segs;
+  int grid = 0;
+  for (int i = 0; i < MAX_SEGS8; ++i) {
+    const int j = i < pb.nseg ? i : 0;  // unused slots repeat segment 0 and are never selected
+    segs.w[i] = reinterpret_cast<const uint8_t*>(pb.w[j]);
+    segs.scales[i] = reinterpret_cast<const uint16_t*>(pb.s[j]);
+    segs.bias[i] = reinterpret_cast<const uint16_t*>(pb.bias[j]);
+    segs.y[i] = reinterpret_cast<uint16_t*>(pb.y[j]) + (size_t)m0 * pb.N[j];
+    segs.N[i] = pb.N[j];
+    segs.first_block[i] = i < pb.nseg ? grid : 0x7FFFFFFF;
+    if (i < pb.nseg) grid += (pb.N[i] + rows_per_block - 1) / rows_per_block;
+  }
+  auto xs = reinterpret_cast<const uint16_t*>(x) + (size_t)m0 * K;
+#define QH_LAUNCH(IT)                                                                                                           \
+  if (pb.nseg > 1)                                                                                                              \
+    hipLaunchKernelGGL((qbytes_gemv_kernel<DT, BDT, MT, IT, true>), dim3(grid), dim3(256), 0, stream, xs, segs, K, wpr);         \
+  else                                                                                                                          \
+    hipLaunchKernelGGL((qbytes_gemv_kernel<DT, BDT, MT, IT, false>), dim3(grid), dim3(256), 0, stream, xs, segs, K, wpr)
   switch (iters) {
     case 1: QH_LAUNCH(1); break;
     case 2: QH_LAUNCH(2); break;
@@ -170,18 +211,28 @@ static int launch_iters(const void* x, const void* w, const void* s, const void*
 }
 
 template <int DT, int BDT>
-static int launch_m(const void* x, const void* w, const void* s, const void* bias, void* y, int M, int N, int K, hipStream_t stream) {
+static int launch_m(const void* x, const GemvProblem8& pb, int M, int K, hipStream_t stream) {
   int m0 = 0;
   while (m0 < M) {  // x lives in registers as fp32 (16 VGPRs per slab and row): two rows per pass, later passes hit the MALL
     const int mt = (M - m0) >= 2 ? 2 : 1;
-    const void* xp = reinterpret_cast<const uint16_t*>(x) + (size_t)m0 * K;
-    void* yp = reinterpret_cast<uint16_t*>(y) + (size_t)m0 * N;
-    const int st = mt == 2 ? launch_iters<DT, BDT, 2>(xp, w, s, bias, yp, N, K, stream)
-                           : launch_iters<DT, BDT, 1>(xp, w, s, bias, yp, N, K, stream);
+    const int st = mt == 2 ? launch_iters<DT, BDT, 2>(x, pb, m0, K, stream) : launch_iters<DT, BDT, 1>(x, pb, m0, K, stream);
     if (st != QUANTO_HIP_OK) return st;
     m0 += mt;
   }
   return QUANTO_HIP_OK;
+}
+
+static int gemv8_dispatch(const void* a, const GemvProblem8& pb, int M, int K, int b_dtype, int out_dtype, hipStream_t stream) {
+#define QH_CASE(DT, BDT) return launch_m<DT, BDT>(a, pb, M, K, stream)
+  if (out_dtype == QUANTO_HIP_BF16) {
+    if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_BF16, QUANTO_HIP_I8);
+    if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_BF16, QUANTO_HIP_F8_E4M3FN);
+    QH_CASE(QUANTO_HIP_BF16, QUANTO_HIP_F8_E5M2);
+  }
+  if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_F16, QUANTO_HIP_I8);
+  if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_F16, QUANTO_HIP_F8_E4M3FN);
+  QH_CASE(QUANTO_HIP_F16, QUANTO_HIP_F8_E5M2);
+#undef QH_CASE
 }
 
 bool qbytes_gemv_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
@@ -194,16 +245,33 @@ int qbytes_mm_gemv(const void* a, const void* b, const void* s, const void* bias
                    int b_dtype, int out_dtype, hipStream_t stream) {
   if (!qbytes_gemv_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
   if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16) return QUANTO_HIP_EALIGN;
-#define QH_CASE(DT, BDT) return launch_m<DT, BDT>(a, b, s, bias, y, (int)M, (int)N, (int)K, stream)
-  if (out_dtype == QUANTO_HIP_BF16) {
-    if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_BF16, QUANTO_HIP_I8);
-    if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_BF16, QUANTO_HIP_F8_E4M3FN);
-    QH_CASE(QUANTO_HIP_BF16, QUANTO_HIP_F8_E5M2);
+  GemvProblem8 pb{};
+  pb.nseg = 1;
+  pb.w[0] = b;
+  pb.s[0] = s;
+  pb.bias[0] = bias;
+  pb.y[0] = y;
+  pb.N[0] = (int)N;
+  return gemv8_dispatch(a, pb, (int)M, (int)K, b_dtype, out_dtype, stream);
+}
+
+// up to QUANTO_HIP_MAX_MULTI weights that share the activation, ONE launch (every member must pass qbytes_gemv_supported)
+int qbytes_mm_gemv_multi(const void* a, int nseg, const void* const* b, const void* const* s, const void* const* bias, void* const* y,
+                         const int64_t* N, int64_t M, int64_t K, int b_dtype, int out_dtype, hipStream_t stream) {
+  if (nseg < 1 || nseg > MAX_SEGS8) return QUANTO_HIP_EINVAL;
+  GemvProblem8 pb{};
+  pb.nseg = nseg;
+  uintptr_t align = reinterpret_cast<uintptr_t>(a);
+  for (int i = 0; i < nseg; ++i) {
+    pb.w[i] = b[i];
+    pb.s[i] = s[i];
+    pb.bias[i] = bias ? bias[i] : nullptr;
+    pb.y[i] = y[i];
+    pb.N[i] = (int)N[i];
+    align |= reinterpret_cast<uintptr_t>(b[i]);
   }
-  if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_F16, QUANTO_HIP_I8);
-  if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_F16, QUANTO_HIP_F8_E4M3FN);
-  QH_CASE(QUANTO_HIP_F16, QUANTO_HIP_F8_E5M2);
-#undef QH_CASE
+  if (align % 16) return QUANTO_HIP_EALIGN;
+  return gemv8_dispatch(a, pb, (int)M, (int)K, b_dtype, out_dtype, stream);
 }
 
 }  // namespace qh

@@ -123,8 +123,20 @@ struct Args {
   int nt;             // non-temporal weight DMA (single-pass calls)
 };
 
-template <int DT, int FMT, int TF, int STAGES>
-__global__ void __launch_bounds__(256) qbytes_skinny_kernel(const Args a) {
+// Several Linears sharing their input in one launch (MULTI, see qbits_skinny.hip): the feature blocks of all segments form
+// one grid, a block takes weight / scale / bias / output pointers and N from its segment.
+constexpr int MAX_SEGS = QUANTO_HIP_MAX_MULTI;
+struct Segs {
+  const uint8_t* w[MAX_SEGS];
+  const void* scale[MAX_SEGS];
+  const void* bias[MAX_SEGS];
+  void* y[MAX_SEGS];
+  int N[MAX_SEGS];
+  int first_fb[MAX_SEGS];  // first feature block of each segment (INT_MAX for unused slots)
+};
+
+template <int DT, int FMT, int TF, int STAGES, bool MULTI = false>
+__global__ void __launch_bounds__(256) qbytes_skinny_kernel(Args a, const Segs segs) {
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
@@ -140,9 +152,21 @@ __global__ void __launch_bounds__(256) qbytes_skinny_kernel(const Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int M = a.M, N = a.N, K = a.K;
   const int S = a.S;
-  const int fb = S > 1 ? blockIdx.x / S : blockIdx.x, sp = S > 1 ? blockIdx.x - fb * S : 0;
+  const int fbg = S > 1 ? blockIdx.x / S : blockIdx.x, sp = S > 1 ? blockIdx.x - fbg * S : 0;  // global feature block
+  int fb = fbg;
+  if constexpr (MULTI) {
+    int seg = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_SEGS; ++i) seg += fbg >= segs.first_fb[i];
+    fb = fbg - segs.first_fb[seg];
+    a.w = segs.w[seg];
+    a.scale = segs.scale[seg];
+    a.bias = segs.bias[seg];
+    a.y = segs.y[seg];
+    a.N = segs.N[seg];
+  }
+  const int M = a.M, N = a.N, K = a.K;
   const int n_blk = fb * ROWS;
   const int nk = K / BK / S;
   const int kt0 = sp * nk;
@@ -256,14 +280,14 @@ __global__ void __launch_bounds__(256) qbytes_skinny_kernel(const Args a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem);
-    if (tid == 0) *flag = __hip_atomic_fetch_add(a.counters + fb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) *flag = __hip_atomic_fetch_add(a.counters + fbg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
     if (*flag != S - 1) return;
-    if (tid == 0) __hip_atomic_store(a.counters + fb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(a.counters + fbg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
     for (int tf = 0; tf < TF; ++tf) acc[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int q = 0; q < S; ++q) {
-      const float* theirs = a.partials + ((size_t)(fb * S + q) * 256 + tid) * (TF * 4);
+      const float* theirs = a.partials + ((size_t)(fbg * S + q) * 256 + tid) * (TF * 4);
       f32x4 v[TF];
 #pragma unroll
       for (int tf = 0; tf < TF; ++tf) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[tf]) : "v"(theirs + tf * 4) : "memory");
@@ -295,6 +319,7 @@ __global__ void __launch_bounds__(256) qbytes_skinny_kernel(const Args a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[tf][r] * sc[r];
+        asm volatile("" : "+v"(v));  // product rounded to fp32 first, with and without bias (no single-rounding v_fma_mixlo_f16)
         if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[r];
         out[r] = E::from_f32(v);
       }
@@ -312,16 +337,27 @@ __global__ void __launch_bounds__(256) qbytes_skinny_kernel(const Args a) {
 constexpr int lds_bytes(int tf, int stages) { return stages * (64 * BK + tf * 16 * BK * 2); }
 
 template <int DT, int FMT, int TF, int STAGES>
-static int launch_s(const Args& a, hipStream_t stream) {
+static int launch_s(const Args& a, hipStream_t stream, const Segs* segs = nullptr, int total_fb = 0) {
   constexpr int lds = lds_bytes(TF, STAGES);
+  if (segs) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_skinny_kernel<DT, FMT, TF, STAGES, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((qbytes_skinny_kernel<DT, FMT, TF, STAGES, true>), dim3(total_fb * a.S), dim3(256), lds, stream, a, *segs);
+    return launch_status();
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_skinny_kernel<DT, FMT, TF, STAGES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((qbytes_skinny_kernel<DT, FMT, TF, STAGES>), dim3((a.N + 63) / 64 * a.S), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((qbytes_skinny_kernel<DT, FMT, TF, STAGES>), dim3((a.N + 63) / 64 * a.S), dim3(256), lds, stream, a, Segs{});
   return launch_status();
 }
 
 template <int DT, int FMT>
-static int launch_tf(const Args& a, hipStream_t stream) {
+static int launch_tf(const Args& a, hipStream_t stream, const Segs* segs = nullptr, int total_fb = 0) {
+  if (segs) {  // the multi-Linear launch keeps the default ring
+    if (a.M <= 16) return launch_s<DT, FMT, 1, 4>(a, stream, segs, total_fb);
+    if (a.M <= 32) return launch_s<DT, FMT, 2, 4>(a, stream, segs, total_fb);
+    return launch_s<DT, FMT, 4, 4>(a, stream, segs, total_fb);
+  }
   // ring depth: 4 stages (48 / 64 KiB: two to three blocks per CU, which hide each other's barrier and reduction stalls - see the
   // measurements in qbits_skinny.hip) unless the experiment knob asks for the deep ring (8 stages, one block per CU)
   const bool deep = env_int("QUANTO_HIP_SKINNY_LDS_KB", 50) >= 100;
@@ -384,6 +420,63 @@ int qbytes_mm_skinny(const void* x, const void* w, const void* s, const void* bi
     if (r != QUANTO_HIP_OK) return r;
   }
   return QUANTO_HIP_OK;
+}
+
+// ---- several Linears with a shared input in one launch (3 <= M <= 64), see qbits_skinny.hip ------------------------------------
+static int64_t multi_total(int nseg, const int64_t* N) {
+  int64_t t = 0;
+  for (int i = 0; i < nseg; ++i) t += N[i];
+  return t;
+}
+
+bool qbytes_skinny_multi_supported(int nseg, const int64_t* N, int64_t M, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
+  if (nseg < 1 || nseg > skinny8::MAX_SEGS || M < 1 || M > 64) return false;
+  for (int i = 0; i < nseg; ++i)
+    if (N[i] <= 0 || N[i] % 64) return false;
+  return qbytes_skinny_supported(M, multi_total(nseg, N), K, a_dtype, b_dtype, out_dtype);
+}
+
+size_t qbytes_skinny_multi_workspace(int nseg, const int64_t* N, int64_t M, int64_t K) { return qbytes_skinny_workspace(M, multi_total(nseg, N), K); }
+
+int qbytes_mm_skinny_multi(const void* x, int nseg, const void* const* w, const void* const* s, const void* const* bias, void* const* y,
+                           const int64_t* N, int64_t M, int64_t K, int a_dtype, int b_dtype, int out_dtype, void* workspace,
+                           size_t workspace_bytes, hipStream_t stream) {
+  if (!qbytes_skinny_multi_supported(nseg, N, M, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
+  const int64_t total = multi_total(nseg, N);
+  uintptr_t align = reinterpret_cast<uintptr_t>(x);
+  skinny8::Segs segs;
+  int fb = 0;
+  for (int i = 0; i < skinny8::MAX_SEGS; ++i) {
+    const int j = i < nseg ? i : 0;  // unused slots repeat segment 0 and are never selected
+    segs.w[i] = reinterpret_cast<const uint8_t*>(w[j]);
+    segs.scale[i] = s[j];
+    segs.bias[i] = bias ? bias[j] : nullptr;
+    segs.y[i] = y[j];
+    segs.N[i] = (int)N[j];
+    segs.first_fb[i] = i < nseg ? fb : 0x7FFFFFFF;
+    if (i < nseg) {
+      fb += (int)(N[i] / 64);
+      align |= reinterpret_cast<uintptr_t>(w[i]);
+    }
+  }
+  if (align % 16) return QUANTO_HIP_EALIGN;
+  int S = skinny8_split(total, K);
+  if (S > 1 && (!workspace || workspace_bytes < qbytes_skinny_workspace(M, total, K) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
+  skinny8::Args a{x, segs.w[0], s[0], segs.bias[0], y[0], (int)M, (int)N[0], (int)K, S, reinterpret_cast<int*>(workspace),
+                  S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny8_counter_bytes(total)) : nullptr,
+                  env_int("QUANTO_HIP_SKINNY_NT", 1)};
+  int r;
+#define QH_FMT(DT)                                                                                        \
+  r = b_dtype == QUANTO_HIP_I8 ? skinny8::launch_tf<DT, skinny8::W_I8>(a, stream, &segs, fb)              \
+      : b_dtype == QUANTO_HIP_F8_E4M3FN ? skinny8::launch_tf<DT, skinny8::W_F8E4M3>(a, stream, &segs, fb) \
+                                        : skinny8::launch_tf<DT, skinny8::W_F8E5M2>(a, stream, &segs, fb)
+  if (out_dtype == QUANTO_HIP_BF16) {
+    QH_FMT(QUANTO_HIP_BF16);
+  } else {
+    QH_FMT(QUANTO_HIP_F16);
+  }
+#undef QH_FMT
+  return r;
 }
 
 }  // namespace qh

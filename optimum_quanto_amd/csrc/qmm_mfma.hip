@@ -285,6 +285,7 @@ __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
         const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
         if (m < M) {
           float v = acc[i][j][r] * sc;
+          asm volatile("" : "+v"(v));  // product rounded to fp32 first, with and without bias (no single-rounding v_fma_mixlo_f16)
           if (has_bias) v = E::to_f32(E::from_f32(v)) + bv;
           yg[(size_t)m * N + n] = E::from_f32(v);
         }

@@ -462,6 +462,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[j][i][r] * sc[r];
+          asm volatile("" : "+v"(v));  // product rounded to fp32 first, with and without bias (no single-rounding v_fma_mixlo_f16)
           if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[r];
           out[r] = E::from_f32(v);
         }

@@ -56,7 +56,7 @@ struct Mma32<QUANTO_HIP_F16> {
 __device__ __forceinline__ int swz_a32(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int swz_w32(int row) { return (row >> 2) & 3; }
 
-constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NWAVES = 8;
+constexpr int BM = 256, BN = 256, WN = 4, NWAVES = 8;  // waves as 2 (token halves) x WN
 constexpr int MI = 4;   // 32-token blocks per wave
 constexpr int NJ = 2;   // 32-feature blocks per wave
 constexpr int KS = 4;   // k-steps of 16 per K-tile
@@ -273,6 +273,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1) qbytes_mfma_large32_kernel(con
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[j][i][q * 4 + r] * sc[r];
+          asm volatile("" : "+v"(v));  // product rounded to fp32 first, with and without bias (no single-rounding v_fma_mixlo_f16)
           if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[r];
           out[r] = E::from_f32(v);
         }

@@ -76,6 +76,11 @@ class _Bindings:
                                                    ctypes.POINTER(vp), ctypes.POINTER(i64), i64, i64, ci, ci, ci, ci, vp, sz, vp]
         c.quanto_hip_qbits_mm_multi_plan.restype = ci
         c.quanto_hip_qbits_mm_multi_plan.argtypes = [ci, ctypes.POINTER(i64), i64, i64, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(i64)]
+        c.quanto_hip_qbytes_mm_multi_ws.restype = ci
+        c.quanto_hip_qbytes_mm_multi_ws.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                                    ctypes.POINTER(i64), i64, i64, ci, ci, ci, vp, sz, vp]
+        c.quanto_hip_qbytes_mm_multi_plan.restype = ci
+        c.quanto_hip_qbytes_mm_multi_plan.argtypes = [ci, ctypes.POINTER(i64), i64, i64, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(i64)]
         c.quanto_hip_qbits_mm_workspace_size.restype = i64
         c.quanto_hip_qbits_mm_workspace_size.argtypes = [i64, i64, i64, ci, ci, ci, ci]
         c.quanto_hip_qbits_mm_plan.restype = ci
@@ -331,6 +336,49 @@ class _Bindings:
                                                       bits, group_size or 0, _dt(scale[0]), _dt(shift[0]), _ptr(ws), ws_bytes, self._stream(x))
         self._check(st, "qbits_mm_multi")
         return [y.reshape(*lead, nf) for y, nf in zip(ys, out_features)]
+
+    # -- quanto::qbytes_mm_multi --------------------------------------------------------------------
+    def qbytes_mm_multi(self, a, weights, scales, bias):
+        """Several qbytes_mm products sharing the activation (q/k/v, gate/up of an int8 / fp8 model): one GEMV launch for M <= 2,
+        one streaming-MFMA launch for M <= 64 when every out_features is a multiple of 64, otherwise the separate ops."""
+        n = len(weights)
+        bias = list(bias) if bias is not None else [None] * n
+        if not (len(scales) == len(bias) == n) or n < 1:
+            raise QuantoHipError("qbytes_mm_multi: inconsistent argument lists")
+        self._require_cuda(a, *weights, *scales, *bias)
+        K = weights[0].shape[1]
+        sdt = scales[0].dtype
+        one_call = (n <= self.MAX_MULTI and a.dtype.is_floating_point and a.dtype.itemsize > 1 and all(w.shape[1] == K for w in weights)
+                    and all(w.dtype == weights[0].dtype for w in weights) and all(s.dtype == sdt for s in scales)
+                    and all(s.numel() == w.shape[0] for s, w in zip(scales, weights)))
+        kernel, ws_bytes = KERNEL_AUTO, 0
+        if one_call:
+            if a.dtype != sdt:
+                a = a.to(sdt)
+            lead = a.shape[:-1]
+            a2 = a.reshape(-1, K).contiguous()
+            M = a2.shape[0]
+            nfs = (ctypes.c_int64 * n)(*[w.shape[0] for w in weights])
+            if 1 <= M <= 64:
+                k_out, ws_out = ctypes.c_int(0), ctypes.c_int64(0)
+                with torch.cuda.device(a.device):
+                    st = self._c.quanto_hip_qbytes_mm_multi_plan(n, nfs, M, K, _dt(a2), _dt(weights[0]), _dt(scales[0]), ctypes.byref(k_out),
+                                                                 ctypes.byref(ws_out))
+                if st == 0:
+                    kernel, ws_bytes = k_out.value, ws_out.value
+        if kernel == KERNEL_AUTO:
+            return [self.qbytes_mm(a, weights[i], scales[i], bias[i]) for i in range(n)]
+        weights = [w.contiguous() for w in weights]
+        scales = [s.reshape(-1).contiguous() for s in scales]
+        bias = [None if b is None else b.to(sdt).contiguous() for b in bias]
+        ys = [torch.empty((M, w.shape[0]), dtype=sdt, device=a.device) for w in weights]
+        arr = lambda ts: (ctypes.c_void_p * n)(*[0 if t is None else t.data_ptr() for t in ts])  # noqa: E731
+        with torch.cuda.device(a.device):
+            ws = self._zeroed_workspace(a.device, ws_bytes, self._stream(a).value) if ws_bytes else None  # split-K arrival counters
+            st = self._c.quanto_hip_qbytes_mm_multi_ws(_ptr(a2), n, arr(weights), arr(scales), arr(bias), arr(ys), nfs, M, K, _dt(a2),
+                                                       _dt(weights[0]), _dt(scales[0]), _ptr(ws), ws_bytes, self._stream(a))
+        self._check(st, "qbytes_mm_multi")
+        return [y.reshape(*lead, w.shape[0]) for y, w in zip(ys, weights)]
 
     # -- quanto::qbytes_mm --------------------------------------------------------------------------
     def qbytes_mm(self, a, b, scales, bias=None, kernel: str = "auto"):

@@ -294,3 +294,17 @@ if _define("qbits_mm_multi",
            "int[] out_features, int in_features) -> Tensor[]"):
     _impl("qbits_mm_multi", "CompositeExplicitAutograd", qbits_mm_multi_default, True)
     _impl("qbits_mm_multi", "CUDA", qbits_mm_multi_hip, True)
+
+
+def qbytes_mm_multi_default(activations, weights, output_scales, bias):
+    return [torch.ops.quanto.qbytes_mm_bias(activations, weights[i], output_scales[i], bias[i]) for i in range(len(weights))]
+
+
+def qbytes_mm_multi_hip(activations, weights, output_scales, bias):
+    return quanto_hip.lib.qbytes_mm_multi(activations, list(weights), list(output_scales), list(bias))
+
+
+# the 8-bit counterpart: several WeightQBytes Linears applied to the same (float) input in one launch
+if _define("qbytes_mm_multi", "(Tensor A, Tensor[] B, Tensor[] scales, Tensor?[] bias) -> Tensor[]"):
+    _impl("qbytes_mm_multi", "CompositeExplicitAutograd", qbytes_mm_multi_default, True)
+    _impl("qbytes_mm_multi", "CUDA", qbytes_mm_multi_hip, True)

@@ -108,10 +108,10 @@ class QuantizedModelForCausalLM(QuantizedTransformersModel):
 # decode-time launch fusion: Linears that read the same activation (q/k/v, gate/up) in ONE quanto::qbits_mm_multi launch
 # ------------------------------------------------------------------------------------------------------------------------
 class _SiblingGroup:
-    """The frozen int4 QLinears of one parent module that are applied to the same input tensor.
+    """The frozen int4 (or int8 / fp8) QLinears of one parent module that are applied to the same input tensor.
 
     The model code is left alone (it still calls ``q_proj(h)``, ``k_proj(h)``, ``v_proj(h)`` one after the other): the first
-    sibling called with a decode-shaped input runs ``quanto::qbits_mm_multi`` for all of them and parks the other outputs,
+    sibling called with a decode-shaped input runs ``quanto::qbits_mm_multi`` / ``qbytes_mm_multi`` for all of them and parks the other outputs,
     which the following calls pick up when they arrive with the very same tensor object.  Anything else - another input, a
     prefill-sized input, an unfrozen weight, gradients - takes the module's normal forward."""
 
@@ -120,19 +120,25 @@ class _SiblingGroup:
         self.input = None      # strong reference: the storage cannot be recycled while outputs are parked
         self.outputs = {}
 
-    def eligible(self, x) -> bool:
-        if type(x) is not torch.Tensor or not x.is_cuda or x.numel() // x.shape[-1] > 64 or torch.is_grad_enabled() and x.requires_grad:
-            return False
-        from .tensor import WeightQBitsTensor
+    def kind(self, x):
+        """"qbits" (int4, group size 128), "qbytes" (int8 / fp8, per-channel scale) or None when the members cannot share a launch."""
+        rows = x.numel() // x.shape[-1] if type(x) is torch.Tensor and x.dim() > 0 else 0
+        if type(x) is not torch.Tensor or not x.is_cuda or not 1 <= rows <= 64 or torch.is_grad_enabled() and x.requires_grad:
+            return None
+        from .tensor import WeightQBitsTensor, WeightQBytesTensor
 
         w0 = self.modules[0].weight
-        for m in self.modules:
-            w = m.weight
-            if not (isinstance(w, WeightQBitsTensor) and w.qtype.bits == 4 and w._group_size == 128 and w.axis == 0
-                    and w.shape[1] == w0.shape[1] and w._shift.dtype == w0._shift.dtype and w.dtype == x.dtype
-                    and m.activation_qtype is None):
-                return False
-        return True
+        if any(m.activation_qtype is not None or m.weight.dtype != x.dtype or m.weight.shape[1] != w0.shape[1] for m in self.modules):
+            return None
+        if all(isinstance(m.weight, WeightQBitsTensor) for m in self.modules):
+            ok = all(w.qtype.bits == 4 and w._group_size == 128 and w.axis == 0 and w._shift.dtype == w0._shift.dtype
+                     for w in (m.weight for m in self.modules))
+            return "qbits" if ok else None
+        if all(type(m.weight) is WeightQBytesTensor for m in self.modules):
+            ok = all(w.axis == 0 and w._data.dtype == w0._data.dtype and w._scale.numel() == w.shape[0] and w._data.dim() == 2
+                     for w in (m.weight for m in self.modules))
+            return "qbytes" if ok else None
+        return None
 
     def forward(self, index: int, x):
         if self.input is x and index in self.outputs:
@@ -141,11 +147,16 @@ class _SiblingGroup:
                 self.input = None
             return y
         self.input, self.outputs = None, {}
-        if not self.eligible(x):
+        kind = self.kind(x)
+        if kind is None:
             return None
         ws = [m.weight for m in self.modules]
-        ys = torch.ops.quanto.qbits_mm_multi(x, [w._data._data for w in ws], [w._scale for w in ws], [w._shift for w in ws],
-                                             [m.bias for m in self.modules], 4, 128, [w.shape[0] for w in ws], ws[0].shape[1])
+        biases = [m.bias for m in self.modules]
+        if kind == "qbits":
+            ys = torch.ops.quanto.qbits_mm_multi(x, [w._data._data for w in ws], [w._scale for w in ws], [w._shift for w in ws], biases,
+                                                 4, 128, [w.shape[0] for w in ws], ws[0].shape[1])
+        else:
+            ys = torch.ops.quanto.qbytes_mm_multi(x, [w._data for w in ws], [w._scale for w in ws], biases)
         self.input = x
         self.outputs = {i: y for i, y in enumerate(ys) if i != index}
         return ys[index]

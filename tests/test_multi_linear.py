@@ -174,3 +174,99 @@ def test_fused_decode_projections_on_device():
     assert torch.equal(got1, ref1) and torch.equal(got[0], ref[0])  # the GEMV launches are bit-identical to the separate calls
     for a, b in zip(ref[1:], got[1:]):  # batched: same arithmetic, possibly another summation order over K
         torch.testing.assert_close(a.float(), b.float(), rtol=3e-2, atol=3e-2)
+
+
+# ---- quanto::qbytes_mm_multi: the 8-bit counterpart ------------------------------------------------------------------------------
+def _qbytes_problems(M, K, Ns, dt, dev, kind=None, seed=0):
+    from helpers import fp8_tensor, make_qbytes_problem
+
+    ps = [make_qbytes_problem(M, n, K, dt, kind=kind, seed=seed + 13 * i) for i, n in enumerate(Ns)]
+    x = to_torch(ps[0]["x"], dt, dev)
+    ws = [fp8_tensor(p["data"], kind, dev) if kind else torch.from_numpy(p["data"]).to(dev) for p in ps]
+    scales = [to_torch(p["scale"], dt, dev) for p in ps]
+    return ps, x, ws, scales
+
+
+def test_qbytes_multi_default_equals_separate_ops_cpu():
+    Ns, K = [64, 32, 16], 256
+    ps, x, ws, scales = _qbytes_problems(3, K, Ns, "fp32", "cpu")
+    biases = [None, torch.randn(32), None]
+    ys = torch.ops.quanto.qbytes_mm_multi(x, ws, scales, biases)
+    for i in range(3):
+        want = torch.ops.quanto.qbytes_mm(x, ws[i], scales[i])
+        assert torch.equal(ys[i], want if biases[i] is None else want + biases[i])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("kind", [None, "e4m3fn", "e5m2"])
+@pytest.mark.parametrize("M", [1, 2, 3, 16, 17, 33, 64])
+@pytest.mark.parametrize("Ns,K", [((4096, 1024, 1024), 4096), ((512, 256, 128, 64), 1024), ((1024, 1024), 14336), ((64, 64), 128)])
+def test_qbytes_multi_one_launch_gpu(dt, kind, M, Ns, K):
+    """int8 / fp8 weights, several Linears per launch: the GEMV for M <= 2 (bit-identical to the separate calls), the streaming
+    MFMA kernel up to 64 rows (exact-math gate per member; bias = rounded product + bias)."""
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    lib = quanto_hip.lib
+    ps, x, ws, scales = _qbytes_problems(M, K, list(Ns), dt, "cuda", kind=kind, seed=M)
+    rng = np.random.default_rng(M)
+    bias_np = [O.round_to(rng.standard_normal(n).astype(np.float32), dt) if i % 2 else None for i, n in enumerate(Ns)]
+    biases = [None if b is None else to_torch(b, dt, "cuda") for b in bias_np]
+    plain = torch.ops.quanto.qbytes_mm_multi(x, ws, scales, [None] * len(Ns))
+    assert lib.last_kernel() == ("gemv_multi" if M <= 2 else "skinny_multi")
+    ys = torch.ops.quanto.qbytes_mm_multi(x, ws, scales, biases)
+    for i, n in enumerate(Ns):
+        exact = O.qbytes_mm_exact(ps[0]["x"], ps[i]["data"], ps[i]["scale"], ps[i]["kind"])
+        y0 = to_numpy(plain[i])
+        assert_close_to_exact(y0, exact, dt, f"qbytes multi M={M} member {i} (N={n})")
+        if M <= 2:
+            assert torch.equal(plain[i], torch.ops.quanto.qbytes_mm(x, ws[i], scales[i]))
+        if bias_np[i] is None:
+            assert torch.equal(ys[i], plain[i])
+        else:
+            want = O.round_to(O.round_to(y0.astype(np.float32), dt) + bias_np[i][None, :], dt)
+            np.testing.assert_array_equal(to_numpy(ys[i]), want)
+
+
+@pytest.mark.gpu
+def test_qbytes_multi_fallbacks_and_fused_int8_model_gpu():
+    """Members that do not qualify (N not a multiple of 64 at M = 9) run as separate ops; an int8 tiny Llama decodes through the
+    fused launches with the same logits (GEMV launches: bit-identical)."""
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    lib = quanto_hip.lib
+    ps, x, ws, scales = _qbytes_problems(9, 512, [256, 48], "bf16", "cuda")
+    ys = torch.ops.quanto.qbytes_mm_multi(x, ws, scales, [None, None])
+    assert lib.last_kernel() not in ("gemv_multi", "skinny_multi")
+    for i in range(2):
+        assert torch.equal(ys[i], torch.ops.quanto.qbytes_mm(x, ws[i], scales[i]))
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                      vocab_size=160, max_position_embeddings=64)
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+    Q.QuantizedModelForCausalLM.quantize(model, weights=Q.qint8, exclude="lm_head")
+    model = model.cuda()
+    ids = torch.randint(1, cfg.vocab_size - 1, (2, 6), generator=torch.Generator().manual_seed(3)).cuda()
+    with torch.no_grad():
+        ref1 = model(ids[:1, :1]).logits
+        ref12 = model(ids).logits
+        assert Q.fuse_decode_projections(model) == 2 * cfg.num_hidden_layers
+        seen = set()
+        orig = lib.qbytes_mm_multi
+
+        def spy(*a, **k):
+            out = orig(*a, **k)
+            seen.add(lib.last_kernel())
+            return out
+
+        lib.qbytes_mm_multi = spy
+        try:
+            got1 = model(ids[:1, :1]).logits   # one row: GEMV launch
+            got12 = model(ids).logits          # 12 rows: streaming launch
+        finally:
+            del lib.qbytes_mm_multi
+    assert seen == {"gemv_multi", "skinny_multi"}, seen
+    assert torch.equal(got1, ref1)
+    torch.testing.assert_close(got12.float(), ref12.float(), rtol=3e-2, atol=3e-2)
