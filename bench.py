@@ -85,7 +85,7 @@ WORKLOADS = {
     "int8_decode32": ("qbytes_i8", 32, 4096, 4096, "bf16 x int8 qbytes_mm, per-channel scale, batched decode (M,K,N)=(32,4096,4096)"),
     "int4_decode32_up": ("qbits_i4", 32, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,14336)"),
 }
-DEFAULT_SUB = ["northstar", "cfg3", "qkv_fused", "gateup_fused", "int4_decode32", "qkv_fused32"]
+DEFAULT_SUB = ["northstar", "cfg3", "qkv_fused", "gateup_fused", "int4_decode32", "qkv_fused32", "int8_gateup_fused"]
 ARITH_DTYPE = {"qbytes_i8": "bf16", "qbytes_f8": "bf16", "qbits_i4": "bf16", "qbits_i4_multi": "bf16", "qbytes_i8_multi": "bf16", "qbytes_i8i8": "int8", "qbytes_f8f8": "fp8"}
 
 

@@ -53,7 +53,7 @@ def check_weight_qtensor_linear(qweight, batch_size, tokens, use_bias):
 def test_weight_qbits_tensor_linear_gpu(dtype, batch_size, tokens, in_features, out_features, use_bias):
     qbt = random_qweight((out_features, in_features), Q.qint4, dtype, group_size=128, device=DEV)
     check_weight_qtensor_linear(qbt, batch_size, tokens, use_bias)
-    assert quanto_hip.lib.last_kernel() in ("gemv", "skinny", "mfma", "dequant_mfma")
+    assert quanto_hip.lib.last_kernel() in ("gemv", "mmv", "skinny", "mfma", "mfma_fused4", "dequant_mfma")
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
