@@ -209,7 +209,7 @@ int quanto_hip_qbytes_mm_multi_plan(int count, const int64_t* N, int64_t M, int6
                                     int* kernel_out, int64_t* workspace_bytes_out);
 
 /*
- * Same, with a caller-provided scratch buffer.  Only the SKINNY kernel (float activations, 8 < M <= QUANTO_HIP_SKINNY_MAX_M)
+ * Same, with a caller-provided scratch buffer.  Only the SKINNY kernel (float activations, 2 < M <= QUANTO_HIP_SKINNY_MAX_M)
  * uses it, to split K across workgroups when N alone cannot occupy the chip: the buffer starts with arrival counters that MUST
  * BE ZERO on entry (the kernel leaves them zero), followed by fp32 partial sums - the contract of quanto_hip_qbits_mm's SKINNY
  * kernel.  With workspace == NULL the call is quanto_hip_qbytes_mm.  quanto_hip_qbytes_mm_pick returns the kernel AUTO selects.

@@ -1,4 +1,4 @@
-// qbits_mm for small batches (8 < M <= 64, e.g. batched decode): weight-streaming MFMA kernel over the generic
+// qbits_mm for small batches (4 < M <= 256 in passes of 64, e.g. batched decode): weight-streaming MFMA kernel over the generic
 // PackedTensor layout (int4, group size 128, N even).
 //
 // HBM-bound like the GEMV, but the products run on the matrix cores so the cost per weight byte does not grow with M:

@@ -1,4 +1,4 @@
-// qbytes_mm for small batches (8 < M <= 256, e.g. batched decode with int8 / fp8 weights): weight-streaming MFMA kernel.
+// qbytes_mm for small batches (2 < M <= 256 in passes of 64, e.g. batched decode with int8 / fp8 weights): weight-streaming MFMA kernel.
 //
 // The 8-bit sibling of qbits_skinny.hip - HBM-bound like the GEMV, products on the matrix cores so that the cost per weight
 // byte does not grow with M:
