@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(NW * 64) qbits_mmv_kernel(const Args a) {
   using V8 = typename Mma<DT>::V8;
   constexpr int L = FG * 2 + TF * 4;  // loads per tile and lane
   constexpr int NF = 16 * FG;         // features per block
+  constexpr int NFP = NF + 4;         // table row pitch: 8 bytes of padding against bank conflicts in the fill (qbits_skinny.hip)
   static_assert((D - 1) * L <= 63, "vmcnt immediate");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // [table: G x {scale, shift} x NF of T] then the cross-wave reduction buffer (re-uses the table's space)
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(NW * 64) qbits_mmv_kernel(const Args a) {
   };
 
   // ---- fill the ring, then the scale / shift table -------------------------------------------------------------------------
-  // sz[(g * 2 + which) * NF + f], f = q*16 + plane*8 + row: the lane's four consecutive features are 8 contiguous bytes.
+  // sz[(g * 2 + which) * NFP + f], f = q*16 + plane*8 + row: the lane's four consecutive features are 8 contiguous bytes.
   // The table loads are hipcc's: it waits for them with vmcnt(0), i.e. for the whole ring issued before them as well - one
   // first-byte latency for both (the other order would pay it twice).
 #pragma unroll
@@ -156,11 +157,11 @@ __global__ void __launch_bounds__(NW * 64) qbits_mmv_kernel(const Args a) {
       const int f = e / G, g = e - f * G;
       const int q = f >> 4, plane = (f >> 3) & 1, row = f & 7;
       const size_t idx = (size_t)(p0 + q * 8 + row + plane * P) * G + g;
-      sz[(g * 2 + 0) * NF + f] = reinterpret_cast<const T*>(a.scale)[idx];
+      sz[(g * 2 + 0) * NFP + f] = reinterpret_cast<const T*>(a.scale)[idx];
       if constexpr (INT_SHIFT)
-        sz[(g * 2 + 1) * NF + f] = E::from_f32((float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[idx]);
+        sz[(g * 2 + 1) * NFP + f] = E::from_f32((float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[idx]);
       else
-        sz[(g * 2 + 1) * NF + f] = reinterpret_cast<const T*>(a.shift)[idx];
+        sz[(g * 2 + 1) * NFP + f] = reinterpret_cast<const T*>(a.shift)[idx];
     }
   }
   __syncthreads();
@@ -207,8 +208,8 @@ __global__ void __launch_bounds__(NW * 64) qbits_mmv_kernel(const Args a) {
 #pragma unroll
     for (int q = 0; q < FG; ++q) {
       T s4t[4], z4t[4];
-      *reinterpret_cast<uint2*>(s4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 0) * NF + q * 16 + floc);
-      *reinterpret_cast<uint2*>(z4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 1) * NF + q * 16 + floc);
+      *reinterpret_cast<uint2*>(s4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 0) * NFP + q * 16 + floc);
+      *reinterpret_cast<uint2*>(z4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 1) * NFP + q * 16 + floc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float s = E::to_f32(s4t[r]);
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(NW * 64) qbits_mmv_kernel(const Args a) {
 }
 
 constexpr int lds_bytes(int tf, int fg, int G, int nw = 8) {
-  const int table = G * 2 * 16 * fg * 2, red = fg * tf * nw * 64 * 16;
+  const int table = G * 2 * (16 * fg + 4) * 2, red = fg * tf * nw * 64 * 16;
   return table > red ? table : red;
 }
 

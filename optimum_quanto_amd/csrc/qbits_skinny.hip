@@ -206,14 +206,18 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(Args a, const 
   // sz[g][0][f] = scale, sz[g][1][f] = shift (zero-points converted to T: small integers are exact),
   // f = plane*ROWS + local packed row; kept in the 16-bit storage type so that K = 14336 (112 groups) fits
   constexpr int NF = 2 * ROWS;  // features per block
+  // Row pitch of the table: NF + 4 entries.  With a pitch of NF (a multiple of 256 bytes for 64 features) the fill below - lanes
+  // run over the groups of one feature - put all 64 lanes of a ds_write_b16 on ONE bank (SQ_LDS_BANK_CONFLICT = 3970 cycles per
+  // block on the gate+up launch, 0.9 us of the (32,4096,4096) call); 8 bytes of padding spread them and keep the 8-byte reads aligned
+  constexpr int NFP = NF + 4;
   for (int e = tid; e < ((a.ablate & 16) ? 0 : NF * G); e += WAVES * 64) {
     const int f = e / G, g = e - f * G;
     const size_t idx = (size_t)(p0 + (f % ROWS) + (f / ROWS) * P) * a.G + kt0 + g;
-    sz[(g * 2 + 0) * NF + f] = reinterpret_cast<const T*>(a.scale)[idx];
+    sz[(g * 2 + 0) * NFP + f] = reinterpret_cast<const T*>(a.scale)[idx];
     if constexpr (INT_SHIFT)
-      sz[(g * 2 + 1) * NF + f] = E::from_f32((float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[idx]);
+      sz[(g * 2 + 1) * NFP + f] = E::from_f32((float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[idx]);
     else
-      sz[(g * 2 + 1) * NF + f] = reinterpret_cast<const T*>(a.shift)[idx];
+      sz[(g * 2 + 1) * NFP + f] = reinterpret_cast<const T*>(a.shift)[idx];
   }
 
   // ---- fragment read offsets ----------------------------------------------------------------------------------------
@@ -275,8 +279,8 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(Args a, const 
     }
     // fold the group: acc += s * acc_g - zz * XS
     T s4t[4], z4t[4];
-    *reinterpret_cast<uint2*>(s4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 0) * NF + floc);
-    *reinterpret_cast<uint2*>(z4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 1) * NF + floc);
+    *reinterpret_cast<uint2*>(s4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 0) * NFP + floc);
+    *reinterpret_cast<uint2*>(z4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 1) * NFP + floc);
     float s4[4], z4[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -396,7 +400,7 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(Args a, const 
   if (a.tl && tid == 0) a.tl[blockIdx.x * 32 + 31] = wall_clock64();
 }
 
-constexpr int lds_bytes(int tf, int stages, int G, int waves) { return stages * (waves * 8 * BK + tf * 16 * BK * 2) + G * 2 * (16 * waves) * 2; }
+constexpr int lds_bytes(int tf, int stages, int G, int waves) { return stages * (waves * 8 * BK + tf * 16 * BK * 2) + G * 2 * (16 * waves + 4) * 2; }
 
 // `segs` (with the total number of feature blocks) selects the multi-Linear launch; 4-wave blocks only
 template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES>
