@@ -127,8 +127,15 @@ struct Segs {
 };
 
 // WAVES per block: 4 (64 features per block), 2 or 1 (16 features) - so that any N that is a multiple of 16 is served.
-template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI = false>
-__global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(Args a, const Segs segs) {
+// SETS = 2 (64-feature blocks only): EIGHT waves, two sets of four with the same feature mapping.  The two tiles a barrier
+// interval consumes go to the two sets - set 0 takes the even tile, set 1 the odd one - instead of one after the other through
+// the single wave a SIMD has with SETS = 1: SQ counters of the four-wave kernel at (32,4096,4096) show waves WAITING (s_waitcnt,
+// s_barrier) 59 % of their cycles, with nobody on the SIMD to use them.  The sets' sums are added through LDS at the end
+// (set 0 + set 1: fixed order) and set 0 runs the split-K tail.  DMA: per pair of tiles one weight piece + TF activation pieces
+// per wave.
+template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI = false, int SETS = 1>
+__global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a, const Segs segs) {
+  static_assert(SETS == 1 || WAVES == 4, "two wave sets: 64-feature blocks only");
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
@@ -142,7 +149,8 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(Args a, const 
   T* sz = reinterpret_cast<T*>(smem + STAGES * STAGE_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0 .. WAVES * SETS - 1
+  const int set = SETS == 1 ? 0 : wave_id / WAVES, wave = SETS == 1 ? wave_id : wave_id % WAVES;  // wave = feature group of 16
   auto probe = [&](int slot) {
     if (a.tl && tid == 0) a.tl[blockIdx.x * 32 + slot] = __builtin_readcyclecounter();
   };
@@ -198,9 +206,46 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(Args a, const 
 #pragma unroll
     for (int u = 0; u < XP; ++u) glds16(xsrc[u] + (size_t)ktx * (BK * 2), st + W_BYTES + (wave * XP + u) * 1024);
   };
+  // SETS = 2: the pieces of a PAIR of tiles (even tile -> stage sa, odd tile -> stage sb) dealt over the eight waves: wave (set,
+  // f) carries weight piece f of the tile of its set and the activation pieces q = wave_id * TF + j of the 8 TF of the pair
+  const uint8_t* xsrc2[SETS == 2 ? TF : 1];
+  uint32_t xdst2[SETS == 2 ? TF : 1];
+  if constexpr (SETS == 2) {
 #pragma unroll
-  for (int t = 0; t < STAGES - 2; ++t)
-    if (t < nk) issue(t, t);
+    for (int j = 0; j < TF; ++j) {
+      const int q = wave_id * TF + j, odd = q / (4 * TF), piece = q % (4 * TF);
+      const int row = 4 * piece + (lane >> 4);
+      const int c = (lane & 15) ^ (row & 15);
+      const int m = row < M ? row : M - 1;
+      xsrc2[j] = reinterpret_cast<const uint8_t*>(reinterpret_cast<const T*>(a.x) + (size_t)m * K + c * 8 + (size_t)(kt0 + odd) * BK);
+      xdst2[j] = ((uint32_t)odd << 31) | (uint32_t)(W_BYTES + piece * 1024);  // bit 31: the odd tile's stage
+    }
+  }
+  auto issue_pair = [&](int kt, int sa, int sb) {  // kt even; the odd tile exists when kt + 1 < nk
+    const uint32_t sta = __builtin_amdgcn_readfirstlane(lds_base + sa * STAGE_BYTES), stb = __builtin_amdgcn_readfirstlane(lds_base + sb * STAGE_BYTES);
+    const bool has_odd = kt + 1 < nk;
+    if (set == 0 || has_odd) {
+      const uint32_t st = set == 0 ? sta : stb;
+      if (a.nt)
+        glds16_nt(wsrc + (size_t)(kt + set) * BK, st + wave * 1024);
+      else
+        glds16(wsrc + (size_t)(kt + set) * BK, st + wave * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < (SETS == 2 ? TF : 0); ++j) {
+      const bool odd = xdst2[j] >> 31;
+      if (!odd || has_odd) glds16(xsrc2[j] + (size_t)kt * (BK * 2), (odd ? stb : sta) + (xdst2[j] & 0x7FFFFFFFu));
+    }
+  };
+  if constexpr (SETS == 2) {
+#pragma unroll
+    for (int t = 0; t < STAGES - 2; t += 2)
+      if (t < nk) issue_pair(t, t, t + 1);
+  } else {
+#pragma unroll
+    for (int t = 0; t < STAGES - 2; ++t)
+      if (t < nk) issue(t, t);
+  }
 
   // ---- park scale / (shift + OFFSET*scale) of the block's 64 features and the XS rows in LDS ---------------------
   // sz[g][0][f] = scale, sz[g][1][f] = shift (zero-points converted to T: small integers are exact),
@@ -210,7 +255,7 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(Args a, const 
   // run over the groups of one feature - put all 64 lanes of a ds_write_b16 on ONE bank (SQ_LDS_BANK_CONFLICT = 3970 cycles per
   // block on the gate+up launch, 0.9 us of the (32,4096,4096) call); 8 bytes of padding spread them and keep the 8-byte reads aligned
   constexpr int NFP = NF + 4;
-  for (int e = tid; e < ((a.ablate & 16) ? 0 : NF * G); e += WAVES * 64) {
+  for (int e = tid; e < ((a.ablate & 16) ? 0 : NF * G); e += WAVES * SETS * 64) {
     const int f = e / G, g = e - f * G;
     const size_t idx = (size_t)(p0 + (f % ROWS) + (f / ROWS) * P) * a.G + kt0 + g;
     sz[(g * 2 + 0) * NFP + f] = reinterpret_cast<const T*>(a.scale)[idx];
@@ -305,19 +350,33 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(Args a, const 
     // tiles kt (and kt+1) have landed when at most the DMA of the tiles younger than them is outstanding
     const int last = pair ? kt + 1 : kt;
     const int younger = nk - 1 - last < STAGES - 4 ? nk - 1 - last : STAGES - 4;
-    wait_vmcnt<(STAGES - 4) * (1 + XP), 1 + XP>(younger);
+    if constexpr (SETS == 2)  // whole pairs only (a trailing single tile counts as none: waits for more, never for less)
+      wait_vmcnt<(STAGES - 4) / 2 * (1 + TF), 1 + TF>(younger / 2);
+    else
+      wait_vmcnt<(STAGES - 4) * (1 + XP), 1 + XP>(younger);
     __builtin_amdgcn_s_barrier();  // both tiles visible to all; everybody is done with the previous pair (and the tables are written)
     asm volatile("" ::: "memory");
     if (kt < 32) probe(3 + (kt >> 1));
     const int nxt = cur + 1 == STAGES ? 0 : cur + 1;
     {  // refill the two stages the previous pair occupied
       const int s0 = cur >= 2 ? cur - 2 : cur + STAGES - 2, s1 = s0 + 1 == STAGES ? 0 : s0 + 1;
-      if (kt + STAGES - 2 < nk) issue(kt + STAGES - 2, s0);
-      if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, s1);
+      if constexpr (SETS == 2) {
+        if (kt + STAGES - 2 < nk) issue_pair(kt + STAGES - 2, s0, s1);
+      } else {
+        if (kt + STAGES - 2 < nk) issue(kt + STAGES - 2, s0);
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, s1);
+      }
     }
     if (!(a.ablate & 2)) {
-      compute_tile(smem + cur * STAGE_BYTES, kt);
-      if (pair) compute_tile(smem + nxt * STAGE_BYTES, kt + 1);
+      if constexpr (SETS == 2) {
+        if (set == 0)
+          compute_tile(smem + cur * STAGE_BYTES, kt);
+        else if (pair)
+          compute_tile(smem + nxt * STAGE_BYTES, kt + 1);
+      } else {
+        compute_tile(smem + cur * STAGE_BYTES, kt);
+        if (pair) compute_tile(smem + nxt * STAGE_BYTES, kt + 1);
+      }
     }
     cur = nxt + 1 == STAGES ? 0 : nxt + 1;
   }
@@ -327,6 +386,23 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(Args a, const 
   // fence would be correct but writes back / invalidates a whole L2 (measured: 23 -> 57 us); instead the few KiB of partials
   // travel with system-coherent (sc0 sc1) 16-byte stores and loads and the only
   // ordering needed is "my stores are acknowledged (vmcnt(0)) before my workgroup's arrival is counted".
+  if constexpr (SETS == 2) {  // set 0 + set 1 through LDS (the ring is free: every DMA was consumed)
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    if (set == 1) {
+#pragma unroll
+      for (int tf = 0; tf < TF; ++tf) red[tf * 256 + (tid - 256)] = acc[tf];
+    }
+    __syncthreads();
+    if (set == 1) return;
+#pragma unroll
+    for (int tf = 0; tf < TF; ++tf) {
+      const f32x4 o = red[tf * 256 + tid];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[tf][r] += o[r];
+    }
+    __syncthreads();  // the tail re-uses smem[0] as its flag
+  }
   probe(20);
   if (S > 1 && (a.ablate & 1)) {
     if (sp != 0) return;
@@ -402,22 +478,29 @@ __global__ void __launch_bounds__(WAVES * 64) qbits_skinny_kernel(Args a, const 
 
 constexpr int lds_bytes(int tf, int stages, int G, int waves) { return stages * (waves * 8 * BK + tf * 16 * BK * 2) + G * 2 * (16 * waves + 4) * 2; }
 
-// `segs` (with the total number of feature blocks) selects the multi-Linear launch; 4-wave blocks only
+// `segs` (with the total number of feature blocks) selects the multi-Linear launch; 64-feature blocks only, like the two-set form
+template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI, int SETS>
+static int launch_k(const Args& a, hipStream_t stream, const Segs& segs, int grid, int lds) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS>), dim3(grid), dim3(WAVES * SETS * 64), lds, stream, a, segs);
+  return launch_status();
+}
+
 template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES>
 static int launch_s(const Args& a, hipStream_t stream, const Segs* segs = nullptr, int total_fb = 0) {
   const int lds = lds_bytes(TF, STAGES, a.G / a.S, WAVES);
   if constexpr (WAVES == 4) {
-    if (segs) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, 4, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, 4, true>), dim3(total_fb * a.S), dim3(256), lds, stream, a, *segs);
-      return launch_status();
-    }
+    // eight waves per block from two token fragments on (us, four -> eight waves: (32,4096,4096) 10.74 -> 10.21, (64,4096,4096)
+    // 17.6 -> 15.7, (32,14336,4096) 18.5 -> 17.7, gate+up M = 32 in one launch 29.5 -> 26.6; but one fragment, q/k/v M = 8:
+    // 9.87 -> 10.52: too little work per tile to share)
+    const bool two_sets = env_int("QUANTO_HIP_SKINNY_SETS", TF >= 2 ? 2 : 1) == 2;
+    if (segs)
+      return two_sets ? launch_k<DT, TF, STAGES, INT_SHIFT, 4, true, 2>(a, stream, *segs, total_fb * a.S, lds)
+                      : launch_k<DT, TF, STAGES, INT_SHIFT, 4, true, 1>(a, stream, *segs, total_fb * a.S, lds);
+    if (two_sets) return launch_k<DT, TF, STAGES, INT_SHIFT, 4, false, 2>(a, stream, Segs{}, a.N / 64 * a.S, lds);
   }
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES>), dim3(a.N / (16 * WAVES) * a.S), dim3(WAVES * 64), lds, stream, a, Segs{});
-  return launch_status();
+  return launch_k<DT, TF, STAGES, INT_SHIFT, WAVES, false, 1>(a, stream, Segs{}, a.N / (16 * WAVES) * a.S, lds);
 }
 
 // Deepest DMA pipeline that fits: the kernel is latency-bound per block (bytes in flight = stages x tile bytes).  Narrow
