@@ -493,7 +493,8 @@ static int launch_s(const Args& a, hipStream_t stream, const Segs* segs = nullpt
   if constexpr (WAVES == 4) {
     // eight waves per block from two token fragments on (us, four -> eight waves: (32,4096,4096) 10.74 -> 10.21, (64,4096,4096)
     // 17.6 -> 15.7, (32,14336,4096) 18.5 -> 17.7, gate+up M = 32 in one launch 29.5 -> 26.6; but one fragment, q/k/v M = 8:
-    // 9.87 -> 10.52: too little work per tile to share)
+    // 9.87 -> 10.52: too little work per tile to share; the 8-bit kernel of qbytes_skinny.hip gains nothing: int8 (32,4096,4096)
+    // 10.95 -> 10.96, gate+up in one launch 26.5 -> 26.7 - four times the weight bytes per tile, no group fold)
     const bool two_sets = env_int("QUANTO_HIP_SKINNY_SETS", TF >= 2 ? 2 : 1) == 2;
     if (segs)
       return two_sets ? launch_k<DT, TF, STAGES, INT_SHIFT, 4, true, 2>(a, stream, *segs, total_fb * a.S, lds)
