@@ -109,6 +109,40 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.quanto_hip_qbytes_mm_pick(4096, 4096, 4096, 3, 3, 2) == 6                         # int8 activations: native8
 
 
+def test_multi_linear_plans_without_a_gpu():
+    """Host logic of quanto_hip_q{bits,bytes}_mm_multi_plan: which single launch serves a group of Linears, and with what scratch."""
+    lib = quanto_hip.cdll
+    i64, ci = ctypes.c_int64, ctypes.c_int
+    lib.quanto_hip_qbits_mm_multi_plan.restype = ci
+    lib.quanto_hip_qbits_mm_multi_plan.argtypes = [ci, ctypes.POINTER(i64), i64, i64, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(i64)]
+    lib.quanto_hip_qbytes_mm_multi_plan.restype = ci
+    lib.quanto_hip_qbytes_mm_multi_plan.argtypes = [ci, ctypes.POINTER(i64), i64, i64, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(i64)]
+
+    def qbits(Ns, M, K, group=128):
+        k, ws = ci(-1), i64(-1)
+        assert lib.quanto_hip_qbits_mm_multi_plan(len(Ns), (i64 * len(Ns))(*Ns), M, K, 4, group, 2, ctypes.byref(k), ctypes.byref(ws)) == 0
+        return k.value, ws.value
+
+    def qbytes(Ns, M, K, a=2, b=3):
+        k, ws = ci(-1), i64(-1)
+        assert lib.quanto_hip_qbytes_mm_multi_plan(len(Ns), (i64 * len(Ns))(*Ns), M, K, a, b, 2, ctypes.byref(k), ctypes.byref(ws)) == 0
+        return k.value, ws.value
+
+    qkv, gate_up = [4096, 1024, 1024], [14336, 14336]
+    assert qbits(qkv, 1, 4096) == (2, 0) and qbits(gate_up, 4, 4096) == (2, 0)               # decode: one GEMV launch, no scratch
+    # batched decode: one streaming launch; q/k/v = 96 feature blocks -> K split 4 ways (counter region + fp32 partials, two fragments)
+    assert qbits(qkv, 32, 4096) == (5, 4096 + 96 * 4 * 256 * 2 * 16)
+    assert qbits(gate_up, 32, 4096) == (5, 0)                                                 # 448 feature blocks: no split, no scratch
+    assert qbits(qkv, 65, 4096)[0] == 0 and qbits([4096, 1000], 8, 4096)[0] == 0              # prefill-sized / ragged N: separate calls
+    assert qbits(qkv, 8, 4096, group=64)[0] == 0                                              # other group sizes: separate calls
+    assert qbytes(qkv, 1, 4096) == (2, 0) and qbytes(qkv, 2, 4096, b=5) == (2, 0)             # int8 / fp8 GEMV launch
+    assert qbytes(qkv, 32, 4096) == (5, 4096 + 96 * 4 * 256 * 2 * 16) and qbytes(gate_up, 16, 4096) == (5, 0)
+    assert qbytes(qkv, 32, 4096, a=3)[0] == 0                                                 # quantized activations: the native8 GEMM per member
+    assert qbytes([4096, 1000], 8, 4096)[0] == 0 and qbytes([4096], 8, 4096)[0] == 0          # ragged N / a single member
+    k, ws = ci(-1), i64(-1)
+    assert lib.quanto_hip_qbits_mm_multi_plan(5, (i64 * 5)(64, 64, 64, 64, 64), 1, 128, 4, 128, 2, ctypes.byref(k), ctypes.byref(ws)) == -1  # > QUANTO_HIP_MAX_MULTI
+
+
 def test_extension_registry_matches_reference_contract():
     # tests/library/test_extensions.py:19-39 in the reference: on ROCm the extension is called quanto_hip
     assert Q.is_extension_available("quanto_hip") == (torch.version.hip is not None)
