@@ -61,6 +61,7 @@ int qbits_mm_mfma(const void*, const uint8_t*, const void*, const void*, const v
                   size_t, hipStream_t);
 
 bool qbits_mfma_fused_supported(int64_t, const PackedGeom&, int);
+bool qbits_mfma_fused_needs_workspace(const PackedGeom&);
 size_t qbits_mfma_fused_workspace(int64_t, const PackedGeom&);
 int qbits_mm_mfma_fused(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, void*,
                         size_t, hipStream_t);
@@ -104,7 +105,8 @@ static size_t dequant_mfma_workspace(const PackedGeom& g) { return (size_t)g.N *
 // pass is amortised over several rounds or over thousands of rows (M <= 1024 measured).  QUANTO_HIP_FUSED4_MAX_WGS overrides the round limit in experiments.
 static bool fused4_wins(int64_t M, const PackedGeom& g) {
   const int64_t wgs = ((M + 127) / 128) * ((g.N + 127) / 128);
-  return M > 192 && M <= 1024 && wgs <= env_int("QUANTO_HIP_FUSED4_MAX_WGS", 256);
+  // long K (split-K form, r2): (256,14336,4096) 76.9 / 153 us, (512,...) 115.5 / 155, (1024,...) 214 / 159
+  return M > 192 && M <= (g.K > 8192 ? 512 : 1024) && wgs <= env_int("QUANTO_HIP_FUSED4_MAX_WGS", 256);
 }
 
 // The register-streaming kernel (K split inside the block, no split-K tail) against the LDS-streaming one, us per launch:
@@ -118,7 +120,8 @@ static bool mmv_wins(int64_t M, const PackedGeom& g) {
 static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {
   if (M <= 4 && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
   if (mmv_wins(M, g) && qbits_mmv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MMV;
-  if (fused4_wins(M, g) && qbits_mfma_fused_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MFMA_FUSED4;
+  if (fused4_wins(M, g) && qbits_mfma_fused_supported(M, g, dtype) && (have_workspace || !qbits_mfma_fused_needs_workspace(g)))
+    return QUANTO_HIP_KERNEL_MFMA_FUSED4;
   // the streaming kernel's time grows with M (passes of 64 rows), dequantize + dense GEMM is flat in M up to 1024 rows:
   // (M, 4096, 4096) us streaming / dequantize + GEMM: M = 128 34 / 56, M = 256 66 / 54; (256, 14336, 4096) 116 / 79; but
   // (256, 4096, 14336) 127 / 167

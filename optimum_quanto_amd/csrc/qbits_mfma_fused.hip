@@ -10,19 +10,18 @@
 // in registers with one fp16 rounding per weight.
 //
 // Where it pays.  dequantize + dense GEMM (c_api.hip, DEQUANT_MFMA) writes N*K*2 bytes and makes the GEMM read 4x the packed
-// bytes; for M up to ~1-2 k the dense GEMM is bound by the bytes a CU pulls per K-tile, not by the matrix pipe: (512,4096,4096)
-// takes 51 us against 27 us for the same shape with int8 weights.  This kernel streams the packed bytes (a quarter of the int8
-// kernel's weight traffic) and pays VALU instead: per group of 128 k and wave 64 MFMAs, 72 VALU for the operands and 128 for the
-// fold (one scaled group accumulator per output) - it is VALU-bound, which is why the workgroup tile is 64 tokens x 128 features with FOUR waves of
-// 64 tokens x 32 features (32 + 32 accumulator registers) and two workgroups per CU: at large M the dequantize pass is amortised
-// and the dense path wins again (dispatch in c_api.hip, thresholds measured).
+// bytes; for M up to ~1 k the dense GEMM is bound by the bytes a CU pulls per K-tile, not by the matrix pipe.  This kernel streams
+// the packed bytes (a quarter of the int8 kernel's weight traffic) and pays VALU instead: the operands (v_perm + v_and_or) and the
+// per-group fold (one scaled group accumulator per output) are three times the int8 kernel's VALU work per MFMA, so at large M,
+// where the dequantize pass is amortised over thousands of rows, the dense path wins again (dispatch in c_api.hip, measured).
 //
-// Structure: workgroup = 64 tokens x 64 packed rows (= 64 features of the low plane + the 64 features N/2 further of the high
-// plane); K-tile = one group (128 k).  Activations: LDS-DMA into a four-stage ring of 16 KiB tiles, three tiles ahead (256-byte rows, chunk ^ (row & 15)
-// swizzle on the DMA source, undone on the read - the layout of qbits_skinny.hip).  Weights: straight to registers, lane
-// (r = lane & 15, g = lane >> 4) loads bytes [16 g, 16 g + 16) and [64 + 16 g, ...) of packed row r of the tile, three tiles ahead
-// (four register sets).
-// Scales / shifts of the workgroup's 128 features for every group are parked in LDS once (16 KiB for K = 4096).
+// Structure: workgroup = 8 waves as 2 x 4 = 128 tokens x 64 packed rows (= 64 features of the low plane + the 64 features N/2
+// further of the high plane), wave = 64 tokens x 32 features; K-tile = one group (128 k).  Activations AND weights travel by LDS-DMA
+// into a ring of three 40 KiB stages, two tiles ahead (256-byte activation rows, chunk ^ (row & 15) on the DMA source, undone on the
+// read; 128-byte weight rows, chunk ^ (row & 7)).  Scales / shifts of the workgroup's 128 features for its groups are parked in LDS
+// once.  Split-K (r2) where the table of all groups does not fit (K = 14336): the groups are split over 2 or 4 workgroups per tile,
+// fp32 partial tiles go through the workspace (write-through stores, arrival counter, the last workgroup adds them in split order -
+// the protocol of qbits_skinny.hip).  It does not pay as a way to fill idle CUs (pick_split below).
 #include <type_traits>
 
 #include "qh_common.h"
@@ -82,6 +81,9 @@ struct Args {
   const void* bias;    // [N] or null
   void* y;             // [M, N]
   int M, N, K, G;
+  int S;               // K split: blockIdx.z handles groups [z * G / S, (z + 1) * G / S)
+  int* counters;       // [tiles] arrival counters, zero on entry and on exit (S > 1)
+  float* partials;     // [tiles][S][512 lanes][2 * MI] float4
 };
 
 template <int DT, bool INT_SHIFT>
@@ -100,7 +102,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
   const int M = a.M, N = a.N, K = a.K, G = a.G;
   const int P = N >> 1;
   const int p0 = blockIdx.x * PR, m0 = blockIdx.y * BM;
-  const int nk = G;  // one tile per group
+  const int S = a.S, sp = blockIdx.z;
+  const int nk = G / S;     // one tile per group; this workgroup's groups are kt0 .. kt0 + nk - 1
+  const int kt0 = sp * nk;
   const int fi = lane & 15, fg = lane >> 4;
 
   // ---- memory pipeline.  A tile lasts under a microsecond, a load from L2 / HBM under load 1-2 us: activations AND weights travel
@@ -132,8 +136,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
   auto issue_tile = [&](int kt_tile, int stage) {  // activation pieces + weight piece of one tile: XP + 1 DMA instructions
     const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
 #pragma unroll
-    for (int u = 0; u < XP; ++u) glds16(xbase + (size_t)kt_tile * (BK * 2), xsrc[u], st + (wave * XP + u) * 1024);
-    glds16(a.w + (size_t)kt_tile * BK, wsrc, st + X_BYTES + wave * 1024);
+    for (int u = 0; u < XP; ++u) glds16(xbase + (size_t)(kt0 + kt_tile) * (BK * 2), xsrc[u], st + (wave * XP + u) * 1024);
+    glds16(a.w + (size_t)(kt0 + kt_tile) * BK, wsrc, st + X_BYTES + wave * 1024);
   };
   const int last = nk - 1;
 
@@ -145,8 +149,8 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
     const int f = tid & (NF - 1);
     int p = p0 + (f & (PR - 1));
     p = p < P ? p : P - 1;
-    const size_t row = (size_t)(p + (f >> 6) * P) * G;
-    for (int g = tid >> 7; g < G; g += (WAVES * 64) >> 7) {
+    const size_t row = (size_t)(p + (f >> 6) * P) * G + kt0;
+    for (int g = tid >> 7; g < nk; g += (WAVES * 64) >> 7) {
       sz[(g * 2 + 0) * NF + f] = reinterpret_cast<const T*>(a.scale)[row + g];
       if constexpr (INT_SHIFT)
         sz[(g * 2 + 1) * NF + f] = E::from_f32((float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[row + g]);
@@ -290,6 +294,40 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-requested tiles past the end: nothing may land in LDS after the kernel moved on
 
+  // ---- split-K: fp32 partial tiles through the workspace, the last workgroup of a tile adds them in split order (qbits_skinny.hip) ----
+  if (S > 1) {
+    const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    float* mine = a.partials + ((size_t)(tile_id * S + sp) * (WAVES * 64) + tid) * (2 * MI * 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)  // s_nop: gfx9 hazard "VMEM store of > 64 bits, then VALU write of its data VGPRs"
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + (j * MI + i) * 4), "v"(acc[j][i]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) *flag = __hip_atomic_fetch_add(a.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (*flag != S - 1) return;
+    if (tid == 0) __hip_atomic_store(a.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // leave the workspace as found
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < S; ++q) {  // fixed order: the result does not depend on which workgroup arrived last
+      const float* theirs = a.partials + ((size_t)(tile_id * S + q) * (WAVES * 64) + tid) * (2 * MI * 4);
+      f32x4 v[2 * MI];
+#pragma unroll
+      for (int e = 0; e < 2 * MI; ++e) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[e]) : "v"(theirs + e * 4) : "memory");
+#pragma unroll
+      for (int e = 0; e < 2 * MI; ++e) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[e])::"memory");  // ties the uses below to the wait
+#pragma unroll
+      for (int e = 0; e < 2 * MI; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[e / MI][e % MI][r] += v[e][r];
+    }
+  }
+
   // ---- epilogue: 4 consecutive features of one token per (plane, fragment): 8-byte stores --------------------------------------------
   T* yg = reinterpret_cast<T*>(a.y);
   const bool has_bias = a.bias != nullptr;
@@ -325,13 +363,30 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
   }
 }
 
-inline int lds_bytes(int G) { return STAGES * STAGE_BYTES + G * 2 * (2 * PR) * 2; }
+inline int lds_bytes(int groups) { return STAGES * STAGE_BYTES + groups * 2 * (2 * PR) * 2; }
+
+inline int tiles_of(int64_t M, int64_t N) { return (int)(((N / 2 + PR - 1) / PR) * ((M + BM - 1) / BM)); }
+
+// K split.  Measured (us, unsplit / 2 / 4): (512,4096,4096) 49.7 / 52.6 / 80.8 - a split costs a 64 KiB fp32 partial tile per
+// workgroup through the fabric and back, which eats what the idle CUs would give - so K is split only where the scale table of
+// all groups does not fit the LDS (K = 14336), and then as far as the tiles leave CUs idle: (256,14336,4096) 76.9 us with 4 splits
+// against 153 us for dequantize + dense GEMM, (512,14336,4096) 115.5 against 155.
+inline int pick_split(int64_t M, int64_t N, int G) {
+  const int forced = env_int("QUANTO_HIP_FUSED4_SPLIT", 0);
+  if (forced > 0 && G % forced == 0) return forced;
+  if (lds_bytes(G) <= 160 * 1024) return 1;
+  const int tiles = tiles_of(M, N);
+  int s = 1;
+  while (s < 4 && G % (s * 2) == 0 && (lds_bytes(G / s) > 160 * 1024 || tiles * s * 2 <= 256)) s *= 2;
+  if ((size_t)tiles * 4 > QUANTO_HIP_WS_COUNTER_BYTES) s = 1;
+  return s;
+}
 
 template <int DT, bool INT_SHIFT>
 static int launch(const Args& a, hipStream_t stream) {
-  const int lds = lds_bytes(a.G);
+  const int lds = lds_bytes(a.G / a.S);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_mfma_fused_kernel<DT, INT_SHIFT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  const dim3 grid((unsigned)((a.N / 2 + PR - 1) / PR), (unsigned)((a.M + BM - 1) / BM));
+  const dim3 grid((unsigned)((a.N / 2 + PR - 1) / PR), (unsigned)((a.M + BM - 1) / BM), (unsigned)a.S);
   hipLaunchKernelGGL((qbits_mfma_fused_kernel<DT, INT_SHIFT>), grid, dim3(WAVES * 64), lds, stream, a);
   return launch_status();
 }
@@ -340,19 +395,31 @@ static int launch(const Args& a, hipStream_t stream) {
 
 bool qbits_mfma_fused_supported(int64_t M, const PackedGeom& g, int dtype) {
   return g.bits == 4 && g.C == 128 && (g.N % 8 == 0) && (g.K % 128 == 0) && M >= 1 && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) &&
-         g.N < (1 << 30) && g.K < (1 << 30) && M * g.K < (1ll << 31) && g.N * g.K < (1ll << 33) && fused4::lds_bytes((int)g.G) <= 160 * 1024;
+         g.N < (1 << 30) && g.K < (1 << 30) && M * g.K < (1ll << 31) && g.N * g.K < (1ll << 33) &&
+         fused4::lds_bytes((int)g.G / fused4::pick_split(M, g.N, (int)g.G)) <= 160 * 1024;
 }
 
-// no scratch: the group sums of x come from the matrix pipe
-size_t qbits_mfma_fused_workspace(int64_t, const PackedGeom&) { return 0; }
+// true when the problem cannot run without the split-K scratch (the scale table of all groups does not fit the LDS: K = 14336)
+bool qbits_mfma_fused_needs_workspace(const PackedGeom& g) { return fused4::lds_bytes((int)g.G) > 160 * 1024; }
+
+// [counters (zero on entry, zero on exit) | fp32 partial tiles]; 0 when K is not split (the group sums of x come from the matrix pipe)
+size_t qbits_mfma_fused_workspace(int64_t M, const PackedGeom& g) {
+  const int S = fused4::pick_split(M, g.N, (int)g.G);
+  if (S == 1) return 0;
+  return QUANTO_HIP_WS_COUNTER_BYTES + (size_t)fused4::tiles_of(M, g.N) * S * (fused4::WAVES * 64) * (2 * fused4::MI * 16);
+}
 
 int qbits_mm_mfma_fused(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t M,
                         const PackedGeom& g, int dtype, bool int_shift, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbits_mfma_fused_supported(M, g, dtype)) return QUANTO_HIP_ENOTSUP;
-  (void)workspace;
-  (void)workspace_bytes;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed)) % 16) return QUANTO_HIP_EALIGN;
-  fused4::Args a{x, packed, scale, shift, bias, y, (int)M, (int)g.N, (int)g.K, (int)g.G};
+  int S = fused4::pick_split(M, g.N, (int)g.G);
+  if (S > 1 && (!workspace || workspace_bytes < qbits_mfma_fused_workspace(M, g) || reinterpret_cast<uintptr_t>(workspace) % 16)) {
+    S = 1;  // no scratch: unsplit, if the whole scale table fits
+    if (fused4::lds_bytes((int)g.G) > 160 * 1024) return QUANTO_HIP_EINVAL;
+  }
+  fused4::Args a{x, packed, scale, shift, bias, y, (int)M, (int)g.N, (int)g.K, (int)g.G, S, reinterpret_cast<int*>(workspace),
+                 S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + QUANTO_HIP_WS_COUNTER_BYTES) : nullptr};
   if (dtype == QUANTO_HIP_BF16)
     return int_shift ? fused4::launch<QUANTO_HIP_BF16, true>(a, stream) : fused4::launch<QUANTO_HIP_BF16, false>(a, stream);
   return int_shift ? fused4::launch<QUANTO_HIP_F16, true>(a, stream) : fused4::launch<QUANTO_HIP_F16, false>(a, stream);

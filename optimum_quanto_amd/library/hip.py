@@ -283,7 +283,7 @@ class _Bindings:
                 k, ws_bytes = KERNEL_NAIVE, 0  # misaligned view: the kernel without an alignment requirement (what AUTO does in C)
             if ws_bytes == 0:
                 ws = None
-            elif k == KERNEL_SKINNY:
+            elif k in (KERNEL_SKINNY, KERNEL_MFMA_FUSED4):
                 ws = self._zeroed_workspace(x.device, ws_bytes, self._stream(x).value)  # split-K arrival counters: zero on entry, left zero by the kernel
             else:
                 ws = self._scratch(x.device, ws_bytes, self._stream(x).value)

@@ -225,9 +225,26 @@ def test_qbits_mfma_fused4_llama_prefill():
         y = _run_qbits(p, "auto")
         assert quanto_hip.lib.last_kernel() == "mfma_fused4"
         assert_close_to_exact(y, _exact_qbits(p), "bf16", f"auto -> mfma_fused4 {M}x{K}x{N}")
-    p = make_qbits_problem(512, 4096, 14336, "bf16", seed=7)  # K = 14336: the scale table does not fit the LDS next to the ring
+    p = make_qbits_problem(512, 4096, 14336, "bf16", seed=7)  # K = 14336: the scale table fits once K is split over two workgroups
     y = _run_qbits(p, "auto")
-    assert quanto_hip.lib.last_kernel() == "dequant_mfma"
+    assert quanto_hip.lib.last_kernel() == "mfma_fused4"
+    assert_close_to_exact(y, _exact_qbits(p), "bf16", "auto -> mfma_fused4 (split-K) 512x14336x4096")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("split", [1, 2, 4])
+@pytest.mark.parametrize("M,N,K,zp", [(200, 256, 1024, False), (300, 520, 2048, True), (130, 136, 512, False)])
+def test_qbits_mfma_fused4_split_k(dt, split, M, N, K, zp, monkeypatch):
+    """K split over 1 / 2 / 4 workgroups per tile (fp32 partial tiles through the workspace, last arriver adds in split order):
+    ragged M / N, zero-points, bias; a second call on the same workspace (counters left zero); unsplit when the split does not
+    divide the groups."""
+    monkeypatch.setenv("QUANTO_HIP_FUSED4_SPLIT", str(split))
+    p = make_qbits_problem(M, N, K, dt, zeropoint=zp, seed=M + N + split)
+    y0 = _run_qbits(p, "mfma_fused4")
+    assert_close_to_exact(y0, _exact_qbits(p), dt, f"mfma_fused4 split {split} {M}x{K}x{N}")
+    np.testing.assert_array_equal(_run_qbits(p, "mfma_fused4"), y0)
+    bias = O.round_to(np.random.default_rng(5).standard_normal(N).astype(np.float32), dt)
+    np.testing.assert_array_equal(_run_qbits(p, "mfma_fused4", bias), O.round_to((y0 + bias).astype(np.float32), dt))
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
