@@ -164,7 +164,7 @@ int quanto_hip_qbits_mm_multi_plan(int count, const int64_t* N, int64_t M, int64
  * Scratch bytes quanto_hip_qbits_mm needs for this problem (0 when the selected kernel needs none).
  * The caller allocates it (16-byte aligned), passes it as `workspace` and may reuse it for any later
  * call on the same stream.  The MFMA kernel stores the per-group row sums of x there
- * (fp32 [K/group_size][roundup(M,128)]; MFMA_FUSED4 needs no scratch); the DEQUANT_MFMA path stores the dequantized weight (dtype[N, K]).
+ * (fp32 [K/group_size][roundup(M,128)]; MFMA_FUSED4 needs none unless it splits K - K > 8192 - then zeroed counters + fp32 partial tiles); the DEQUANT_MFMA path stores the dequantized weight (dtype[N, K]).
  * The SKINNY kernel splits K across workgroups when N alone cannot occupy the chip: its workspace starts with
  * QUANTO_HIP_WS_COUNTER_BYTES bytes of arrival counters that MUST BE ZERO on entry (the kernel leaves them zero), followed by
  * fp32 partial sums; without a workspace it runs unsplit.  quanto_hip_qbits_mm_pick tells which kernel AUTO selects, so
