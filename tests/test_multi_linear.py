@@ -197,6 +197,24 @@ def test_qbytes_multi_default_equals_separate_ops_cpu():
         assert torch.equal(ys[i], want if biases[i] is None else want + biases[i])
 
 
+def test_fuse_decode_projections_int8_model_is_transparent_on_cpu():
+    """8-bit siblings are linked as well; on CPU tensors the groups never engage and the logits do not change."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    cfg = LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+                      vocab_size=96, max_position_embeddings=32)
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+    Q.QuantizedModelForCausalLM.quantize(model, weights=Q.qint8, exclude="lm_head")
+    ids = torch.randint(1, 95, (2, 5), generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        ref = model(ids).logits
+        assert Q.fuse_decode_projections(model) == 2
+        group = model.model.layers[0].self_attn.q_proj._sibling_group
+        assert group.kind(torch.zeros(2, 128, dtype=torch.bfloat16)) is None  # CPU tensor: not eligible
+        assert torch.equal(model(ids).logits, ref)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("kind", [None, "e4m3fn", "e5m2"])
