@@ -22,10 +22,17 @@ Method (same formulas as the reference's bench/kernels/benchmark_w4a16.py:44-71:
     against the imported reference in tests/test_reference_integration.py) - on the FULL shape and the SAME tensors the
     GPU side just multiplied, on the GPU box's host cores: median + IQR + thread count.
 
-With N > 1 (``python -m torch.distributed.run``) every rank runs the same workload on its own GPU: the path is
-embarrassingly parallel per Linear, no data-path collective, weak scaling; ``value`` aggregates over ranks / max-over-ranks
-time.  ``--shard`` instead column-shards ONE Linear (``configs[3]``: fp8 weights, (512,8192,8192)) over the ranks with
-``ColumnParallelQLinear`` and times compute-only and compute + all_gather (RCCL over xGMI) - SURVEY.md 8(e).
+With N > 1 every rank runs the same workload on its own GPU: the path is embarrassingly parallel per Linear, no data-path
+collective, weak scaling; ``value`` aggregates over ranks / max-over-ranks time.  The ranks come from the launcher
+(``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: RANK / LOCAL_RANK / WORLD_SIZE in the environment) or,
+when ``--gpus N`` is given with no launcher around it, from bench.py itself (it re-executes under torch.distributed.run on
+127.0.0.1).  At N > 1 the default run appends one more sub-result, ``cfg4_sharded``: ``configs[3]`` (fp8 weights, (512,8192,8192))
+column-sharded over the ranks with ``ColumnParallelQLinear``, compute-only and compute + ``all_gather_into_tensor`` (RCCL over xGMI),
+``"scaling": "strong"`` - SURVEY.md 8(e); ``--shard`` makes that the headline line instead.
+
+The printed line is kept under ~6 KB (the driver keeps an 8 KB stdout tail): sub-results are compact records (name, shape, us,
+kernel, fraction, algorithmic bytes / flops, counter traffic, CPU seconds), the prose that explains the CPU paths is printed once
+(``cpu_paths``); ``--verbose`` prints every sub-result in full on stderr.
 """
 import argparse
 import json
@@ -85,7 +92,19 @@ WORKLOADS = {
     "int8_decode32": ("qbytes_i8", 32, 4096, 4096, "bf16 x int8 qbytes_mm, per-channel scale, batched decode (M,K,N)=(32,4096,4096)"),
     "int4_decode32_up": ("qbits_i4", 32, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,14336)"),
 }
-DEFAULT_SUB = ["northstar", "cfg3", "qkv_fused", "gateup_fused", "int4_decode32", "qkv_fused32", "int8_gateup_fused"]
+DEFAULT_SUB = ["northstar", "cfg3", "cfg4", "qkv_fused", "gateup_fused", "int4_decode32", "qkv_fused32", "int8_gateup_fused", "int4_prefill512"]
+# printed ONCE per JSON line (r2's line repeated this prose in every sub-result, grew past the driver's 8 KB stdout tail and lost
+# its first two sub-results): what cpu_baseline.kind == "reference" and each cpu_baseline.path code stand for
+CPU_BASELINE_NOTE = {
+    "reference": "the ATen kernels the reference's CPU QLinear path executes, issued in its order by oracle/reference_cpu_path.py "
+                 "(torch.equal to the imported reference in the build container); same tensors as the GPU leg, full shape, all host threads",
+    "int8pack": "torch._weight_int8pack_mm, library/qbytes_mm.py:91-105",
+    "int_mm": "torch._int_mm + fp32 rescale, library/qbytes_mm.py:36-50",
+    "fp8_generic": "cast fp8->bf16, scale the weight, matmul, library/qbytes_mm.py:25-33",
+    "int4_generic": "generic WeightQBitsTensor: unpack+dequantize+matmul per call, tensor/qbits.py:27-49, tensor/function.py:41-47",
+    "tinygemm": "TinyGemmWeightQBitsTensor (create()'s CPU choice for bf16 scales): torch._weight_int4pack_mm_for_cpu, "
+                "tensor/weights/tinygemm/qbits.py:51-58; lossy shift repack at load time",
+}
 ARITH_DTYPE = {"qbytes_i8": "bf16", "qbytes_f8": "bf16", "qbits_i4": "bf16", "qbits_i4_multi": "bf16", "qbytes_i8_multi": "bf16", "qbytes_i8i8": "int8", "qbytes_f8f8": "fp8"}
 
 
@@ -203,9 +222,7 @@ def cpu_baseline(kind, M, K, N, x, wset, budget_s):
     from oracle import reference_cpu_path as R
 
     xc = x.cpu()
-    out = {"kind": "reference", "cores": torch.get_num_threads(),
-           "how": "the ATen kernels the reference's CPU QLinear path executes, issued in its order by oracle/reference_cpu_path.py "
-                  "(torch.equal to the imported reference in the build container); same tensors as the GPU leg, full shape"}
+    out = {"kind": "reference", "cores": torch.get_num_threads()}  # what "reference" means: CPU_BASELINE_NOTE, printed once per line
     if kind in ("qbits_i4", "qbits_i4_multi"):
         parts = wset if kind == "qbits_i4_multi" else [wset]
         Ns = list(N) if isinstance(N, tuple) else [N]
@@ -215,24 +232,19 @@ def cpu_baseline(kind, M, K, N, x, wset, budget_s):
         tiny = lambda: [R.tinygemm_linear(xc, d, 128, ss, n) for (d, ss), n in zip(tg, Ns)]  # noqa: E731
         t_gen = R.time_call(generic, budget_s)
         t_tiny = R.time_call(tiny, min(budget_s, 3.0), min_calls=20, max_calls=200)
-        out["path"] = "generic WeightQBitsTensor: unpack + dequantize + matmul per call (tensor/qbits.py:27-49, tensor/function.py:41-47)"
+        out["path"] = "int4_generic"
         t = t_gen
-        out["tinygemm"] = {"path": "TinyGemmWeightQBitsTensor, what create() selects for bf16 scales on CPU: torch._weight_int4pack_mm_for_cpu "
-                                   "(tensor/weights/tinygemm/qbits.py:51-58); lossy shift repack at load time",
-                           "seconds_per_call": round(t_tiny["median_s"], 6), "iqr_s": round(t_tiny["iqr_s"], 6), "calls": t_tiny["calls"]}
+        out["tinygemm"] = {"seconds_per_call": round(t_tiny["median_s"], 6), "iqr_s": round(t_tiny["iqr_s"], 6), "calls": t_tiny["calls"]}
     else:
         parts = [(w.cpu(), sc.cpu()) for w, sc in (wset if kind == "qbytes_i8_multi" else [wset])]
         fn = lambda: [R.qbytes_mm_cpu(xc, wc, sc) for wc, sc in parts]  # noqa: E731
         t = R.time_call(fn, budget_s)
-        out["path"] = {"qbytes_i8": "torch._weight_int8pack_mm (library/qbytes_mm.py:91-105, bf16 x int8 branch)",
-                       "qbytes_i8_multi": "torch._weight_int8pack_mm per member (library/qbytes_mm.py:91-105, bf16 x int8 branch)",
-                       "qbytes_i8i8": "torch._int_mm + fp32 rescale (library/qbytes_mm.py:36-50)"}.get(
-                           kind, "generic: cast fp8 -> bf16, scale the weight, matmul (library/qbytes_mm.py:25-33)")
+        out["path"] = {"qbytes_i8": "int8pack", "qbytes_i8_multi": "int8pack", "qbytes_i8i8": "int_mm"}.get(kind, "fp8_generic")
     flops, nbytes = algorithmic_work(kind, M, K, N)
     compute_bound = M > 64
     out["value"] = round(flops / t["median_s"] / 1e12, 5) if compute_bound else round(nbytes / t["median_s"] / 1e9, 4)
     out["unit"] = "TFLOP/s" if compute_bound else "GB/s"
-    out["sample"] = f"full call (M,K,N)=({M},{K},{N}), {t['calls']} timed calls after 3 warm-up calls"
+    out["sample"] = f"full call, {t['calls']} timed calls after 3 warm-up"
     out["seconds_per_call"] = round(t["median_s"], 6)
     out["iqr_s"] = round(t["iqr_s"], 6)
     out["calls_timed"] = t["calls"]
@@ -327,7 +339,7 @@ def run_workload(name, args, device, rank, world, dist, steps, with_cpu):
     if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (profiles/README.md)
         rec = json.load(open(pmc))
         roof["traffic"] = rec.get("hbm_bytes_per_launch")
-        roof["traffic_source"] = f"profiles/pmc_{name}.json: builder-run rocprofv3 --pmc passes ({rec.get('round', 'r01')}), not measured in this run"
+        roof["traffic_source"] = f"profiles/pmc_{name}.json ({rec.get('round', 'r01')} builder-run rocprofv3 --pmc passes, not this run)"
     out = {
         "metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -348,7 +360,7 @@ def run_workload(name, args, device, rank, world, dist, steps, with_cpu):
 
 def run_sharded(args, device, rank, world, dist):
     """configs[3], ONE Linear column-sharded over the ranks (parallel.py): rank r multiplies x by its N/G output features,
-    one all_gather rebuilds y.  Times compute only and compute + all_gather, both as max over ranks."""
+    one all_gather_into_tensor rebuilds y.  Times compute only and compute + all_gather, both as max over ranks."""
     import optimum_quanto_amd as Q
     from optimum_quanto_amd.parallel import ColumnParallelQLinear, shard_qweight
 
@@ -396,10 +408,64 @@ def run_sharded(args, device, rank, world, dist):
             "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t * 1e3, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "bf16 x fp8-e4m3fn qbytes_mm, (M,K,N)=(512,8192,8192), output features sharded over the ranks + all_gather",
-                       "M": M, "K": K, "N": N, "launch": "eager (the collective is issued by torch.distributed)",
-                       "parallelism": f"column shard x{world}, one all_gather of [M, N/{world}] per call"},
+                       "name": "cfg4_sharded", "M": M, "K": K, "N": N, "launch": "eager (the collective is issued by torch.distributed)",
+                       "parallelism": f"column shard x{world}, one all_gather_into_tensor of [M, N/{world}] per call"},
             "compute_only_us": round(results["compute_only"] * 1e6, 2), "with_all_gather_us": round(t * 1e6, 2),
             "compute_only_tflops": round(flops / results["compute_only"] / 1e12, 3)}
+
+
+def run_stub(args, rank, world, dist):
+    """Test-only (--stub): the launch / barrier / max-over-ranks / rank-0-prints skeleton of this file on CPU tensors over gloo, so
+    that `bench.py --gpus 2` can be exercised where there is no GPU (tests/test_bench_cli.py).  Measures nothing of the product."""
+    x = torch.randn(64, 64)
+    for _ in range(args.warmup):
+        x @ x
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x @ x
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    if rank != 0:
+        return None
+    return {"metric": "stub", "value": round(world * args.steps / elapsed, 3), "unit": "calls/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "stub", "config": {"workload": "CPU stub over gloo (test only)"}}
+
+
+def compact(r):
+    """A sub-result in ~300 bytes: everything the reader needs to recompute the roofline fraction, nothing repeated."""
+    roof, cfg = r["roofline"], r["config"]
+    out = {"name": cfg["name"], "M": cfg["M"], "K": cfg["K"], "N": cfg["N"], "value": r["value"], "unit": r["unit"], "steps": r["steps"],
+           "us_per_step": round(r["ms_per_step"] * 1e3, 3), "launch_us": roof["launch_us"], "kernel": roof["kernel"], "bound": roof["bound"],
+           "frac": roof["frac"], "alg_bytes": int(roof["algorithmic_bytes"]), "alg_flops": int(roof["algorithmic_flops"]),
+           "traffic": roof["traffic"], "rot": cfg["weight_buffers_rotated"]}
+    if "cpu_baseline" in r:
+        c = r["cpu_baseline"]
+        out["cpu"] = {"v": c["value"], "unit": c["unit"], "s": c["seconds_per_call"], "iqr_s": c["iqr_s"], "path": c["path"]}
+        if "tinygemm" in c:
+            out["cpu"]["tinygemm_GBs"] = c["tinygemm"]["value"]
+    return out
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks of this same command, one per GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -412,24 +478,43 @@ def main():
     ap.add_argument("--no-sub", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=6.0, help="seconds of host time per timed CPU path")
-    ap.add_argument("--shard", action="store_true", help="configs[3] column-sharded over the ranks (ColumnParallelQLinear + all_gather)")
+    ap.add_argument("--shard", action="store_true", help="configs[3] column-sharded over the ranks (ColumnParallelQLinear + all_gather) as the headline line")
     ap.add_argument("--eager", action="store_true", help="issue the timed steps one by one from Python instead of replaying a hipGraph")
     ap.add_argument("--ramp-ms", type=float, default=300.0,
                     help="untimed: keep the device busy with the same steps for this long before the timed region (clock ramp)")
+    ap.add_argument("--verbose", action="store_true", help="also print every sub-result in full on stderr")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # test-only: CPU + gloo skeleton run (run_stub)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    use_gpu = not args.stub
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if use_gpu and torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.stub:
+        out = run_stub(args, rank, world, dist)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
 
     import optimum_quanto_amd  # noqa: F401  registers the quanto:: ops; raises if the HIP library cannot be loaded later
 
@@ -444,12 +529,26 @@ def main():
             # decode launches last a few microseconds: time at least 200 of them so that the event pair brackets milliseconds
             r = run_workload(name, args, device, rank, world, dist, max(args.steps, 200), with_cpu)
             if r is not None:
-                keep = ("metric", "value", "unit", "steps", "ms_per_step", "dtype", "config", "tflops", "gbps", "roofline", "cpu_baseline")
-                sub_results.append({k: r[k] for k in keep if k in r})
+                if args.verbose:
+                    print(json.dumps(r), file=sys.stderr, flush=True)
+                sub_results.append(compact(r))
+        if world > 1 and not args.no_sub and args.workload == "cfg2":
+            # N > 1: the one place the path has a collective - configs[3] column-sharded over the ranks, strong scaling
+            r = run_sharded(args, device, rank, world, dist)
+            if r is not None:
+                sub_results.append({"name": "cfg4_sharded", "scaling": "strong", "n_gpus": world, "value": r["value"], "unit": r["unit"],
+                                    "compute_only_us": r["compute_only_us"], "with_all_gather_us": r["with_all_gather_us"],
+                                    "compute_only_tflops": r["compute_only_tflops"], "parallelism": r["config"]["parallelism"]})
         if out is not None and sub_results:
             out["sub_results"] = sub_results
+        if out is not None and "cpu_baseline" in out:
+            out["cpu_baseline"]["how"] = CPU_BASELINE_NOTE["reference"]
+            used = {out["cpu_baseline"]["path"]} | {sr["cpu"]["path"] for sr in sub_results if "cpu" in sr}
+            if any("tinygemm_GBs" in sr.get("cpu", {}) for sr in sub_results):
+                used.add("tinygemm")
+            out["cpu_paths"] = {k: CPU_BASELINE_NOTE[k] for k in sorted(used)}
     if rank == 0 and out is not None:
-        print(json.dumps(out))
+        print(json.dumps(out, separators=(",", ":")), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

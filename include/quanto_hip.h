@@ -63,7 +63,7 @@ typedef enum {
   QUANTO_HIP_KERNEL_NATIVE8 = 6, /* qbytes_mm with quantized activations: int8 x int8 (i32 MFMA) / fp8 x fp8 (fp8 MFMA) */
   QUANTO_HIP_KERNEL_DEQUANT_MFMA = 7, /* qbits_mm, large M: fused dequantize into the workspace + 256x256 dense MFMA GEMM */
   QUANTO_HIP_KERNEL_MFMA_FUSED4 = 8,  /* qbits_mm, prefill-sized M: packed int4 -> MFMA operands in registers, per-group fp32 fold */
-  QUANTO_HIP_KERNEL_MMV = 9           /* qbits_mm, 4 < M <= 32: register-streaming MFMA kernel, K split over the waves of a block (no workspace) */
+  QUANTO_HIP_KERNEL_MMV = 9           /* qbits_mm, 4 < M <= 16 (AUTO; the kernel itself accepts up to 32 rows): register-streaming MFMA kernel, K split over the waves of a block (no workspace) */
 } quanto_hip_kernel;
 
 /* Split-K workspaces (SKINNY and MFMA_LARGE kernels) all share ONE layout: the first QUANTO_HIP_WS_COUNTER_BYTES bytes are

@@ -345,10 +345,19 @@ int quanto_hip_qbits_mm_multi_ws(const void* x, int count, const uint8_t* const*
     if (r == QUANTO_HIP_OK) set_last_kernel("skinny_multi");
     if (r != QUANTO_HIP_EALIGN) return r;
   }
+  // Separate calls that share ONE workspace.  The kernels that use it as scratch (dequantized weight, row sums) write from offset 0,
+  // i.e. over the counter words the split-K kernels expect to find zero: the counter region is zeroed again behind every such
+  // member, so that whichever member comes next (and the caller's next call) sees the "zero on entry" contract.
   for (int i = 0; i < count; ++i) {
+    const PackedGeom g = make_geom(N[i], K, bits, group_size);
+    const int picked = workspace ? pick_qbits_kernel(M, g, dtype, true) : QUANTO_HIP_KERNEL_NAIVE;
     const int r = quanto_hip_qbits_mm(x, packed[i], scale[i], shift[i], bias ? bias[i] : nullptr, y[i], M, N[i], K, bits, group_size, dtype,
                                       shift_dtype, QUANTO_HIP_KERNEL_AUTO, workspace, workspace_bytes, stream_);
     if (r != QUANTO_HIP_OK) return r;
+    if (workspace && (picked == QUANTO_HIP_KERNEL_DEQUANT_MFMA || picked == QUANTO_HIP_KERNEL_MFMA)) {
+      const size_t nz = workspace_bytes < (size_t)QUANTO_HIP_WS_COUNTER_BYTES ? workspace_bytes : (size_t)QUANTO_HIP_WS_COUNTER_BYTES;
+      if (hipMemsetAsync(workspace, 0, nz, stream) != hipSuccess) return QUANTO_HIP_ELAUNCH;
+    }
   }
   return QUANTO_HIP_OK;
 }

@@ -107,14 +107,25 @@ inline PackedGeom make_geom(int64_t N, int64_t K, int bits, int group_size) {
   return g;
 }
 
-// Experiment knobs: read on every call (a getenv is ~100 ns next to a microsecond launch path) so that one process can
-// A/B the variants - scripts/ab.py flips the variable between hipGraph captures.
+// Experiment knobs.  The product dispatch reads NO environment variable per call: the switch QUANTO_HIP_EXPERIMENT is read once,
+// when the library first needs it; unless it was set to a non-zero value at that moment every knob is its default and env_int /
+// env_ptr are a load and a branch.  With the switch on, the knobs are read on every call, so that one process can A/B variants
+// (scripts/ab.py flips a variable between hipGraph captures; the GPU tests force the tile configurations the same way).
+inline bool experiments_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("QUANTO_HIP_EXPERIMENT");
+    return e != nullptr && atoi(e) != 0;
+  }();
+  return on;
+}
 inline int env_int(const char* name, int dflt) {
+  if (!experiments_enabled()) return dflt;
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
 // debugging aid: a device address handed over as text (scripts/skinny_timeline.py), null when unset
 inline void* env_ptr(const char* name) {
+  if (!experiments_enabled()) return nullptr;
   const char* e = getenv(name);
   return e ? reinterpret_cast<void*>(strtoull(e, nullptr, 0)) : nullptr;
 }

@@ -151,6 +151,8 @@ class _Bindings:
         buffer per (device, stream, capture) instead of an allocation per call; calls on one stream use it in stream order."""
         cache = self.__dict__.setdefault("_scratch_ws", {})
         capture = self._c.quanto_hip_stream_capture_id(ctypes.c_void_p(stream))
+        if capture < 0:
+            self._check(int(capture), "stream_capture_id")
         key = (device, stream, capture)
         buf = cache.get(key)
         if buf is None or buf.numel() < nbytes:

@@ -67,22 +67,38 @@ def _routable(other) -> bool:
 
 
 def install() -> bool:
-    """Idempotent.  Returns True when the reference is imported and the backend was installed into it."""
-    ref = _reference()
-    if ref is None:
+    """Idempotent.  Returns True when the reference is imported and the backend was installed into it.  An ``optimum.quanto`` that
+    is only partially imported, or laid out differently from the version this was written against, is left untouched (a warning,
+    not an ImportError of this package)."""
+    if _reference() is None:
         return False
     if _state["installed"]:
         return True
+    try:
+        return _install()
+    except (KeyError, AttributeError, ImportError) as e:
+        import warnings
+
+        warnings.warn(f"optimum_quanto_amd: optimum.quanto is imported but plug-in mode could not be installed into it ({type(e).__name__}: {e}); "
+                      "the reference is left unmodified", RuntimeWarning)
+        return False
+
+
+def _install() -> bool:
+    ref = _reference()
     from .hip import quanto_hip
 
-    # 1. the reference's extension registry
+    # look everything up first: nothing of the reference is modified unless all of it is where this code expects it
     registry = sys.modules["optimum.quanto.library.extensions.extension"]._extensions
+    cls = ref.tensor.weights.qbits.WeightQBitsTensor
+    original = cls.__dict__["__torch_function__"].__func__
+    ref.tensor.packed.PackedTensor, ref.tensor.function.QuantizedLinearFunction  # noqa: B018  (used by the routed function)
+
+    # 1. the reference's extension registry
     if torch.version.hip is not None:
         registry["quanto_hip"] = quanto_hip
 
     # 2. F.linear on the generic WeightQBitsTensor
-    cls = ref.tensor.weights.qbits.WeightQBitsTensor
-    original = cls.__dict__["__torch_function__"].__func__
 
     def __torch_function__(klass, func, types, args=(), kwargs=None):
         if func is torch.nn.functional.linear:

@@ -5,7 +5,7 @@ from typing import Any, Dict, List, Optional, Union
 import torch
 
 from .nn import QModuleMixin, quantize_module
-from .tensor import Optimizer, qtype
+from .tensor import Optimizer, QTensor, qtype
 
 __all__ = ["quantize", "freeze", "requantize", "quantization_map"]
 
@@ -85,11 +85,27 @@ def requantize(model: torch.nn.Module, state_dict: Dict[str, Any], quantization_
             setattr(m, bname, move(b))
     # dtype of the model's own (non-quantized) parameters wins over the checkpoint's, as with a copying load_state_dict
     want = {k: v.dtype for k, v in list(model.named_parameters()) + list(model.named_buffers()) if v.device.type != "meta"}
+    # ... including a quantized module's weight: its scale (and float shift) follow the dtype the module was built in, so that a
+    # checkpoint saved in another float dtype does not leave bias / activations in one dtype and the weight's scale in another
+    qdtype = {name: m.weight.dtype for name, m in model.named_modules() if isinstance(m, QModuleMixin) and m.weight is not None}
     model.load_state_dict(state_dict, strict=False, assign=True)
     for k, v in list(model.named_parameters()) + list(model.named_buffers()):
         if k in want and type(v.data) is torch.Tensor and v.is_floating_point() and v.dtype != want[k]:
             v.data = v.data.to(want[k])
+    for name, m in model.named_modules():
+        if name in qdtype and isinstance(m.weight, QTensor) and m.weight._scale.dtype != qdtype[name]:
+            m.weight = torch.nn.Parameter(_cast_qweight(m.weight, qdtype[name]), requires_grad=False)
     model.to(device)
+
+
+def _cast_qweight(qw, dtype):
+    """The same quantized weight with its float metadata (scale, float shift) in ``dtype``; integers untouched."""
+    names, meta = qw.__tensor_flatten__()
+    inner = {}
+    for n in names:
+        t = getattr(qw, n)
+        inner[n] = t.to(dtype) if type(t) is torch.Tensor and t.is_floating_point() and n in ("_scale", "_shift") else t
+    return type(qw).__tensor_unflatten__(inner, meta, None, None)
 
 
 def freeze(model: torch.nn.Module):

@@ -13,7 +13,7 @@ import torch
 
 from .checkpoint import load_state_dict_to_device, save_sharded_state_dict
 from .model_api import freeze, quantization_map, quantize, requantize
-from .nn import QModuleMixin
+from .nn import QLinear, QModuleMixin
 from .tensor import Optimizer, qtype
 
 __all__ = ["QuantizedTransformersModel", "QuantizedModelForCausalLM", "fuse_decode_projections"]
@@ -112,18 +112,38 @@ class _SiblingGroup:
 
     The model code is left alone (it still calls ``q_proj(h)``, ``k_proj(h)``, ``v_proj(h)`` one after the other): the first
     sibling called with a decode-shaped input runs ``quanto::qbits_mm_multi`` / ``qbytes_mm_multi`` for all of them and parks the other outputs,
-    which the following calls pick up when they arrive with the very same tensor object.  Anything else - another input, a
-    prefill-sized input, an unfrozen weight, gradients - takes the module's normal forward."""
+    which the following calls pick up when they arrive with the very same tensor - same object, same storage address and same
+    version counter (an in-place update of the activation between two siblings makes the parked outputs stale: they are dropped and
+    the sibling recomputes).  Anything else - another input, a prefill-sized input, an unfrozen weight, gradients wanted for the
+    input or for a bias - takes the module's normal forward."""
 
     def __init__(self, modules):
         self.modules = modules
+        self._clear()
+
+    def _clear(self):
         self.input = None      # strong reference: the storage cannot be recycled while outputs are parked
+        self.stamp = None      # (data_ptr, _version) of the input when the outputs were computed
         self.outputs = {}
+
+    def __getstate__(self):    # copy.deepcopy / pickle: the links travel (to the copied modules), parked tensors do not
+        return {"modules": self.modules}
+
+    def __setstate__(self, state):
+        self.modules = state["modules"]
+        self._clear()
+
+    def wants_grad(self, x) -> bool:
+        """The multi ops have no autograd formula: a call that wants a gradient (for the input or for a member's bias) must go
+        through the members' own forward, or the gradient would be dropped without an error."""
+        return torch.is_grad_enabled() and (x.requires_grad or any(m.bias is not None and m.bias.requires_grad for m in self.modules))
 
     def kind(self, x):
         """"qbits" (int4, group size 128), "qbytes" (int8 / fp8, per-channel scale) or None when the members cannot share a launch."""
         rows = x.numel() // x.shape[-1] if type(x) is torch.Tensor and x.dim() > 0 else 0
-        if type(x) is not torch.Tensor or not x.is_cuda or not 1 <= rows <= 64 or torch.is_grad_enabled() and x.requires_grad:
+        if type(x) is not torch.Tensor or not x.is_cuda or not 1 <= rows <= 64:
+            return None
+        if self.wants_grad(x):
             return None
         from .tensor import WeightQBitsTensor, WeightQBytesTensor
 
@@ -141,12 +161,12 @@ class _SiblingGroup:
         return None
 
     def forward(self, index: int, x):
-        if self.input is x and index in self.outputs:
+        if self.input is x and index in self.outputs and self.stamp == (x.data_ptr(), x._version):
             y = self.outputs.pop(index)
             if not self.outputs:
-                self.input = None
+                self._clear()
             return y
-        self.input, self.outputs = None, {}
+        self._clear()
         kind = self.kind(x)
         if kind is None:
             return None
@@ -157,32 +177,40 @@ class _SiblingGroup:
                                                  4, 128, [w.shape[0] for w in ws], ws[0].shape[1])
         else:
             ys = torch.ops.quanto.qbytes_mm_multi(x, [w._data for w in ws], [w._scale for w in ws], biases)
-        self.input = x
+        self.input, self.stamp = x, (x.data_ptr(), x._version)
         self.outputs = {i: y for i, y in enumerate(ys) if i != index}
         return ys[index]
+
+
+class FusedDecodeQLinear(QLinear):
+    """A ``QLinear`` linked to its siblings by ``fuse_decode_projections``.  The link is the module's class plus two plain attributes
+    (``_sibling_group``, ``_sibling_index``), not a closure stored in ``module.forward``: ``copy.deepcopy`` / pickle produce modules
+    that are linked to their OWN copied siblings, and wrappers that replace ``module.forward`` on the instance (accelerate hooks)
+    compose with it."""
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        group = self.__dict__.get("_sibling_group")
+        if group is not None:
+            y = group.forward(self._sibling_index, input)
+            if y is not None:
+                return y
+        return super().forward(input)
 
 
 def fuse_decode_projections(model, groups=(("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"))):
     """Opt-in: make sibling QLinears (same parent, same input) share one kernel launch at decode time (up to 64 rows).
 
-    Weights, state dict and module tree are untouched; only ``forward`` of the listed children is wrapped.  Returns the
-    number of groups that were linked."""
-    from .nn import QLinear
-
+    Weights, state dict and module tree are untouched; the listed children become ``FusedDecodeQLinear`` (same parameters, same
+    state-dict keys).  Returns the number of groups that were linked."""
     linked = 0
     for parent in model.modules():
         for names in groups:
             mods = [getattr(parent, n, None) for n in names]
-            if not all(isinstance(m, QLinear) for m in mods) or any(getattr(m, "_sibling_group", None) is not None for m in mods):
+            if not all(type(m) in (QLinear, FusedDecodeQLinear) for m in mods) or any(m.__dict__.get("_sibling_group") is not None for m in mods):
                 continue
             group = _SiblingGroup(mods)
             for i, m in enumerate(mods):
-                m._sibling_group = group
-
-                def forward(input, _m=m, _i=i, _g=group, _orig=m.forward):
-                    y = _g.forward(_i, input)
-                    return _orig(input) if y is None else y
-
-                m.forward = forward
+                m.__class__ = FusedDecodeQLinear
+                m._sibling_group, m._sibling_index = group, i
             linked += 1
     return linked

@@ -68,16 +68,20 @@ def shard_bias(bias: Optional[torch.Tensor], qweight, rank: int, world_size: int
 
 
 def gather_columns(y_local: torch.Tensor, planes: int, group=None) -> torch.Tensor:
-    """all_gather the ``[..., N/G]`` partial outputs and restore the global feature order."""
+    """all_gather the ``[..., N/G]`` partial outputs and restore the global feature order: ONE collective
+    (``all_gather_into_tensor`` into a ``[G * rows, N/G]`` buffer) and ONE copy (the permuted view of that buffer)."""
     world_size = dist.get_world_size(group) if dist.is_initialized() else 1  # a single process needs no process group
     if world_size == 1:
         return y_local
-    parts = [torch.empty_like(y_local) for _ in range(world_size)]
-    dist.all_gather(parts, y_local.contiguous(), group=group)
-    if planes == 1:
-        return torch.cat(parts, dim=-1)
-    h = y_local.shape[-1] // planes
-    return torch.cat([p[..., i * h:(i + 1) * h] for i in range(planes) for p in parts], dim=-1)
+    y_local = y_local.contiguous()
+    lead, n_local = y_local.shape[:-1], y_local.shape[-1]
+    rows = y_local.numel() // max(n_local, 1)
+    buf = torch.empty((world_size * rows, n_local), dtype=y_local.dtype, device=y_local.device)  # rank-major concatenation
+    dist.all_gather_into_tensor(buf, y_local.reshape(rows, n_local), group=group)
+    # rank g's columns are `planes` runs of h features: global feature (i, g, c) <- buf[g, ..., i*h + c]
+    h = n_local // planes
+    src = buf.reshape(world_size, -1, planes, h).permute(1, 2, 0, 3)
+    return src.reshape(*lead, world_size * n_local)
 
 
 class ColumnParallelQLinear(torch.nn.Module):

@@ -24,6 +24,19 @@ def qfallback(callable, *args, **kwargs):
     return callable(*args, **kwargs)
 
 
+def _deepcopy_flattened(t, memo):
+    import copy
+
+    if id(t) in memo:
+        return memo[id(t)]
+    names, meta = t.__tensor_flatten__()
+    inner = {n: copy.deepcopy(getattr(t, n), memo) for n in names}
+    out = type(t).__tensor_unflatten__(inner, meta, None, None)
+    out.requires_grad_(t.requires_grad)
+    memo[id(t)] = out
+    return out
+
+
 class QTensor(torch.Tensor):
     def __init__(self, qtype, axis):
         self._qtype = qtype
@@ -56,6 +69,11 @@ class QTensor(torch.Tensor):
                     walk(inner, pfx + name + ".")
 
         walk(self, prefix)
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(model) of a frozen model: rebuild the same class around deep copies of the inner tensors (torch's default
+        for wrapper subclasses wants an aten.clone that returns the subclass, which weights do not have - nor do the reference's)."""
+        return _deepcopy_flattened(self, memo)
 
     def equal(self, other) -> bool:
         if type(self) is not type(other):

@@ -71,6 +71,11 @@ class PackedTensor(torch.Tensor):
     def dtype(self):
         return torch.uint8
 
+    def __deepcopy__(self, memo):
+        import copy
+
+        return PackedTensor(copy.deepcopy(self._data, memo), self._bits, self.size(), self.stride())
+
     # -- serialization (flatten protocol; meta values are AST-evaluable strings) --------------------
     def __tensor_flatten__(self):
         meta = {"bits": str(self._bits), "size": str(list(self.size())), "stride": str(self.stride())}

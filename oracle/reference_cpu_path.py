@@ -7,7 +7,8 @@ this module issues exactly those kernels, in the reference's order, so that ``be
 reference's own CPU arithmetic on the GPU box's host cores.  Every function cites the reference lines it follows
 (paths relative to /root/reference/optimum/quanto).
 
-Pinned: ``tests/test_reference_cpu_path.py`` runs the real reference (scratch copy, subprocess) in the build container and
+Pinned: ``tests/test_reference_integration.py`` (``tests/reference_subprocess.py cpu_path``) runs the real reference (scratch copy,
+subprocess) in the build container and
 asserts ``torch.equal`` between its outputs and these functions' on the same tensors, for every path below.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product never does.

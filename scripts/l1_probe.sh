@@ -17,7 +17,7 @@ GROUPS_=(
 for WD in 0 5; do
   for i in "${!GROUPS_[@]}"; do
     D=$OUT/wd${WD}_g$i
-    (cd /tmp && QUANTO_HIP_LARGE_CFG=2 QUANTO_HIP_LARGE_WD=$WD timeout 300 rocprofv3 --pmc ${GROUPS_[$i]} --output-format csv -d $D -o pmc -- \
+    (cd /tmp && QUANTO_HIP_EXPERIMENT=1 QUANTO_HIP_LARGE_CFG=2 QUANTO_HIP_LARGE_WD=$WD timeout 300 rocprofv3 --pmc ${GROUPS_[$i]} --output-format csv -d $D -o pmc -- \
         python $REPO/scripts/microbench_qbytes.py --kernel mfma_large --pairs bf16:i8 --iters 4 --ramp-ms 0 --shapes $SHAPES > $D.log 2>&1)
     python - "$D" "$WD" <<'PY'
 import collections, csv, glob, sys

@@ -12,6 +12,8 @@ import sys
 import numpy as np
 import torch
 
+os.environ.setdefault("QUANTO_HIP_EXPERIMENT", "1")  # the library reads its knobs only behind this switch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402

@@ -12,7 +12,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = os.environ.get("QUANTO_REFERENCE", "/root/reference")
+REF = os.environ.get("QUANTO_REFERENCE") or ("/root/reference" if os.path.isdir("/root/reference") else os.path.join(ROOT, ".refcopy"))
 
 
 def import_reference():
@@ -153,6 +153,63 @@ def check_plugin():
     shutil.rmtree(scratch, ignore_errors=True)
 
 
+def check_plugin_gpu():
+    """On the MI355X box, with a shipped scratch copy of the reference: a ROCm tensor goes through the reference's own classes
+    (QLinear / quantize / freeze / WeightQBitsTensor.__torch_function__) and lands on this library's fast kernels."""
+    scratch = import_reference()
+    import torch
+    import optimum.quanto as Q
+
+    assert torch.cuda.is_available() and torch.version.hip is not None
+    sys.path.insert(0, ROOT)
+    import optimum_quanto_amd  # noqa: F401  -> plug-in mode
+    from optimum_quanto_amd.library import plugin
+    from optimum_quanto_amd.library.hip import quanto_hip
+    from optimum.quanto.library.extensions import get_extension
+
+    assert plugin.installed() and get_extension("quanto_hip") is quanto_hip
+    lib = quanto_hip.lib
+    F = torch.nn.functional.linear
+    torch.manual_seed(0)
+    fast = {1: ("gemv",), 8: ("mmv", "skinny"), 48: ("skinny",), 512: ("mfma_fused4",), 2048: ("dequant_mfma",)}
+    for dt in (torch.bfloat16, torch.float16):
+        N, K = 1024, 1024
+        w = (torch.randn(N, K) * 0.02).to(dt)
+        s4, z4 = Q.MaxOptimizer()(w, Q.qint4, 0, 128)
+        q4 = Q.quantize_weight(w, Q.qint4, 0, s4, z4, group_size=128, optimized=False)
+        assert type(q4).__name__ == "WeightQBitsTensor"
+        q4d = q4.to("cuda")
+        assert type(q4d).__name__ == "WeightQBitsTensor" and q4d.device.type == "cuda"
+        assert torch.equal(q4d.dequantize().cpu(), q4.dequantize())  # cross-device equality of the generic class (the reference's own gate)
+        for M, kernels in fast.items():
+            x = torch.randn(M, K).to(dt)
+            with torch.no_grad():
+                want = F(x.float(), q4.dequantize().float())   # fp32 CPU reference on the same integers / scales
+                got = F(x.cuda(), q4d)
+            assert lib.last_kernel() in kernels, (M, lib.last_kernel())
+            err = (got.float().cpu() - want).abs().max().item() / want.abs().max().item()
+            assert err < 2e-2, (dt, M, err)                    # the reference's own tolerance on cuda (weight_helpers.py:19-37)
+        # 8-bit: the reference calls quanto::qbytes_mm itself; the CUDA kernel behind it is ours now
+        q8 = Q.quantize_weight(w, Q.qint8, 0, Q.AbsmaxOptimizer()(w, Q.qint8, 0), optimized=False).to("cuda")
+        with torch.no_grad():
+            got = F(torch.randn(1, K).to(dt).cuda(), q8)
+        assert lib.last_kernel() == "gemv", lib.last_kernel()
+        print(f"plugin_gpu {dt}: int4 M in {sorted(fast)} on {sorted(set(sum(fast.values(), ())))}; int8 decode on gemv")
+    # the reference's module API end to end on the device
+    lin = torch.nn.Linear(1024, 512, bias=True).to(torch.bfloat16).cuda()
+    x = torch.randn(3, 1024, device="cuda", dtype=torch.bfloat16)
+    ref = lin(x)
+    Q.quantize(lin, weights=Q.qint4)
+    Q.freeze(lin)
+    qmods = [m for m in [lin] if isinstance(m, Q.nn.QLinear)] or [lin]
+    with torch.no_grad():
+        y = lin(x)
+    assert lib.last_kernel() == "gemv", lib.last_kernel()
+    assert (y.float() - ref.float()).abs().max().item() / ref.float().abs().max().item() < 0.2  # int4 quantization error only
+    print("plugin_gpu: reference QLinear(qint4).forward ->", lib.last_kernel(), type(qmods[0]).__name__)
+    shutil.rmtree(scratch, ignore_errors=True)
+
+
 if __name__ == "__main__":
-    {"cpu_path": check_cpu_path, "plugin": check_plugin}[sys.argv[1]]()
+    {"cpu_path": check_cpu_path, "plugin": check_plugin, "plugin_gpu": check_plugin_gpu}[sys.argv[1]]()
     print("ALL-OK")

@@ -183,3 +183,49 @@ def test_auto_dispatch_accepts_misaligned_views(M):
     y = lib.qbytes_mm(x, torch.from_numpy(q["data"]).to(dev), to_torch(q["scale"], "bf16", dev))
     assert lib.last_kernel() == "naive"
     assert_close_to_exact(to_numpy(y), O.qbytes_mm_exact(q["x"], q["data"], q["scale"]), "bf16", "misaligned qbytes")
+
+
+@pytest.mark.gpu
+def test_c_api_multi_fallback_restores_the_counter_words_behind_scratch_members():
+    """quanto_hip_qbits_mm_multi_ws falls back to separate calls that share ONE workspace.  Member 0 (N = 11008, K = 14336,
+    M = 300) resolves to DEQUANT_MFMA and writes the dequantized weight from offset 0 - over the arrival counters; member 1 (N = 256)
+    resolves to the split-K form of the fused int4 GEMM and needs those counters to be zero.  Straight through the C ABI with one
+    caller-owned buffer (the Python binding keeps zeroed and scratch buffers apart, so only a C caller can hit this)."""
+    import ctypes
+
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    lib, dev = quanto_hip.lib, "cuda"
+    c = lib._c
+    M, K, Ns = 300, 14336, [11008, 256]
+    BF16, DEQUANT, FUSED4 = 2, 7, 8
+    c.quanto_hip_qbits_mm_pick.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 3
+    assert [c.quanto_hip_qbits_mm_pick(M, n, K, 4, 128, BF16) for n in Ns] == [DEQUANT, FUSED4]
+    ps = [make_qbits_problem(M, n, K, "bf16", seed=7 + i) for i, n in enumerate(Ns)]
+    x = to_torch(ps[0]["x"], "bf16", dev)
+    packed = [torch.from_numpy(p["packed"]).to(dev) for p in ps]
+    scale = [to_torch(p["scale"], "bf16", dev) for p in ps]
+    shift = [to_torch(p["shift"], "bf16", dev) for p in ps]
+    ys = [torch.full((M, n), float("nan"), dtype=torch.bfloat16, device=dev) for n in Ns]
+    nfs = (ctypes.c_int64 * 2)(*Ns)
+    c.quanto_hip_qbits_mm_multi_workspace_size.restype = ctypes.c_int64
+    c.quanto_hip_qbits_mm_multi_workspace_size.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    need = c.quanto_hip_qbits_mm_multi_workspace_size(2, nfs, M, K, 4, 128, BF16)
+    assert need >= 11008 * K * 2
+    ws = torch.zeros((need,), dtype=torch.uint8, device=dev)  # the documented contract: counters zero on entry
+    arr = lambda ts: (ctypes.c_void_p * 2)(*[t.data_ptr() for t in ts])  # noqa: E731
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for rep in range(2):  # the second round starts from whatever the first one left in the buffer
+        st = c.quanto_hip_qbits_mm_multi_ws(ctypes.c_void_p(x.data_ptr()), 2, arr(packed), arr(scale), arr(shift), None, arr(ys), nfs,
+                                            ctypes.c_int64(M), ctypes.c_int64(K), 4, 128, BF16, BF16, ctypes.c_void_p(ws.data_ptr()),
+                                            ctypes.c_size_t(need), stream)
+        assert st == 0, st
+        torch.cuda.synchronize()
+        assert int(ws[:4096].max()) == 0, "counter words left dirty"
+        got = to_numpy(ys[1])
+        assert np.isfinite(got).all(), "member 1: unwritten tiles (arrival election failed on dirty counters)"
+        assert_close_to_exact(got, O.qbits_mm_exact(ps[0]["x"], ps[1]["packed"], 4, ps[1]["scale"], ps[1]["shift"], 128, 256, K), "bf16", f"member 1, round {rep}")
+    rows = slice(0, 8)
+    w0 = O.dequantize_qbits_ref(ps[0]["packed"], 4, ps[0]["scale"], ps[0]["shift"], 0, 128, (11008, K), "bf16")  # the reference's rounded weight
+    want0 = np.matmul(ps[0]["x"][rows].astype(np.float64), w0.astype(np.float64).T)
+    assert_close_to_exact(to_numpy(ys[0])[rows], want0, "bf16", "member 0 (dequantize + dense), first rows")

@@ -1,0 +1,65 @@
+"""bench.py's launch contract, exercised where there is no GPU: `--gpus N` without a launcher spawns N ranks itself (r2's
+`--gpus` was parsed and never used), and the default line stays short enough for the driver's ~8 KB stdout tail."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _run(*argv, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=600, env=e)
+
+
+def test_gpus_2_spawns_two_ranks_over_gloo():
+    r = _run("--gpus", "2", "--stub", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 prints ONE line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["data"] == "stub"
+
+
+def test_gpus_2_without_a_device_reaches_the_process_group_then_fails_loudly():
+    r = _run("--gpus", "2", "--steps", "1", "--warmup", "0")
+    if r.returncode == 0:  # a box with two GPUs: the real thing ran
+        assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["n_gpus"] == 2
+        return
+    assert "needs a ROCm device" in r.stderr  # both ranks were started and initialised; no silent single-rank run, no CPU fallback
+
+
+def test_launcher_and_flag_must_agree():
+    r = _run("--gpus", "2", "--stub", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 2" in r.stderr
+
+
+def test_default_line_fits_the_driver_tail():
+    import bench
+
+    def fake(name):
+        kind, M, K, N, desc = bench.WORKLOADS[name]
+        flops, nbytes = bench.algorithmic_work(kind, M, K, N)
+        roof = {"bound": "hbm", "achieved": 1234.5, "peak": 8000.0, "unit": "GB/s", "frac": 0.1543, "traffic": 123456789, "kernel": "skinny_multi",
+                "launch_us": 12.345, "algorithmic_bytes": nbytes, "algorithmic_flops": flops, "traffic_source": "x" * 90}
+        cpu = {"kind": "reference", "cores": 128, "path": "int4_generic", "value": 1.23456, "unit": "GB/s", "sample": "full call, 50 timed calls after 3 warm-up",
+               "seconds_per_call": 0.123456, "iqr_s": 0.012345, "calls_timed": 50,
+               "tinygemm": {"seconds_per_call": 0.000123, "iqr_s": 1e-6, "calls": 200, "value": 123.456, "unit": "GB/s"}}
+        return {"metric": "QLinear GEMM GB/s (bf16 x int4 qbits_mm, decode)", "value": 1234.567, "unit": "GB/s", "n_gpus": 1, "steps": 200, "warmup": 5,
+                "ms_per_step": 0.01234, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": desc, "name": name, "M": M, "K": K, "N": list(N) if isinstance(N, tuple) else N, "weight_buffers_rotated": 58,
+                           "launch": "hipGraph replay of the K steps", "clock_ramp_ms": 300.0, "parallelism": "replicas x1 (no data-path collective)"},
+                "tflops": 1.234, "gbps": 1234.5, "roofline": roof, "cpu_baseline": cpu}
+
+    out = fake("cfg2")
+    out["cpu_baseline"]["how"] = bench.CPU_BASELINE_NOTE["reference"]
+    out["sub_results"] = [bench.compact(fake(n)) for n in bench.DEFAULT_SUB]
+    out["cpu_paths"] = dict(bench.CPU_BASELINE_NOTE)
+    line = json.dumps(out, separators=(",", ":"))
+    assert len(line) < 6500, len(line)
+    for sr in out["sub_results"]:  # enough to recompute every fraction from the line alone
+        assert {"name", "launch_us", "frac", "alg_bytes", "alg_flops", "kernel", "traffic", "cpu"} <= set(sr)
+    assert {"northstar", "cfg3", "cfg4"} <= {sr["name"] for sr in out["sub_results"]}

@@ -280,6 +280,13 @@ def test_qlinear_quantize_freeze_state_dict_roundtrip():
     assert (128, 256) not in allocated and (64, 128) in allocated, allocated
     assert isinstance(lazy[0].weight, Q.WeightQBitsTensor) and lazy[2].weight.dtype == torch.bfloat16 and lazy[0].bias.dtype == torch.bfloat16
     assert not any(p.device.type == "meta" for p in lazy.parameters())
+    # the checkpoint above is fp32, the model bf16: the rebuilt weight's scale / shift follow the MODEL's dtype (as its bias
+    # does), and the module runs - r2 left scale fp32 next to a bf16 bias and forward raised a dtype mismatch
+    assert lazy[0].weight._scale.dtype == torch.bfloat16 and lazy[0].weight._shift.dtype == torch.bfloat16
+    assert lazy[0].weight.dtype == torch.bfloat16
+    assert torch.equal(lazy[0].weight._data._data, model[0].weight._data._data)  # integers untouched
+    out = lazy(x.to(torch.bfloat16))
+    assert out.dtype == torch.bfloat16 and (out.float() - y).abs().max() < 0.05 * y.abs().max()
 
 
 def test_group_size_selection_follows_reference():

@@ -143,6 +143,99 @@ def test_multi_batched_decode_one_streaming_launch_gpu(dt, M, Ns, K):
             np.testing.assert_array_equal(to_numpy(ys[i]), want)
 
 
+def _force_engage(model):
+    """CPU stand-in for a decode step on the device: make every sibling group eligible (the ops' default implementations run on CPU)."""
+    groups = {id(m._sibling_group): m._sibling_group for m in model.modules() if m.__dict__.get("_sibling_group") is not None}
+    for g in groups.values():
+        g.kind = lambda x, _g=g: "qbits"
+    return list(groups.values())
+
+
+def test_sibling_group_drops_parked_outputs_when_the_input_changes_in_place():
+    """q_proj(x); x += 1; k_proj(x) must see the new x: parked outputs are keyed on (object, data_ptr, _version)."""
+    model, cfg = _tiny_llama("cpu")
+    attn = model.model.layers[0].self_attn
+    x = torch.randn(1, 1, cfg.hidden_size).to(torch.bfloat16)
+    with torch.no_grad():
+        k_before, k_after = attn.k_proj(x), attn.k_proj(x + 1)
+        Q.fuse_decode_projections(model)
+        _force_engage(model)
+        attn.q_proj(x)
+        assert set(attn.q_proj._sibling_group.outputs) == {1, 2}  # k and v parked
+        assert torch.equal(attn.k_proj(x), k_before)            # same tensor, untouched: served from the parked outputs
+        attn.q_proj(x)
+        x.add_(1)                                                # in-place update between siblings
+        got = attn.k_proj(x)
+    assert torch.equal(got, k_after) and not torch.equal(got, k_before)
+
+
+def test_sibling_group_leaves_gradients_to_the_members():
+    model, cfg = _tiny_llama("cpu")
+    Q.fuse_decode_projections(model)
+    g = model.model.layers[0].self_attn.q_proj._sibling_group
+    x = torch.randn(1, cfg.hidden_size, dtype=torch.bfloat16)
+    with torch.enable_grad():
+        assert not g.wants_grad(x)
+        assert g.wants_grad(x.clone().requires_grad_())
+        g.modules[1].bias = torch.nn.Parameter(torch.zeros(g.modules[1].weight.shape[0], dtype=torch.bfloat16))
+        assert g.wants_grad(x)          # a member's bias wants a gradient
+        with torch.no_grad():
+            assert not g.wants_grad(x)  # ... but not under no_grad
+
+
+@pytest.mark.gpu
+def test_bias_gradient_is_not_dropped_by_the_fused_launch():
+    model, cfg = _tiny_llama("cuda")
+    Q.fuse_decode_projections(model)
+    attn = model.model.layers[0].self_attn
+    attn.k_proj.bias = torch.nn.Parameter(torch.zeros(attn.k_proj.weight.shape[0], dtype=torch.bfloat16, device="cuda"))
+    x = torch.randn(1, 1, cfg.hidden_size, device="cuda").to(torch.bfloat16)
+    with torch.enable_grad():
+        attn.q_proj(x)
+        assert attn.q_proj._sibling_group.outputs == {}  # not engaged
+        attn.k_proj(x).float().sum().backward()
+    assert attn.k_proj.bias.grad is not None and torch.all(attn.k_proj.bias.grad == 1)
+
+
+def test_fused_model_survives_deepcopy_and_pickle():
+    """The link is the module class + plain attributes: a deep copy is linked to its OWN siblings and runs its OWN weights."""
+    import copy
+    import pickle
+
+    model, cfg = _tiny_llama("cpu")
+    Q.fuse_decode_projections(model)
+    clone = copy.deepcopy(model)
+    a, b = model.model.layers[0].self_attn, clone.model.layers[0].self_attn
+    assert b.q_proj._sibling_group is not a.q_proj._sibling_group
+    assert b.q_proj._sibling_group.modules[1] is b.k_proj and b.k_proj._sibling_index == 1
+    with torch.no_grad():
+        b.k_proj.weight._scale.mul_(2)  # the clone's weights are its own ...
+        b.k_proj.weight._shift.mul_(2)  # (W = scale * q - shift: both doubled = 2 W)
+        x = torch.randn(1, 1, cfg.hidden_size).to(torch.bfloat16)
+        _force_engage(clone)
+        b.q_proj(x)
+        doubled = b.k_proj(x)           # ... and the clone's fused launch reads them, not the original's
+        plain = a.k_proj(x)
+    torch.testing.assert_close(doubled.float(), 2 * plain.float(), rtol=2e-2, atol=2e-2)
+    q = pickle.loads(pickle.dumps(a.q_proj))
+    assert type(q).__name__ == "FusedDecodeQLinear" and len(q._sibling_group.modules) == 3 and q._sibling_group.outputs == {}
+
+
+@pytest.mark.gpu
+def test_sibling_group_in_place_update_on_device():
+    model, cfg = _tiny_llama("cuda")
+    attn = model.model.layers[0].self_attn
+    x = torch.randn(1, 1, cfg.hidden_size, device="cuda").to(torch.bfloat16)
+    with torch.no_grad():
+        want = attn.k_proj(x + 1)
+        Q.fuse_decode_projections(model)
+        attn.q_proj(x)
+        assert set(attn.q_proj._sibling_group.outputs) == {1, 2}
+        x.add_(1)
+        got = attn.k_proj(x)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.gpu
 def test_fused_decode_projections_on_device():
     """Tiny Llama, decode step by step with a static cache: logits with q/k/v and gate/up fused are identical to the unfused

@@ -14,7 +14,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = os.environ.get("QUANTO_REFERENCE", "/root/reference")
+REF = os.environ.get("QUANTO_REFERENCE") or ("/root/reference" if os.path.isdir("/root/reference") else os.path.join(ROOT, ".refcopy"))
 needs_reference = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "optimum", "quanto")), reason="reference checkout not present")
 
 
@@ -36,3 +36,12 @@ def test_reference_cpu_path_restatement_equals_the_reference():
 def test_plugin_mode_installs_into_an_imported_reference():
     out = _run("plugin")
     assert "CUDA kernels overridden" in out and "get_extension('quanto_hip') resolves" in out
+
+
+@pytest.mark.gpu
+@needs_reference
+def test_plugin_mode_runs_reference_tensors_on_the_fast_kernels():
+    """Needs a ROCm device AND a reference checkout (scripts/run_reference_tests_gpu.sh ships a scratch copy as .refcopy/): F.linear on
+    a reference WeightQBitsTensor living on the device ends in this library's GEMV / streaming / fused kernels."""
+    out = _run("plugin_gpu")
+    assert "reference QLinear(qint4).forward -> gemv" in out
