@@ -29,13 +29,21 @@
 namespace qh {
 namespace fused4 {
 
-// Workgroup: 8 waves as 2 (token halves) x 4 (blocks of 16 packed rows) = 128 tokens x 64 packed rows (128 features), one per CU
-// (two waves per SIMD).  Wave: 64 tokens x 32 features = MI x 2 accumulator blocks (running + group: 2 x 32 registers).
-constexpr int BK = 128, BM = 128, PR = 64, WAVES = 8, MI = 4, DEPTH = 2, STAGES = 3;
-constexpr int X_BYTES = BM * BK * 2, W_BYTES = PR * BK, STAGE_BYTES = X_BYTES + W_BYTES;  // 32 KiB + 8 KiB
-constexpr int XP = BM / 4 / WAVES;  // activation DMA pieces (4 rows x 256 B = 1 KiB) per wave and tile; the weight tile is one piece per wave
-constexpr int OPS = XP + 1;         // vector-memory instructions per wave and tile: activation pieces + weight piece
-static_assert(W_BYTES == WAVES * 1024 && DEPTH * OPS <= 63, "tile geometry");
+// Workgroup: 8 waves as 2 (token halves) x 4 (blocks of 16 packed rows) = BM tokens x 64 packed rows (128 features), one per CU
+// (two waves per SIMD).  Wave: BM/2 tokens x 32 features = MI x 2 accumulator blocks (running + group).
+//   BM = 128 (MI = 4): 32 KiB of activations per 8 KiB of packed weights and tile - the form for grids that fill the chip;
+//   BM = 64  (MI = 2): r3 - twice the workgroups for short prefills whose 128-token tiles leave CUs idle ((512,4096,4096): 128 ->
+//                      256 workgroups), 24 KiB per tile.
+constexpr int BK = 128, PR = 64, WAVES = 8, DEPTH = 2, STAGES = 3;
+constexpr int W_BYTES = PR * BK;  // 8 KiB
+template <int BM>
+struct Geo {
+  static constexpr int MI = BM / 32;            // 16-token fragments per wave
+  static constexpr int X_BYTES = BM * BK * 2, STAGE_BYTES = X_BYTES + W_BYTES;
+  static constexpr int XP = BM / 4 / WAVES;     // activation DMA pieces (4 rows x 256 B = 1 KiB) per wave and tile; the weight tile is one piece per wave
+  static constexpr int OPS = XP + 1;            // vector-memory instructions per wave and tile: activation pieces + weight piece
+  static_assert(W_BYTES == WAVES * 1024 && DEPTH * OPS <= 63 && (MI == 2 || MI == 4), "tile geometry");
+};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 

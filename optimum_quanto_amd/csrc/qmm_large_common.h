@@ -30,10 +30,6 @@ template <>
 struct Mma<QUANTO_HIP_BF16> {
   using V8 = bf16x8;
   static __device__ __forceinline__ f32x4 run(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-  // accumulator pinned in the AGPR half of the register file, updated in place (see run_agpr's callers for the hazards)
-  static __device__ __forceinline__ void run_agpr(V8 a, V8 b, f32x4& c) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-  }
   static __device__ __forceinline__ uint32_t pack(float a, float b) {
     bf16x2 r;
     r.x = (__bf16)a;
@@ -45,9 +41,6 @@ template <>
 struct Mma<QUANTO_HIP_F16> {
   using V8 = f16x8;
   static __device__ __forceinline__ f32x4 run(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ void run_agpr(V8 a, V8 b, f32x4& c) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-  }
   static __device__ __forceinline__ uint32_t pack(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));  // exact for int8 / fp8 values
   }

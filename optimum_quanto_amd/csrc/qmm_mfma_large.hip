@@ -75,13 +75,6 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   constexpr int ND = (NJ * 4 + MI - 1) / MI;    // converted dwords per step (one phase converts NJ*4 dwords in MI steps)
   constexpr int DSTEPS = WD ? 1 : NPIECES % 6 == 0 ? 6 : 3;  // the DMA of tile kt+2 is issued over the first DSTEPS steps of tile kt
   constexpr int PPS = NPIECES / DSTEPS;         // pieces per step
-  // One wave per SIMD with 256 accumulator registers (four waves on a 256-tile): the accumulators live in the AGPR half of the
-  // 512-entry register file and every MFMA updates its block in place through inline asm.  Left to itself hipcc also gives this
-  // layout 256 AGPRs, but renames the blocks across the unrolled stages of the K loop: ~3 v_accvgpr_read/write/mov per MFMA in
-  // the loop and 31 spilled VGPRs (r2's "within 2 %" measurement of this layout was of that code).  hipcc neither schedules nor
-  // pads the asm MFMAs: an accumulator block is touched once per k-half (64 MFMAs apart), operands are converted a phase ahead,
-  // and the two places where a fresh VALU result / the last MFMA results could be consumed too early carry explicit s_nops.
-  constexpr bool AGPR = NWAVES == 4 && BM == 256 && BN == 256 && WD == 0;
   static_assert(WD || (NPIECES % DSTEPS == 0 && PPS <= NJ), "unsupported tile configuration");
   static_assert(STEPS % 4 == 0 && ND <= NJ && APIECES + NJ <= STEPS, "unsupported tile configuration");
   using E = Elem<DT>;
@@ -303,7 +296,6 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
       for (int d = 0; d < 4; ++d) w0[j][d] = convert_pair<DT, FMT>(rawword(j, 0, d), d & 1);
     xf[0] = read_x(smem, 0, 0);
     xf[1] = read_x(smem, 1, 0);
-    if constexpr (AGPR) asm volatile("s_nop 3" ::: "memory");  // VALU-written operand -> asm MFMA (hipcc pads nothing for asm)
 
     // One K-tile.  The source order below IS the schedule: a sched_barrier after every MFMA group keeps hipcc from
     // clustering the conversions (it otherwise hoists ~50 VALU ops in front of the first MFMA of a tile, which leaves the
@@ -334,14 +326,10 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
         const int kk = s / MI, i = s % MI;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          if constexpr (AGPR) {
-            Mma<DT>::run_agpr(as_v8(kk == 0 ? w0[j] : w1[j]), xf[s & 3], acc[j][i]);
-          } else {
-            if (kk == 0)
-              acc[j][i] = Mma<DT>::run(as_v8(w0[j]), xf[s & 3], acc[j][i]);
-            else
-              acc[j][i] = Mma<DT>::run(as_v8(w1[j]), xf[s & 3], acc[j][i]);
-          }
+          if (kk == 0)
+            acc[j][i] = Mma<DT>::run(as_v8(w0[j]), xf[s & 3], acc[j][i]);
+          else
+            acc[j][i] = Mma<DT>::run(as_v8(w1[j]), xf[s & 3], acc[j][i]);
           if (j < ND && i * ND + j < NJ * 4) {
             // conversion: step i of a phase produces dwords i*ND .. i*ND+ND-1 of the phase's NJ*4 (fragment-major)
             const int c = i * ND + j, f = c >> 2, d = c & 3;
@@ -407,7 +395,6 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
     if (rem > 3) tile(S0{}, kt + 3, false, false);
   }
   QH_LT_STAMP(4);
-  if constexpr (AGPR) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMAs -> compiler-generated reads of the accumulators
 
   // ---- epilogue: scale (+bias) on the fp32 accumulator; each wave parks MI*16 tokens x 64 features per pass -------------
   T* yg = reinterpret_cast<T*>(a.y);
@@ -511,7 +498,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   QH_LT_STAMP(6);
 }
 
-enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2, CFG_256_1X8 = 3, CFG_256_MFMA32 = 4 /* qmm_mfma_large32.hip */, CFG_256_1X4 = 5 };
+enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2, CFG_256_1X8 = 3, CFG_256_MFMA32 = 4 /* qmm_mfma_large32.hip */ };
 
 template <int DT, int FMT, int BM, int BN, int WM, int WN, int WD = 0>
 static int launch_cfg(const Args& a, hipStream_t stream) {
@@ -557,7 +544,6 @@ static int launch(const Args& a, int cfg, hipStream_t stream) {
   // (tried: 128-tiles as eight waves of 128 x 16 with one workgroup per CU - LDS-bound, cfg4 90-98 us vs 86-90 us)
   if (cfg == CFG_256_4W) return launch_cfg<DT, FMT, 256, 256, 2, 2>(a, stream);
   if (cfg == CFG_256_1X8) return launch_cfg<DT, FMT, 256, 256, 1, 8>(a, stream);
-  if (cfg == CFG_256_1X4) return launch_cfg<DT, FMT, 256, 256, 1, 4>(a, stream);
   return launch_cfg<DT, FMT, 256, 256, 2, 4>(a, stream);
 }
 

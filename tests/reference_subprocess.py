@@ -196,14 +196,15 @@ def check_plugin_gpu():
         assert lib.last_kernel() == "gemv", lib.last_kernel()
         print(f"plugin_gpu {dt}: int4 M in {sorted(fast)} on {sorted(set(sum(fast.values(), ())))}; int8 decode on gemv")
     # the reference's module API end to end on the device
-    lin = torch.nn.Linear(1024, 512, bias=True).to(torch.bfloat16).cuda()
+    model = torch.nn.Sequential(torch.nn.Linear(1024, 512, bias=True)).to(torch.bfloat16).cuda()
     x = torch.randn(3, 1024, device="cuda", dtype=torch.bfloat16)
-    ref = lin(x)
-    Q.quantize(lin, weights=Q.qint4)
-    Q.freeze(lin)
-    qmods = [m for m in [lin] if isinstance(m, Q.nn.QLinear)] or [lin]
+    ref = model(x)
+    Q.quantize(model, weights=Q.qint4)
+    Q.freeze(model)
+    qmods = [m for m in model.modules() if isinstance(m, Q.nn.QLinear)]
+    assert len(qmods) == 1 and type(qmods[0].weight).__name__ == "WeightQBitsTensor"
     with torch.no_grad():
-        y = lin(x)
+        y = model(x)
     assert lib.last_kernel() == "gemv", lib.last_kernel()
     assert (y.float() - ref.float()).abs().max().item() / ref.float().abs().max().item() < 0.2  # int4 quantization error only
     print("plugin_gpu: reference QLinear(qint4).forward ->", lib.last_kernel(), type(qmods[0]).__name__)

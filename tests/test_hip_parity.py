@@ -587,12 +587,13 @@ def test_int4_prefill_4096_cubed():
     np.testing.assert_array_equal(_run_qbits(dict(p, x=p["x"] * 2), "auto"), y * 2)
 
 
-@pytest.mark.parametrize("cfg", ["0", "2", "3", "4"])
+@pytest.mark.parametrize("cfg", ["0", "1", "2", "3", "4"])
 @pytest.mark.parametrize("shape", [(512, 512, 256), (300, 520, 192), (1024, 768, 4096), (257, 255, 128)])
 @pytest.mark.parametrize("kind,dt,bias", [(None, "bf16", False), ("e4m3fn", "bf16", True), (None, "fp16", True), ("e5m2", "fp16", False)])
 def test_large_tile_configurations(monkeypatch, cfg, shape, kind, dt, bias):
     """Every tile configuration of the large-tile kernels, forced through the experiment knob (QUANTO_HIP_LARGE_CFG: 0 = 256^2 as
-    2x4 waves of 16x16x32 MFMAs, 2 = 128^2, 3 = 256^2 as 1x8, 4 = 256^2 on 32x32x16 MFMAs, qmm_mfma_large32.hip): ragged M / N,
+    2x4 waves of 16x16x32 MFMAs, 1 = 256^2 as four waves of 128x128 (hipcc-allocated AGPR accumulators), 2 = 128^2,
+    3 = 256^2 as 1x8, 4 = 256^2 on 32x32x16 MFMAs, qmm_mfma_large32.hip): ragged M / N,
     short and long K, int8 / fp8 weights, both 16-bit dtypes, bias - whole output against the float64 oracle."""
     monkeypatch.setenv("QUANTO_HIP_LARGE_CFG", cfg)
     M, N, K = shape
@@ -605,6 +606,14 @@ def test_large_tile_configurations(monkeypatch, cfg, shape, kind, dt, bias):
         assert_close_with_bias(y, exact, b, dt, f"large cfg {cfg} {shape} {kind} {dt}")
     else:
         assert_close_to_exact(y, exact, dt, f"large cfg {cfg} {shape} {kind} {dt}")
+
+
+def test_cfg2_on_the_four_wave_layout(monkeypatch):
+    """The 4096^3 headline shape on the one-wave-per-SIMD layout (four waves of 128x128, 256 AGPR accumulators): whole output."""
+    monkeypatch.setenv("QUANTO_HIP_LARGE_CFG", "1")
+    p = make_qbytes_problem(4096, 4096, 4096, "bf16", None, seed=12)
+    y = _run_qbytes(p, "mfma_large")
+    assert_close_to_exact(y, O.qbytes_mm_exact(p["x"], p["data"], p["scale"]), "bf16", "cfg2 on large cfg 1 (all rows)")
 
 
 def test_cfg2_on_the_32x32x16_kernel(monkeypatch):
