@@ -97,16 +97,20 @@ static bool prefer_gemv(int64_t M) { return M <= QUANTO_HIP_GEMV_MAX_M; }
 static bool dequant_mfma_supported(int64_t M, const PackedGeom& g, int dtype) { return dense_mm_large_supported(M, g.N, g.K, dtype); }
 static size_t dequant_mfma_workspace(const PackedGeom& g) { return (size_t)g.N * g.K * 2; }
 
-// Fused int4 GEMM (qbits_mfma_fused.hip) vs dequantize + dense GEMM, r2 measurements (us, fused / dequantize + dense):
-//   N = K = 4096:        M = 256 49 / 53, 512 51 / 53, 1024 54 / 54, 2048 102 / 83, 4096 227 / 112
-//   N = 14336, K = 4096: M = 256 53 / 68, 512 102 / 97, 1024 229 / 122
-// The fused kernel is bound by the bytes its workgroup pulls into the CU per tile (32 KiB of activations for 8 KiB of packed
-// weights), so it wins while its 128 x 128 tiles fit the chip in one round (<= 256 workgroups) and loses once the dequantize
-// pass is amortised over several rounds or over thousands of rows (M <= 1024 measured).  QUANTO_HIP_FUSED4_MAX_WGS overrides the round limit in experiments.
+// Fused int4 GEMM (qbits_mfma_fused.hip) vs dequantize + dense GEMM vs the streaming kernel, r3 measurements (us; fused / dequantize +
+// dense / streaming in passes of 64 rows):
+//   N = K = 4096:        M = 72 21.6 / 58 / 24.4, 128 21.8 / 55 / 31.8, 256 25.2 / 53 / 61.6, 512 28.5 / 52.7, 1024 50.4 / 53.1,
+//                        1536 79.3 / 81.9, 2048 98.4 / 84.4, 4096 191 / 108
+//   N = 14336, K = 4096: M = 128 27.9 / 66 / 71, 256 49.6 / 68.5, 512 97.1 / 97.2, 1024 184 / 128
+//   N = 4096, K = 14336: M = 128 40.0 / 155 / 80, 256 55.1 / 154, 512 84.8 / 155, 1024 169 / 162
+//   N = 1024, K = 4096:  M = 128 18.5 / 47 / 25.7, 512 22.5 / 49.5, 1024 26.6 / 48.7
+// The fused kernel's time is rounds of tiles x groups (its own model picks 64- or 128-token tiles and the K split, qbits_mfma_fused.hip);
+// dequantize + dense is flat in M up to ~1 k rows (one dequantize pass + a dense GEMM that cannot fill the chip) and wins once the
+// fused kernel needs more than ~1.2 rounds of 128-token tiles.  QUANTO_HIP_FUSED4_MAX_COST (x 100) / _MIN_M override the limits in experiments.
+float qbits_mfma_fused_cost(int64_t, const PackedGeom&);
 static bool fused4_wins(int64_t M, const PackedGeom& g) {
-  const int64_t wgs = ((M + 127) / 128) * ((g.N + 127) / 128);
-  // long K (split-K form, r2): (256,14336,4096) 76.9 / 153 us, (512,...) 115.5 / 155, (1024,...) 214 / 159
-  return M > 192 && M <= (g.K > 8192 ? 512 : 1024) && wgs <= env_int("QUANTO_HIP_FUSED4_MAX_WGS", 256);
+  if (M <= env_int("QUANTO_HIP_FUSED4_MIN_M", 64)) return false;
+  return qbits_mfma_fused_cost(M, g) * 100.f <= (float)env_int("QUANTO_HIP_FUSED4_MAX_COST", 120);
 }
 
 // The register-streaming kernel (K split inside the block, no split-K tail) against the LDS-streaming one, us per launch:

@@ -15,13 +15,16 @@
 // per-group fold (one scaled group accumulator per output) are three times the int8 kernel's VALU work per MFMA, so at large M,
 // where the dequantize pass is amortised over thousands of rows, the dense path wins again (dispatch in c_api.hip, measured).
 //
-// Structure: workgroup = 8 waves as 2 x 4 = 128 tokens x 64 packed rows (= 64 features of the low plane + the 64 features N/2
-// further of the high plane), wave = 64 tokens x 32 features; K-tile = one group (128 k).  Activations AND weights travel by LDS-DMA
-// into a ring of three 40 KiB stages, two tiles ahead (256-byte activation rows, chunk ^ (row & 15) on the DMA source, undone on the
-// read; 128-byte weight rows, chunk ^ (row & 7)).  Scales / shifts of the workgroup's 128 features for its groups are parked in LDS
-// once.  Split-K (r2) where the table of all groups does not fit (K = 14336): the groups are split over 2 or 4 workgroups per tile,
-// fp32 partial tiles go through the workspace (write-through stores, arrival counter, the last workgroup adds them in split order -
-// the protocol of qbits_skinny.hip).  It does not pay as a way to fill idle CUs (pick_split below).
+// Structure (r3): workgroup = 8 waves, BM tokens x 64 packed rows (= 64 features of the low plane + the 64 features N/2 further of
+// the high plane); wave w = ALL BM tokens x 16 features (packed rows 8w .. 8w+7, both planes: lanes 0-7 of every 16 keep the low
+// nibbles, lanes 8-15 the high nibbles of the same 8 rows - the decode kernels' mapping); K-tile = one group (128 k).  Every weight
+// is turned into an MFMA operand exactly once per workgroup (r2's 2 x 4 layout built every operand in both token halves and spent
+// 2.2 VALU per MFMA on it; here 8 VALU serve 4 k-steps x MI MFMAs).  Activations AND weights travel by LDS-DMA into a ring of three
+// stages, two tiles ahead (256-byte activation rows, chunk ^ (row & 15) on the DMA source, undone on the read; 128-byte weight rows,
+// chunk ^ (row & 7)).  Scales / shifts of the workgroup's 128 features for its groups are parked in LDS once (16-byte loads, issued
+// in front of the first tiles' DMA).  Split-K where the scale table does not fit (K = 14336 with 128-token tiles) and, with 64-token
+// tiles, to fill the chip: fp32 partial tiles through the workspace, write-through stores, arrival counter, the last workgroup adds
+// them in split order - the protocol of qbits_skinny.hip.
 #include <type_traits>
 
 #include "qh_common.h"
@@ -29,20 +32,17 @@
 namespace qh {
 namespace fused4 {
 
-// Workgroup: 8 waves as 2 (token halves) x 4 (blocks of 16 packed rows) = BM tokens x 64 packed rows (128 features), one per CU
-// (two waves per SIMD).  Wave: BM/2 tokens x 32 features = MI x 2 accumulator blocks (running + group).
-//   BM = 128 (MI = 4): 32 KiB of activations per 8 KiB of packed weights and tile - the form for grids that fill the chip;
-//   BM = 64  (MI = 2): r3 - twice the workgroups for short prefills whose 128-token tiles leave CUs idle ((512,4096,4096): 128 ->
-//                      256 workgroups), 24 KiB per tile.
+// Token tile: BM = 128 (MI = 8 fragments per wave) for grids that fill the chip - 32 KiB of activations per 8 KiB of packed weights
+// and tile -, BM = 64 (MI = 4) for short prefills whose 128-token tiles would leave CUs idle ((512,4096,4096): 128 -> 256 workgroups).
 constexpr int BK = 128, PR = 64, WAVES = 8, DEPTH = 2, STAGES = 3;
 constexpr int W_BYTES = PR * BK;  // 8 KiB
 template <int BM>
 struct Geo {
-  static constexpr int MI = BM / 32;            // 16-token fragments per wave
+  static constexpr int MI = BM / 16;            // 16-token fragments (every wave owns all of them)
   static constexpr int X_BYTES = BM * BK * 2, STAGE_BYTES = X_BYTES + W_BYTES;
   static constexpr int XP = BM / 4 / WAVES;     // activation DMA pieces (4 rows x 256 B = 1 KiB) per wave and tile; the weight tile is one piece per wave
   static constexpr int OPS = XP + 1;            // vector-memory instructions per wave and tile: activation pieces + weight piece
-  static_assert(W_BYTES == WAVES * 1024 && DEPTH * OPS <= 63 && (MI == 2 || MI == 4), "tile geometry");
+  static_assert(W_BYTES == WAVES * 1024 && DEPTH * OPS <= 63 && (MI == 4 || MI == 8), "tile geometry");
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -91,38 +91,50 @@ struct Args {
   int M, N, K, G;
   int S;               // K split: blockIdx.z handles groups [z * G / S, (z + 1) * G / S)
   int* counters;       // [tiles] arrival counters, zero on entry and on exit (S > 1)
-  float* partials;     // [tiles][S][512 lanes][2 * MI] float4
+  float* partials;     // [tiles][S][512 lanes][MI] float4
+  // QUANTO_HIP_FUSED4_ABLATE (timing experiments, WRONG results): 1 at most two tiles of the K loop, 2 no output stores, 4 no table fill
+  // (r3 also tried 8 = no DMA inside the K loop and 16 = no MFMA steps: (512,4096,4096) 38.8 -> 36.4 / 16.7 us - the step loop, not
+  // the DMA, is what a tile waits for; those two knobs changed the code of the loop they were meant to measure and were removed)
+  int ablate;
 };
 
-template <int DT, bool INT_SHIFT>
+template <int DT, bool INT_SHIFT, int BM>
 __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const Args a) {
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
+  constexpr int MI = Geo<BM>::MI, XP = Geo<BM>::XP, OPS = Geo<BM>::OPS, X_BYTES = Geo<BM>::X_BYTES, STAGE_BYTES = Geo<BM>::STAGE_BYTES;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  // layout: [STAGES x (activation tile | weight tile)] [sz: G x 2 x 128 features of T]
-  T* sz = reinterpret_cast<T*>(smem + STAGES * STAGE_BYTES);
+  // r3, measured and dropped ("shift term in the tail"): for bf16 the K loop folded only acc += s * acc_g, kept XS[m, g] of all groups and
+  // applied  - sum_g (z + 128 s)[n, g] * XS[m, g]  once, after the loop, as two K' = groups GEMMs on the matrix pipe (z, s: bf16 as stored;
+  // XS split into three bf16 pieces by truncation: exact products).  Parity-green; the loop lost a third of its VALU work and 9 % of
+  // its time (0.74 -> 0.67 us per 64-token tile), the tail cost 3.4 us per workgroup: (512,4096,4096) 28.5 -> 30.2 us.
+  // layout: [STAGES x (activation tile | weight tile)] [xs: 2 x BM fp32 group sums of x] [sz: G x 2 x 128 features of T]
+  float* xs_slot = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);
   constexpr int NF = 2 * PR;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
   const int M = a.M, N = a.N, K = a.K, G = a.G;
   const int P = N >> 1;
   const int p0 = blockIdx.x * PR, m0 = blockIdx.y * BM;
   const int S = a.S, sp = blockIdx.z;
   const int nk = G / S;     // one tile per group; this workgroup's groups are kt0 .. kt0 + nk - 1
+  const int nk_run = (a.ablate & 1) && nk > 2 ? 2 : nk;  // tiles the K loop runs (timing experiments only)
   const int kt0 = sp * nk;
   const int fi = lane & 15, fg = lane >> 4;
+  T* sz = reinterpret_cast<T*>(smem + STAGES * STAGE_BYTES + 2 * BM * 4);
 
   // ---- memory pipeline.  A tile lasts under a microsecond, a load from L2 / HBM under load 1-2 us: activations AND weights travel
   // by LDS-DMA into a ring of three stages, DEPTH = 2 tiles ahead.  The loop contains no other vector-memory instruction, so the
   // hand-counted s_waitcnt below is the only wait on that queue (hipcc counts only the loads it can see and would drain the DMA
   // queue at each of its own waits).  Every tile issues the same OPS DMA instructions; tiles past the end re-request the last tile
-  // (harmless), so the count never changes.  XS[m, g] needs no memory at all: one extra MFMA per step against an all-ones operand
+  // (harmless), so the count never changes.  XS[m, g] comes from the matrix pipe: an extra MFMA per k-step against an all-ones operand
   // accumulates sum_k x[m, k] in the same order and with the same roundings as the products it corrects - measured necessary for
   // fp16, where the 1024 offset leaves only ~13 bits of the fp32 accumulator for the signal: with XS from a separately ordered sum
-  // (a pre-kernel) 20 of 51 k outputs missed the 2-ulp gate; the matrix pipe has the slack (the loop is VALU-bound).
+  // (a pre-kernel) 20 of 51 k outputs missed the 2-ulp gate.  r3: the four waves that share a token half no longer compute it four
+  // times (12 of a wave's 48 MFMAs per tile were these): wave (wm, wn) runs the ones-products of fragment wn only and leaves the sums
+  // in LDS (xs_slot, double-buffered by tile parity) - the fold of a tile runs one tile later anyway, behind a barrier.
   uint32_t xsrc[XP];  // byte offsets from a.x (M * K * 2 < 4 GiB, checked by the launcher)
 #pragma unroll
   for (int u = 0; u < XP; ++u) {
@@ -149,10 +161,49 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
   };
   const int last = nk - 1;
 
-  // ---- prologue: tiles 0 and 1 requested; tables parked ------------------------------------------------------------------------------
+  // ---- prologue: tables requested, tiles 0 and 1 requested, ONE wait, tables parked ---------------------------------------------------
+  // r3: the scale / shift entries of a feature are contiguous over the groups, so a thread fetches 8 groups of one feature with one
+  // 16-byte load (r2: 2-byte loads, four groups apart per iteration, each iteration waiting for its own round trip: 8 dependent
+  // round trips in front of every workgroup's first MFMA).  The loads go out BEFORE the first two tiles' DMA and everything is
+  // waited for once.  Needs G % 8 == 0, a K-range of whole 8-group chunks and 16-byte aligned tables; otherwise the element loop.
+  constexpr int FILL_IT = 4;  // up to 4 x 512 chunks of 8 groups = 128 features x 128 groups
+  const int chunks = nk >> 3;
+  const bool vec_fill = !INT_SHIFT && (G & 7) == 0 && (nk & 7) == 0 && NF * chunks <= FILL_IT * WAVES * 64 &&
+                        ((reinterpret_cast<uintptr_t>(a.scale) | reinterpret_cast<uintptr_t>(a.shift)) & 15) == 0;
+  uint4 sv[FILL_IT], zv[FILL_IT];
+  if (vec_fill && !(a.ablate & 4)) {
+#pragma unroll
+    for (int it = 0; it < FILL_IT; ++it) {
+      const int e = tid + it * (WAVES * 64);
+      if (e < NF * chunks) {
+        const int f = e & (NF - 1), c = e >> 7;
+        int p = p0 + (f & (PR - 1));
+        p = p < P ? p : P - 1;
+        const size_t row = (size_t)(p + (f >> 6) * P) * G + kt0 + c * 8;
+        sv[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.scale) + row);
+        zv[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.shift) + row);
+      }
+    }
+  }
   issue_tile(0, 0);
   issue_tile(nk > 1 ? 1 : 0, 1);
-  {
+  if (a.ablate & 4) {
+  } else if (vec_fill) {
+#pragma unroll
+    for (int it = 0; it < FILL_IT; ++it) {
+      const int e = tid + it * (WAVES * 64);
+      if (e < NF * chunks) {
+        const int f = e & (NF - 1), c = e >> 7;
+        const T* se = reinterpret_cast<const T*>(&sv[it]);
+        const T* ze = reinterpret_cast<const T*>(&zv[it]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          sz[((c * 8 + j) * 2 + 0) * NF + f] = se[j];
+          sz[((c * 8 + j) * 2 + 1) * NF + f] = ze[j];
+        }
+      }
+    }
+  } else {
     // thread -> feature tid & 127 (plane = bit 6), groups (tid >> 7), +4, ...: no division in front of the loop
     const int f = tid & (NF - 1);
     int p = p0 + (f & (PR - 1));
@@ -166,71 +217,86 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
         sz[(g * 2 + 1) * NF + f] = reinterpret_cast<const T*>(a.shift)[row + g];
     }
   }
-  // the table loop contains compiler-visible loads with compiler-placed waits: drain once so that the hand-counted waits below
+  // the table code contains compiler-visible loads with compiler-placed waits: drain once so that the hand-counted waits below
   // start from a known state (tiles 0 and 1 have landed, nothing outstanding)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
   // ---- fragment read offsets --------------------------------------------------------------------------------------------------------
   // activations: chunk of k-step t for lane group g is 8 (t >> 1) + 2 g + (t & 1) (the weight bytes the lane holds: k = 16 g +
-  // 8 (t & 1) .. for t < 2, 64 + 16 g + 8 (t & 1) .. for t >= 2); rows wm*64 + i*16 + fi, so (row & 15) == fi for every fragment
+  // 8 (t & 1) .. for t < 2, 64 + 16 g + 8 (t & 1) .. for t >= 2); rows i*16 + fi, so (row & 15) == fi for every fragment
   int xoff[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) xoff[t] = (wm * 64 + fi) * 256 + (((8 * (t >> 1) + 2 * fg + (t & 1)) ^ fi) << 4);
-  // weights: 16-byte chunks fg and 4 + fg of packed row wn*16 + fi of the tile (128-byte rows, chunk ^ (row & 7))
+  for (int t = 0; t < 4; ++t) xoff[t] = fi * 256 + (((8 * (t >> 1) + 2 * fg + (t & 1)) ^ fi) << 4);
+  // weights: 16-byte chunks fg and 4 + fg of packed row wave*8 + (fi & 7) of the tile (128-byte rows, chunk ^ (row & 7)); lanes fi and
+  // fi + 8 read the same bytes (LDS broadcast) and keep the low / the high nibbles
   int woff[2];
   {
-    const int r = wn * 16 + fi;
+    const int r = wave * 8 + (fi & 7);
 #pragma unroll
     for (int h = 0; h < 2; ++h) woff[h] = X_BYTES + r * 128 + (((4 * h + fg) ^ (r & 7)) << 4);
   }
-  // this lane's 4 consecutive features inside the block: plane j, local packed rows wn*16 + 4*fg + r
-  const int floc = wn * 16 + 4 * fg;
+  const uint32_t nib_shift = (fi >> 3) * 4;
+  // this lane's 4 consecutive features inside the block: plane fg >> 1, local packed rows wave*8 + 4*(fg & 1) + r
+  const int floc = (fg >> 1) * PR + wave * 8 + 4 * (fg & 1);
 
-  f32x4 acc[2][MI];
+  f32x4 acc[MI];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  uint32_t kmask = 0x000F000Fu, kmagic = Mma<DT>::MAGIC;
-  asm volatile("" : "+s"(kmask));
+  for (int i = 0; i < MI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // operand construction, 8 VALU per k-step (8 weights per lane): the lane's nibble plane is shifted down and masked once per raw
+  // dword, then ONE v_perm per pair of weights interleaves their bytes with the exponent byte of 128 (bf16 0x43) / 1024 (fp16 0x64)
+  uint32_t nibmask = 0x0F0F0F0Fu, kmagic = Mma<DT>::MAGIC;
+  asm volatile("" : "+s"(nibmask));
   asm volatile("" : "+v"(kmagic));
   const V8 ones = __builtin_bit_cast(V8, make_uint4(ONE2<DT>(), ONE2<DT>(), ONE2<DT>(), ONE2<DT>()));
 
   // Group accumulators are double-buffered: while tile kt accumulates into one set, the fold of tile kt-1 (scale / shift applied to
-  // the other set, 64 VALU + the table reads) is sliced over the 16 MFMA steps of tile kt.  Without this the two waves of a SIMD,
-  // re-synchronised by the barrier of every tile, run their MFMA phases together and then their fold phases together, and the
-  // matrix pipe and the VALU take turns idling (measured: 1.56 us per tile instead of ~0.8).
-  f32x4 accgA[2][MI], accxA[MI], accgB[2][MI], accxB[MI];
-  float s4[2][4], z4[2][4];  // scale and (shift + OFFSET * scale) of the lane's 2 x 4 features for the group being folded
+  // the other set) is sliced over the MFMA steps of tile kt - the two waves of a SIMD, re-synchronised by the barrier of every tile,
+  // would otherwise run their MFMA phases together and then their fold phases together.
+  f32x4 accgA[MI], accgB[MI];
+  float s4[4], z4[4];  // scale and (shift + OFFSET * scale) of the lane's 4 features for the group being folded
+  float xsp[MI];       // XS[token of this lane, group being folded] per fragment, from xs_slot
+  // XS[m, g] = sum_k x[m, k] comes from the matrix pipe: an MFMA per k-step against an all-ones operand accumulates it in the same
+  // order and with the same roundings as the products it corrects - measured necessary for fp16, where the 1024 offset leaves only
+  // ~13 bits of the fp32 accumulator for the signal (XS from a separately ordered sum: 20 of 51 k outputs missed the 2-ulp gate).
+  // r3: every wave used to run these products for all its fragments (a third of its MFMAs); now wave w runs them for fragment w only
+  // and leaves the sums in LDS (xs_slot, double-buffered by tile parity) - the fold runs one tile later anyway, behind a barrier.
+  const int my_xs = wave < MI ? wave : -1;
   auto load_sz = [&](int g) {
+    T s4t[4], z4t[4];
+    *reinterpret_cast<uint2*>(s4t) = *reinterpret_cast<const uint2*>(sz + (g * 2 + 0) * NF + floc);
+    *reinterpret_cast<uint2*>(z4t) = *reinterpret_cast<const uint2*>(sz + (g * 2 + 1) * NF + floc);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      T s4t[4], z4t[4];
-      *reinterpret_cast<uint2*>(s4t) = *reinterpret_cast<const uint2*>(sz + (g * 2 + 0) * NF + j * PR + floc);
-      *reinterpret_cast<uint2*>(z4t) = *reinterpret_cast<const uint2*>(sz + (g * 2 + 1) * NF + j * PR + floc);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s4[j][r] = E::to_f32(s4t[r]);
-        const float z = E::to_f32(z4t[r]);
-        z4[j][r] = INT_SHIFT ? s4[j][r] * (z + Mma<DT>::OFFSET) : z + Mma<DT>::OFFSET * s4[j][r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      s4[r] = E::to_f32(s4t[r]);
+      const float z = E::to_f32(z4t[r]);
+      z4[r] = INT_SHIFT ? s4[r] * (z + Mma<DT>::OFFSET) : z + Mma<DT>::OFFSET * s4[r];
     }
   };
-  // slice q (0..15) of the fold of one group: features r = 2 (q & 1), +1 of block (j = q >> 3, i = (q >> 1) & 3)
-  auto fold_slice = [&](const f32x4 (&pg)[2][MI], const f32x4 (&px)[MI], int q) {
-    const int j = q >> 3, i = (q >> 1) & 3, r0 = (q & 1) * 2;
+  auto load_xs = [&](int kt_prev) {
 #pragma unroll
-    for (int r = r0; r < r0 + 2; ++r) acc[j][i][r] += s4[j][r] * pg[j][i][r] - z4[j][r] * px[i][0];  // every row of the ones-product holds XS
+    for (int i = 0; i < MI; ++i) xsp[i] = xs_slot[(kt_prev & 1) * BM + i * 16 + fi];
+  };
+  // slice q (0 .. 4 MI - 1) of the fold of one group: feature r = q & 3 of fragment i = q >> 2
+  // Two FMAs, as asm: left as C++, hipcc SINKS the whole fold (pure arithmetic whose result nobody reads before the next fold)
+  // out of the MFMA steps to the end of the loop body, where it runs as one block while the matrix pipe idles (and its SLP
+  // vectorizer turns it into v_pk_* there).  The operands were produced a tile ago (pg) or by LDS reads hipcc waits for.
+  auto fold_slice = [&](const f32x4 (&pg)[MI], int q) {
+    const int i = q >> 2, r = q & 3;
+    float v = acc[i][r];
+    asm volatile("v_fmac_f32 %0, %1, %2\n\tv_fma_f32 %0, -%3, %4, %0" : "+v"(v) : "v"(s4[r]), "v"(pg[i][r]), "v"(z4[r]), "v"(xsp[i]));
+    acc[i][r] = v;
   };
 
   int stage = 0;
-  // One tile (= one group) accumulating into (cg, cx) while the previous tile's (pg, px) is folded.
-  auto tile = [&](int kt, f32x4 (&cg)[2][MI], f32x4 (&cx)[MI], const f32x4 (&pg)[2][MI], const f32x4 (&px)[MI], bool have_prev) {
+  constexpr int XR = 6, XD = 4;  // activation fragments: ring of 6 registers sets, fetched 4 steps ahead of their MFMA (one MFMA per step)
+  // One tile (= one group) accumulating into cg while the previous tile's pg is folded.
+  auto tile = [&](int kt, f32x4 (&cg)[MI], const f32x4 (&pg)[MI], auto have_prev_tag) {
+    constexpr bool have_prev = decltype(have_prev_tag)::value;
     // requests of tile kt (issued two tiles ago) have landed once at most the one younger group is outstanding.  (Tiles 0 and 1:
     // completed by the prologue; fewer groups are outstanding than the count allows, the wait falls through.)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * OPS) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragment / table reads of the previous tile
-    __builtin_amdgcn_s_barrier();  // tile kt visible to all; everybody is done with tile kt-1, whose stage is refilled now
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragment / table reads and the XS store of the previous tile
+    __builtin_amdgcn_s_barrier();  // tile kt and the XS sums of tile kt-1 visible to all; everybody is done with tile kt-1, whose stage is refilled now
     asm volatile("" ::: "memory");
     {
       const int tn = kt + DEPTH < nk ? kt + DEPTH : last;
@@ -241,76 +307,91 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
     uint4 w[2];
     w[0] = *reinterpret_cast<const uint4*>(st + woff[0]);
     w[1] = *reinterpret_cast<const uint4*>(st + woff[1]);
-    if (have_prev) load_sz(kt - 1);
+    V8 xf[XR];
+#pragma unroll
+    for (int u = 0; u < XD; ++u) xf[u] = *reinterpret_cast<const V8*>(st + xoff[u / MI] + (u % MI) * 4096);
+    if constexpr (have_prev) {
+      load_sz(kt - 1);
+      load_xs(kt - 1);
+    }
 
-    // 4 * MI steps (k-step t, token fragment i) of three MFMAs (low plane, high plane, ones -> XS); behind them a slice of the NEXT
-    // k-step's operand conversion, a slice of the previous group's fold and the activation fragment of step s+2.  The sched_barrier
-    // pins that order: left alone, hipcc hoists all fragment reads to the top of the tile and spills.
-    uint32_t lo[2][4], hi[2][4];
+    // 4 * MI steps (k-step t, token fragment i) of ONE product MFMA (+ the ones-product in the steps of this wave's XS fragment);
+    // behind it a slice of the NEXT k-step's operand construction, a slice of the previous group's fold and the activation fragment
+    // of step s + XD.  The sched_barrier pins that order: left alone, hipcc hoists all fragment reads to the top of the tile.
+    uint32_t opw[2][4], mk[2];
     auto raw = [&](int t, int d) -> uint32_t {  // dword d (0, 1) of the 8 weight bytes of k-step t
       const uint4& q = w[t >> 1];
       return (t & 1) ? (d ? q.w : q.z) : (d ? q.y : q.x);
     };
-    auto convert = [&](int t, int c) {  // operand dword c (0..3 low plane, 4..7 high plane) of k-step t
-      const uint32_t src = raw(t, (c & 3) >> 1) >> (c >= 4 ? 4 : 0);
-      const uint32_t v = (__builtin_amdgcn_perm(0u, src, (c & 1) ? 0x0C030C02u : 0x0C010C00u) & kmask) | kmagic;
-      if (c < 4)
-        lo[t & 1][c] = v;
-      else
-        hi[t & 1][c - 4] = v;
+    auto conv_op = [&](int t, int o) {  // the 8 VALU ops that build the operand of k-step t: 2 x (shift, mask), 4 x v_perm
+      if (o == 0 || o == 2) {
+        mk[o >> 1] = raw(t, o >> 1) >> nib_shift;
+      } else if (o == 1 || o == 3) {
+        mk[o >> 1] &= nibmask;
+      } else {
+        const int c = o - 4;  // operand dword c: weights 2c, 2c + 1 -> (q, exp, q', exp)
+        opw[t & 1][c] = __builtin_amdgcn_perm(kmagic, mk[c >> 1], (c & 1) ? 0x07030502u : 0x07010500u);
+      }
     };
 #pragma unroll
-    for (int c = 0; c < 8; ++c) convert(0, c);
-    V8 xf[3];
-    xf[0] = *reinterpret_cast<const V8*>(st + xoff[0]);
-    xf[1] = *reinterpret_cast<const V8*>(st + xoff[0] + 4096);
+    for (int o = 0; o < 8; ++o) conv_op(0, o);
 #pragma unroll
     for (int s = 0; s < 4 * MI; ++s) {
       const int t = s / MI, i = s % MI;
-      const V8 wl = __builtin_bit_cast(V8, make_uint4(lo[t & 1][0], lo[t & 1][1], lo[t & 1][2], lo[t & 1][3]));
-      const V8 wh = __builtin_bit_cast(V8, make_uint4(hi[t & 1][0], hi[t & 1][1], hi[t & 1][2], hi[t & 1][3]));
-      cg[0][i] = Mma<DT>::run(wl, xf[s % 3], t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : cg[0][i]);
+      const V8 wa = __builtin_bit_cast(V8, make_uint4(opw[t & 1][0], opw[t & 1][1], opw[t & 1][2], opw[t & 1][3]));
+      cg[i] = Mma<DT>::run(wa, xf[s % XR], t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : cg[i]);
       if (t < 3) {
-        // the 8 operand dwords of k-step t+1, spread over the MI steps of k-step t
+        // the operand of k-step t+1, spread over the MI steps of k-step t (the masks of ops 0..3 are consumed by ops 4..7 of the
+        // same k-step, all later in this loop)
 #pragma unroll
-        for (int c = i * 8 / MI; c < (i + 1) * 8 / MI; ++c) convert(t + 1, c);
+        for (int o = i * 8 / MI; o < (i + 1) * 8 / MI; ++o) conv_op(t + 1, o);
       }
-      cg[1][i] = Mma<DT>::run(wh, xf[s % 3], t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : cg[1][i]);
-      if (have_prev) fold_slice(pg, px, s);
-      cx[i] = Mma<DT>::run(ones, xf[s % 3], t == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : cx[i]);
-      if (s + 2 < 4 * MI) xf[(s + 2) % 3] = *reinterpret_cast<const V8*>(st + xoff[(s + 2) / MI] + ((s + 2) % MI) * 4096);
+      if constexpr (have_prev) fold_slice(pg, s);
+      if (s + XD < 4 * MI) xf[(s + XD) % XR] = *reinterpret_cast<const V8*>(st + xoff[(s + XD) / MI] + ((s + XD) % MI) * 4096);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    // XS of this wave's fragment: four ones-products in k-step order (the order of the products they correct), ONE wave-uniform
+    // branch per tile; every row of the result holds sum_k x[token, k] of this group: lanes 0..15 (row 0) leave it for the fold
+    // one tile later
+    if (my_xs >= 0) {
+      f32x4 cx = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) cx = Mma<DT>::run(ones, *reinterpret_cast<const V8*>(st + xoff[t] + my_xs * 4096), cx);
+      if (lane < 16) xs_slot[(kt & 1) * BM + my_xs * 16 + lane] = cx[0];
     }
     stage = stage + 1 == STAGES ? 0 : stage + 1;
   };
-  static_assert(MI == 4, "fold_slice maps 16 slices onto 2 x MI x 2 register pairs");
-  tile(0, accgA, accxA, accgB, accxB, false);
+  auto final_fold = [&](const f32x4 (&pg)[MI]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the XS sums of the last tile
+    asm volatile("" ::: "memory");
+    load_sz(nk_run - 1);
+    load_xs(nk_run - 1);
+#pragma unroll
+    for (int q = 0; q < 4 * MI; ++q) fold_slice(pg, q);
+  };
+  using yes = std::integral_constant<bool, true>;
+  tile(0, accgA, accgB, std::integral_constant<bool, false>{});
   int kt = 1;
-  for (; kt + 2 <= nk; kt += 2) {
-    tile(kt, accgB, accxB, accgA, accxA, true);
-    tile(kt + 1, accgA, accxA, accgB, accxB, true);
+  for (; kt + 2 <= nk_run; kt += 2) {
+    tile(kt, accgB, accgA, yes{});
+    tile(kt + 1, accgA, accgB, yes{});
   }
-  if (kt < nk) {
-    tile(kt, accgB, accxB, accgA, accxA, true);  // nk even: the last tile landed in set B
-    load_sz(nk - 1);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) fold_slice(accgB, accxB, q);
+  if (kt < nk_run) {
+    tile(kt, accgB, accgA, yes{});  // nk even: the last tile landed in set B
+    final_fold(accgB);
   } else {
-    load_sz(nk - 1);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) fold_slice(accgA, accxA, q);
+    final_fold(accgA);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-requested tiles past the end: nothing may land in LDS after the kernel moved on
 
   // ---- split-K: fp32 partial tiles through the workspace, the last workgroup of a tile adds them in split order (qbits_skinny.hip) ----
   if (S > 1) {
     const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
-    float* mine = a.partials + ((size_t)(tile_id * S + sp) * (WAVES * 64) + tid) * (2 * MI * 4);
+    float* mine = a.partials + ((size_t)(tile_id * S + sp) * (WAVES * 64) + tid) * (MI * 4);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int i = 0; i < MI; ++i)  // s_nop: gfx9 hazard "VMEM store of > 64 bits, then VALU write of its data VGPRs"
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + (j * MI + i) * 4), "v"(acc[j][i]) : "memory");
+    for (int i = 0; i < MI; ++i)  // s_nop: gfx9 hazard "VMEM store of > 64 bits, then VALU write of its data VGPRs"
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + i * 4), "v"(acc[i]) : "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem);
@@ -319,118 +400,168 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
     if (*flag != S - 1) return;
     if (tid == 0) __hip_atomic_store(a.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // leave the workspace as found
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < MI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fixed order: the result does not depend on which workgroup arrived last.  The loads of up to four splits are in flight
+    // together: a system-coherent load is a ~2 us round trip, and r2's loop paid one per split ((128,4096,4096) with 4 splits:
+    // ~12 of its 21.7 us were this tail)
+    constexpr int QB = BM == 64 ? 4 : 2;  // splits per batch: QB * MI float4 registers
+    for (int q0 = 0; q0 < S; q0 += QB) {
+      f32x4 v[QB][MI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int q = 0; q < S; ++q) {  // fixed order: the result does not depend on which workgroup arrived last
-      const float* theirs = a.partials + ((size_t)(tile_id * S + q) * (WAVES * 64) + tid) * (2 * MI * 4);
-      f32x4 v[2 * MI];
+      for (int j = 0; j < QB; ++j) {
+        const int q = q0 + j < S ? q0 + j : S - 1;
+        const float* theirs = a.partials + ((size_t)(tile_id * S + q) * (WAVES * 64) + tid) * (MI * 4);
 #pragma unroll
-      for (int e = 0; e < 2 * MI; ++e) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[e]) : "v"(theirs + e * 4) : "memory");
+        for (int e = 0; e < MI; ++e) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[j][e]) : "v"(theirs + e * 4) : "memory");
+      }
 #pragma unroll
-      for (int e = 0; e < 2 * MI; ++e) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[e])::"memory");  // ties the uses below to the wait
+      for (int j = 0; j < QB; ++j)
 #pragma unroll
-      for (int e = 0; e < 2 * MI; ++e)
+        for (int e = 0; e < MI; ++e) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[j][e])::"memory");  // ties the uses below to the wait
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[e / MI][e % MI][r] += v[e][r];
+      for (int j = 0; j < QB; ++j)
+        if (q0 + j < S) {
+#pragma unroll
+          for (int e = 0; e < MI; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[e][r] += v[j][e][r];
+        }
     }
   }
 
-  // ---- epilogue: 4 consecutive features of one token per (plane, fragment): 8-byte stores --------------------------------------------
+  // ---- epilogue: 4 consecutive features of one token per fragment: 8-byte stores -------------------------------------------------------
   T* yg = reinterpret_cast<T*>(a.y);
   const bool has_bias = a.bias != nullptr;
+  const int pl = p0 + wave * 8 + 4 * (fg & 1);  // first of the lane's 4 packed rows
+  const int n0 = pl + (fg >> 1) * P;            // 4 consecutive output features n0 .. n0+3
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (has_bias) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int pl = p0 + floc;            // first of the lane's 4 packed rows
-    const int n0 = pl + j * P;           // 4 consecutive output features n0 .. n0+3
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (has_bias) {
+    for (int r = 0; r < 4; ++r) bv[r] = pl + r < P ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n0 + r]) : 0.f;
+  }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = pl + r < P ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n0 + r]) : 0.f;
-    }
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + i * 16 + fi;
+    if (m < M && !(a.ablate & 2)) {
+      T out[4];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + fi;
-      if (m < M) {
-        T out[4];
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][r];
+        if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[r];
+        out[r] = E::from_f32(v);
+      }
+      if (pl + 3 < P && (N & 3) == 0) {
+        *reinterpret_cast<uint2*>(yg + (size_t)m * N + n0) = *reinterpret_cast<const uint2*>(out);
+      } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[j][i][r];
-          if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[r];
-          out[r] = E::from_f32(v);
-        }
-        if (pl + 3 < P && (N & 3) == 0) {
-          *reinterpret_cast<uint2*>(yg + (size_t)m * N + n0) = *reinterpret_cast<const uint2*>(out);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (pl + r < P) yg[(size_t)m * N + n0 + r] = out[r];
-        }
+        for (int r = 0; r < 4; ++r)
+          if (pl + r < P) yg[(size_t)m * N + n0 + r] = out[r];
       }
     }
   }
 }
 
-inline int lds_bytes(int groups) { return STAGES * STAGE_BYTES + groups * 2 * (2 * PR) * 2; }
+inline int lds_bytes(int groups, int bm) { return STAGES * (bm * BK * 2 + W_BYTES) + 2 * bm * 4 + groups * 2 * (2 * PR) * 2; }
 
-inline int tiles_of(int64_t M, int64_t N) { return (int)(((N / 2 + PR - 1) / PR) * ((M + BM - 1) / BM)); }
+inline int tiles_of(int64_t M, int64_t N, int bm) { return (int)(((N / 2 + PR - 1) / PR) * ((M + bm - 1) / bm)); }
 
-// K split.  Measured (us, unsplit / 2 / 4): (512,4096,4096) 49.7 / 52.6 / 80.8 - a split costs a 64 KiB fp32 partial tile per
-// workgroup through the fabric and back, which eats what the idle CUs would give - so K is split only where the scale table of
-// all groups does not fit the LDS (K = 14336), and then as far as the tiles leave CUs idle: (256,14336,4096) 76.9 us with 4 splits
-// against 153 us for dequantize + dense GEMM, (512,14336,4096) 115.5 against 155.
-inline int pick_split(int64_t M, int64_t N, int G) {
-  const int forced = env_int("QUANTO_HIP_FUSED4_SPLIT", 0);
-  if (forced > 0 && G % forced == 0) return forced;
-  if (lds_bytes(G) <= 160 * 1024) return 1;
-  const int tiles = tiles_of(M, N);
-  int s = 1;
-  while (s < 4 && G % (s * 2) == 0 && (lds_bytes(G / s) > 160 * 1024 || tiles * s * 2 <= 256)) s *= 2;
-  if ((size_t)tiles * 4 > QUANTO_HIP_WS_COUNTER_BYTES) s = 1;
-  return s;
+// Token tile and K split, chosen together from a small time model fitted to r3's sweeps (profiles/r03_fused_int4_gemm.md; us):
+//   t = 5.8 + rounds * groups_per_workgroup * t_tile + tail,   rounds = ceil(workgroups / 256 CUs),
+//   t_tile = 0.68 (64-token tiles) / 1.2 (128-token tiles),     tail = 4 + 1.2 per MB of fp32 partial tiles when K is split.
+// 128 tokens per workgroup halve the activation bytes per weight byte, but a short prefill then leaves CUs idle ((512,4096,4096) is
+// 128 tiles of 128 tokens on 256 CUs: 46.7 us against 28.5 with 64-token tiles); a split costs its tail (a 32 / 64 KiB partial tile
+// per workgroup through the fabric and back, arrival counter, one more round trip for the last workgroup), so it pays for few
+// tiles or long K only: (128,4096,4096) 27.5 / 24.4 / 23.4 us with 1 / 2 / 4 splits, (128,14336,4096) 82 / 52 / 41, but
+// (256,4096,4096) 27.7 / 28.1.  The scale tables of a workgroup's groups must fit the LDS next to the ring (K = 14336 with 128-token
+// tiles needs a split for that alone).
+struct Plan {
+  int bm, S;
+  float us;
+};
+inline float model_us(int tiles, int nk, int bm, int S) {
+  const int wgs = tiles * S, rounds = (wgs + 255) / 256;
+  const float tail = S > 1 ? 4.f + 1.2f * (float)wgs * (float)(bm * 512) * 1e-6f : 0.f;
+  return 5.8f + (float)rounds * (float)nk * (bm == 64 ? 0.68f : 1.2f) + tail;
+}
+inline Plan make_plan(int64_t M, int64_t N, int G) {
+  const int fbm = env_int("QUANTO_HIP_FUSED4_BM", 0), fs = env_int("QUANTO_HIP_FUSED4_SPLIT", 0);  // experiments / tests
+  Plan best{0, 0, 0.f};
+  for (int bm = 128; bm >= 64; bm -= 64) {
+    if ((fbm == 64 || fbm == 128) && bm != fbm) continue;
+    const int tiles = tiles_of(M, N, bm);
+    for (int S = 1; S <= 8; S *= 2) {
+      if (G % S) break;
+      const int nk = G / S;
+      if (fs > 0 ? (S != fs) : (S > 1 && nk < 4)) continue;
+      if (lds_bytes(nk, bm) > 160 * 1024) continue;
+      if (S > 1 && (size_t)tiles * 4 > QUANTO_HIP_WS_COUNTER_BYTES) continue;
+      const float us = model_us(tiles, nk, bm, S);
+      if (best.bm == 0 || us < best.us * 0.97f) best = Plan{bm, S, us};  // ties: fewer splits, the larger tile
+    }
+  }
+  return best;  // bm == 0: no configuration fits (a forced split that does not divide the groups, tables that never fit)
+}
+
+template <int DT, bool INT_SHIFT, int BM>
+static int launch_bm(const Args& a, hipStream_t stream) {
+  const int lds = lds_bytes(a.G / a.S, BM);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_mfma_fused_kernel<DT, INT_SHIFT, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const dim3 grid((unsigned)((a.N / 2 + PR - 1) / PR), (unsigned)((a.M + BM - 1) / BM), (unsigned)a.S);
+  hipLaunchKernelGGL((qbits_mfma_fused_kernel<DT, INT_SHIFT, BM>), grid, dim3(WAVES * 64), lds, stream, a);
+  return launch_status();
 }
 
 template <int DT, bool INT_SHIFT>
-static int launch(const Args& a, hipStream_t stream) {
-  const int lds = lds_bytes(a.G / a.S);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_mfma_fused_kernel<DT, INT_SHIFT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  const dim3 grid((unsigned)((a.N / 2 + PR - 1) / PR), (unsigned)((a.M + BM - 1) / BM), (unsigned)a.S);
-  hipLaunchKernelGGL((qbits_mfma_fused_kernel<DT, INT_SHIFT>), grid, dim3(WAVES * 64), lds, stream, a);
-  return launch_status();
+static int launch(const Args& a, int bm, hipStream_t stream) {
+  return bm == 64 ? launch_bm<DT, INT_SHIFT, 64>(a, stream) : launch_bm<DT, INT_SHIFT, 128>(a, stream);
 }
 
 }  // namespace fused4
 
 bool qbits_mfma_fused_supported(int64_t M, const PackedGeom& g, int dtype) {
-  return g.bits == 4 && g.C == 128 && (g.N % 8 == 0) && (g.K % 128 == 0) && M >= 1 && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) &&
-         g.N < (1 << 30) && g.K < (1 << 30) && M * g.K < (1ll << 31) && g.N * g.K < (1ll << 33) &&
-         fused4::lds_bytes((int)g.G / fused4::pick_split(M, g.N, (int)g.G)) <= 160 * 1024;
+  if (!(g.bits == 4 && g.C == 128 && (g.N % 8 == 0) && (g.K % 128 == 0) && M >= 1 && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) &&
+        g.N < (1 << 30) && g.K < (1 << 30) && M * g.K < (1ll << 31) && g.N * g.K < (1ll << 33)))
+    return false;
+  return fused4::make_plan(M, g.N, (int)g.G).bm != 0;
 }
 
-// true when the problem cannot run without the split-K scratch (the scale table of all groups does not fit the LDS: K = 14336)
-bool qbits_mfma_fused_needs_workspace(const PackedGeom& g) { return fused4::lds_bytes((int)g.G) > 160 * 1024; }
+// modelled time of the configuration make_plan picks, in units of "one round of 128-token tiles at this K" (46 us at K = 4096): what
+// c_api.hip compares with the dequantize + dense GEMM path (flat in M up to ~1 k rows)
+float qbits_mfma_fused_cost(int64_t M, const PackedGeom& g) {
+  const fused4::Plan p = fused4::make_plan(M, g.N, (int)g.G);
+  return p.bm == 0 ? 1e9f : p.us / (46.f * (float)g.K / 4096.f);
+}
+
+// true when the problem cannot run without the split-K scratch (no unsplit configuration fits the LDS: the scale tables of K = 14336)
+bool qbits_mfma_fused_needs_workspace(const PackedGeom& g) {
+  return fused4::lds_bytes((int)g.G, 128) > 160 * 1024 && fused4::lds_bytes((int)g.G, 64) > 160 * 1024;
+}
 
 // [counters (zero on entry, zero on exit) | fp32 partial tiles]; 0 when K is not split (the group sums of x come from the matrix pipe)
 size_t qbits_mfma_fused_workspace(int64_t M, const PackedGeom& g) {
-  const int S = fused4::pick_split(M, g.N, (int)g.G);
-  if (S == 1) return 0;
-  return QUANTO_HIP_WS_COUNTER_BYTES + (size_t)fused4::tiles_of(M, g.N) * S * (fused4::WAVES * 64) * (2 * fused4::MI * 16);
+  const fused4::Plan p = fused4::make_plan(M, g.N, (int)g.G);
+  if (p.bm == 0 || p.S == 1) return 0;
+  return QUANTO_HIP_WS_COUNTER_BYTES + (size_t)fused4::tiles_of(M, g.N, p.bm) * p.S * (fused4::WAVES * 64) * ((p.bm / 16) * 16);
 }
 
 int qbits_mm_mfma_fused(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t M,
                         const PackedGeom& g, int dtype, bool int_shift, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbits_mfma_fused_supported(M, g, dtype)) return QUANTO_HIP_ENOTSUP;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed)) % 16) return QUANTO_HIP_EALIGN;
-  int S = fused4::pick_split(M, g.N, (int)g.G);
-  if (S > 1 && (!workspace || workspace_bytes < qbits_mfma_fused_workspace(M, g) || reinterpret_cast<uintptr_t>(workspace) % 16)) {
-    S = 1;  // no scratch: unsplit, if the whole scale table fits
-    if (fused4::lds_bytes((int)g.G) > 160 * 1024) return QUANTO_HIP_EINVAL;
+  fused4::Plan p = fused4::make_plan(M, g.N, (int)g.G);
+  if (p.S > 1 && (!workspace || workspace_bytes < qbits_mfma_fused_workspace(M, g) || reinterpret_cast<uintptr_t>(workspace) % 16)) {
+    // no scratch: unsplit, with whichever token tile lets the whole scale table fit
+    p.S = 1;
+    if (fused4::lds_bytes((int)g.G, p.bm) > 160 * 1024) p.bm = 64;
+    if (fused4::lds_bytes((int)g.G, p.bm) > 160 * 1024) return QUANTO_HIP_EINVAL;
   }
+  const int bm = p.bm, S = p.S;
   fused4::Args a{x, packed, scale, shift, bias, y, (int)M, (int)g.N, (int)g.K, (int)g.G, S, reinterpret_cast<int*>(workspace),
-                 S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + QUANTO_HIP_WS_COUNTER_BYTES) : nullptr};
+                 S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + QUANTO_HIP_WS_COUNTER_BYTES) : nullptr,
+                 env_int("QUANTO_HIP_FUSED4_ABLATE", 0)};
   if (dtype == QUANTO_HIP_BF16)
-    return int_shift ? fused4::launch<QUANTO_HIP_BF16, true>(a, stream) : fused4::launch<QUANTO_HIP_BF16, false>(a, stream);
-  return int_shift ? fused4::launch<QUANTO_HIP_F16, true>(a, stream) : fused4::launch<QUANTO_HIP_F16, false>(a, stream);
+    return int_shift ? fused4::launch<QUANTO_HIP_BF16, true>(a, bm, stream) : fused4::launch<QUANTO_HIP_BF16, false>(a, bm, stream);
+  return int_shift ? fused4::launch<QUANTO_HIP_F16, true>(a, bm, stream) : fused4::launch<QUANTO_HIP_F16, false>(a, bm, stream);
 }
 
 }  // namespace qh

@@ -1,0 +1,4 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; O=gpurun_out/r3e; mkdir -p $O; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_hip_parity.py -q -m gpu -k "fused4 or prefill" -p no:cacheprovider -x > $O/parity.log 2>&1; echo "parity rc=$?"; tail -3 $O/parity.log
+timeout 900 python scripts/ab_prefill.py --shapes 4096x4096 --ms 128 256 512 1024 2048 4096 --variants mfma_fused4 dequant_mfma --fused-env "" "BM=64,SPLIT=1" "BM=64,SPLIT=1,ABLATE=1" "BM=128,SPLIT=1" "BM=128,SPLIT=1,ABLATE=1" > $O/sweep.jsonl 2> $O/sweep.err; cat $O/sweep.jsonl; tail -2 $O/sweep.err

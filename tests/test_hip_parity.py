@@ -204,10 +204,13 @@ def test_qbits_dequant_mfma(dt, M, N, K, bits, gs, zp):
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K,zp", [(200, 256, 512, False), (96, 128, 256, True), (300, 520, 384, False), (65, 8, 128, False),
                                       (513, 1024, 1152, True), (1000, 2048, 2048, False)])
-def test_qbits_mfma_fused4(dt, M, N, K, zp):
+@pytest.mark.parametrize("bm", ["64", "128"])
+def test_qbits_mfma_fused4(dt, M, N, K, zp, bm, monkeypatch):
     """Fused int4 GEMM (qbits_mfma_fused.hip): packed nibbles -> MFMA operands in registers, scale / shift folded per group in
-    fp32; ragged M / N, short K (fewer tiles than the prefetch depth), zero-points, bias.  Oracle = exact math on the stored
-    integers (NOT the reference's rounded weight): this kernel never rounds a weight."""
+    fp32; ragged M / N, short K (fewer tiles than the prefetch depth), zero-points, bias; both token-tile sizes (64 / 128 rows per
+    workgroup, forced through the experiment knob).  Oracle = exact math on the stored integers (NOT the reference's rounded
+    weight): this kernel never rounds a weight."""
+    monkeypatch.setenv("QUANTO_HIP_FUSED4_BM", bm)
     p = make_qbits_problem(M, N, K, dt, zeropoint=zp, seed=M + N)
     assert_close_to_exact(_run_qbits(p, "mfma_fused4"), _exact_qbits(p), dt, f"mfma_fused4 {M}x{K}x{N}")
     # bias: the product rounded to the output dtype, the bias added, rounded again (the reference's order) - checked bit for bit
@@ -218,9 +221,9 @@ def test_qbits_mfma_fused4(dt, M, N, K, zp):
 
 
 def test_qbits_mfma_fused4_llama_prefill():
-    """What AUTO picks for short prefills of a Llama-3-8B layer (one round of 128 x 128 tiles): the fused kernel; whole output
-    against exact math."""
-    for M, N, K in ((512, 4096, 4096), (256, 14336, 4096), (1024, 4096, 4096)):
+    """What AUTO picks for short prefills of a Llama-3-8B layer (one round of tiles; 64-token tiles, K split to fill the chip, from
+    65 rows on): the fused kernel; whole output against exact math."""
+    for M, N, K in ((512, 4096, 4096), (256, 14336, 4096), (1024, 4096, 4096), (128, 4096, 4096), (200, 1024, 4096)):
         p = make_qbits_problem(M, N, K, "bf16", seed=N + K)
         y = _run_qbits(p, "auto")
         assert quanto_hip.lib.last_kernel() == "mfma_fused4"
@@ -234,11 +237,13 @@ def test_qbits_mfma_fused4_llama_prefill():
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("split", [1, 2, 4])
 @pytest.mark.parametrize("M,N,K,zp", [(200, 256, 1024, False), (300, 520, 2048, True), (130, 136, 512, False)])
-def test_qbits_mfma_fused4_split_k(dt, split, M, N, K, zp, monkeypatch):
+@pytest.mark.parametrize("bm", ["64", "128"])
+def test_qbits_mfma_fused4_split_k(dt, split, M, N, K, zp, bm, monkeypatch):
     """K split over 1 / 2 / 4 workgroups per tile (fp32 partial tiles through the workspace, last arriver adds in split order):
     ragged M / N, zero-points, bias; a second call on the same workspace (counters left zero); unsplit when the split does not
     divide the groups."""
     monkeypatch.setenv("QUANTO_HIP_FUSED4_SPLIT", str(split))
+    monkeypatch.setenv("QUANTO_HIP_FUSED4_BM", bm)
     p = make_qbits_problem(M, N, K, dt, zeropoint=zp, seed=M + N + split)
     y0 = _run_qbits(p, "mfma_fused4")
     assert_close_to_exact(y0, _exact_qbits(p), dt, f"mfma_fused4 split {split} {M}x{K}x{N}")
