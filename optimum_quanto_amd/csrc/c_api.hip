@@ -122,7 +122,7 @@ static bool mmv_wins(int64_t M, const PackedGeom& g) {
 }
 
 static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {
-  if (M <= 4 && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
+  if (M <= env_int("QUANTO_HIP_GEMV_MAX_M", 4) && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
   if (mmv_wins(M, g) && qbits_mmv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MMV;
   if (fused4_wins(M, g) && qbits_mfma_fused_supported(M, g, dtype) && (have_workspace || !qbits_mfma_fused_needs_workspace(g)))
     return QUANTO_HIP_KERNEL_MFMA_FUSED4;

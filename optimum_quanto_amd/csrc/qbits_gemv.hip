@@ -457,7 +457,7 @@ static int gemv_launch_m(const void* x, const GemvProblem& pb, int M, int K, hip
   // iters <= 2 slabs per wave (K <= 8192) to stay inside the register file.
   const int nslab = (K + 1023) / 1024;
   const int iters = (nslab + (nslab >= 3 ? 4 : nslab) - 1) / (nslab >= 3 ? 4 : nslab);
-  const int mt_max = iters <= 2 ? 8 : 4;
+  const int mt_max = (pb.gs != 128 || pb.bits != 4 || pb.nseg > 1) ? 4 : (iters <= 2 ? 8 : 4);  // the per-lane scale fetch variants exist for <= 4 rows
   int m0 = 0;
   while (m0 < M) {
     const int left = M - m0;
@@ -480,9 +480,11 @@ static int gemv_launch_m(const void* x, const GemvProblem& pb, int M, int K, hip
 bool qbits_gemv_supported(int64_t M, const PackedGeom& g, int dtype) {
   const bool common = (g.N % g.vpi == 0) && g.K <= 16384 && M >= 1 && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30);
   if (g.bits == 4 && g.C == 128) return common && (g.K % 128 == 0) && M <= QUANTO_HIP_GEMV_MAX_M_QBITS;
-  // the other group sizes of nn/qmodule.py:121-129 and per-channel scales: decode-sized calls only (M <= 4)
+  // the other group sizes of nn/qmodule.py:121-129, per-channel scales and qint2: decode-sized calls, in passes of 4 rows up to 24
+  // rows (r3; ~5-6 us per pass for a 4096^2 weight streamed from the Infinity Cache, against ~55 us for dequantize + dense GEMM,
+  // which these formats otherwise take for every M > 4)
   const bool other = g.C == 32 || g.C == 64 || g.C == 96 || g.C == 128 || (g.C == g.K && g.K % 16 == 0);
-  return common && other && (g.K % g.C == 0) && M <= 4;
+  return common && other && (g.K % g.C == 0) && M <= QUANTO_HIP_GEMV_MAX_M_OTHER;
 }
 
 static int gemv_dispatch(const void* x, const GemvProblem& pb, int M, int K, int dtype, bool int_shift, hipStream_t stream) {

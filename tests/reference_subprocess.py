@@ -171,7 +171,7 @@ def check_plugin_gpu():
     lib = quanto_hip.lib
     F = torch.nn.functional.linear
     torch.manual_seed(0)
-    fast = {1: ("gemv",), 8: ("mmv", "skinny"), 48: ("skinny",), 512: ("mfma_fused4",), 2048: ("dequant_mfma",)}
+    fast = {1: ("gemv",), 8: ("mmv", "skinny"), 48: ("skinny",), 100: ("mfma_fused4",), 512: ("mfma_fused4",), 2048: ("dequant_mfma", "mfma_fused4")}
     for dt in (torch.bfloat16, torch.float16):
         N, K = 1024, 1024
         w = (torch.randn(N, K) * 0.02).to(dt)

@@ -187,8 +187,8 @@ def test_auto_dispatch_accepts_misaligned_views(M):
 
 @pytest.mark.gpu
 def test_c_api_multi_fallback_restores_the_counter_words_behind_scratch_members():
-    """quanto_hip_qbits_mm_multi_ws falls back to separate calls that share ONE workspace.  Member 0 (N = 11008, K = 14336,
-    M = 300) resolves to DEQUANT_MFMA and writes the dequantized weight from offset 0 - over the arrival counters; member 1 (N = 256)
+    """quanto_hip_qbits_mm_multi_ws falls back to separate calls that share ONE workspace.  Member 0 (N = 4096, K = 4096,
+    M = 1100) resolves to DEQUANT_MFMA and writes the dequantized weight from offset 0 - over the arrival counters; member 1 (N = 256)
     resolves to the split-K form of the fused int4 GEMM and needs those counters to be zero.  Straight through the C ABI with one
     caller-owned buffer (the Python binding keeps zeroed and scratch buffers apart, so only a C caller can hit this)."""
     import ctypes
@@ -197,7 +197,7 @@ def test_c_api_multi_fallback_restores_the_counter_words_behind_scratch_members(
 
     lib, dev = quanto_hip.lib, "cuda"
     c = lib._c
-    M, K, Ns = 300, 14336, [11008, 256]
+    M, K, Ns = 1100, 4096, [4096, 256]
     BF16, DEQUANT, FUSED4 = 2, 7, 8
     c.quanto_hip_qbits_mm_pick.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 3
     assert [c.quanto_hip_qbits_mm_pick(M, n, K, 4, 128, BF16) for n in Ns] == [DEQUANT, FUSED4]
@@ -211,7 +211,7 @@ def test_c_api_multi_fallback_restores_the_counter_words_behind_scratch_members(
     c.quanto_hip_qbits_mm_multi_workspace_size.restype = ctypes.c_int64
     c.quanto_hip_qbits_mm_multi_workspace_size.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     need = c.quanto_hip_qbits_mm_multi_workspace_size(2, nfs, M, K, 4, 128, BF16)
-    assert need >= 11008 * K * 2
+    assert need >= 4096 * K * 2
     ws = torch.zeros((need,), dtype=torch.uint8, device=dev)  # the documented contract: counters zero on entry
     arr = lambda ts: (ctypes.c_void_p * 2)(*[t.data_ptr() for t in ts])  # noqa: E731
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -226,6 +226,6 @@ def test_c_api_multi_fallback_restores_the_counter_words_behind_scratch_members(
         assert np.isfinite(got).all(), "member 1: unwritten tiles (arrival election failed on dirty counters)"
         assert_close_to_exact(got, O.qbits_mm_exact(ps[0]["x"], ps[1]["packed"], 4, ps[1]["scale"], ps[1]["shift"], 128, 256, K), "bf16", f"member 1, round {rep}")
     rows = slice(0, 8)
-    w0 = O.dequantize_qbits_ref(ps[0]["packed"], 4, ps[0]["scale"], ps[0]["shift"], 0, 128, (11008, K), "bf16")  # the reference's rounded weight
+    w0 = O.dequantize_qbits_ref(ps[0]["packed"], 4, ps[0]["scale"], ps[0]["shift"], 0, 128, (4096, K), "bf16")  # the reference's rounded weight
     want0 = np.matmul(ps[0]["x"][rows].astype(np.float64), w0.astype(np.float64).T)
     assert_close_to_exact(to_numpy(ys[0])[rows], want0, "bf16", "member 0 (dequantize + dense), first rows")

@@ -99,3 +99,73 @@ def test_checkpoint_loads_straight_onto_the_device(tmp_path):
     # not torch.equal: the non-persistent rotary table is rebuilt in fp32 on reload, the original model's was cast to bf16
     cos = torch.nn.functional.cosine_similarity(got.flatten().float(), logits.flatten().float(), dim=0)
     assert cos > 0.9999, float(cos)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 32, 512])
+def test_llama3_8b_layer_at_full_size_every_qlinear_against_exact_math(rows):
+    """BASELINE config 5 at REAL size, one decoder layer (hidden 4096, intermediate 14336, 32 / 8 heads; small vocabulary so that
+    the embedding does not dominate): int4 weights, q/k/v and gate/up linked by fuse_decode_projections.  Forward hooks capture the
+    input and output of all seven QLinears inside the running model; every output is gated against float64 math on that module's
+    own integers / scales and its captured input (decode M = 1: fused GEMV launches; batched decode M = 32: one streaming launch per
+    sibling group; prefill M = 512: the fused int4 GEMM), and the fused model's logits equal the unfused model's where the
+    arithmetic is the same."""
+    import numpy as np
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    import optimum_quanto_amd as Q
+    from helpers import assert_close_to_exact, to_numpy
+    from oracle import quanto_oracle as O
+
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=1, num_attention_heads=32, num_key_value_heads=8,
+                      vocab_size=512, max_position_embeddings=1024, rope_theta=500000.0, tie_word_embeddings=False)
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        model = LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+    Q.QuantizedModelForCausalLM.quantize(model, weights=Q.qint4, exclude="lm_head")
+    ids = torch.randint(1, cfg.vocab_size - 1, (1, rows), generator=torch.Generator().manual_seed(rows)).cuda()
+    with torch.no_grad():
+        ref_logits = model(ids).logits
+    assert Q.fuse_decode_projections(model) == 2
+    captured = {}
+
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    def hook(name):
+        def fn(mod, args, out):
+            captured[name] = (args[0].detach().reshape(-1, args[0].shape[-1]), out.detach().reshape(-1, out.shape[-1]), quanto_hip.lib.last_kernel())
+        return fn
+
+    layer = model.model.layers[0]
+    mods = {"q_proj": layer.self_attn.q_proj, "k_proj": layer.self_attn.k_proj, "v_proj": layer.self_attn.v_proj, "o_proj": layer.self_attn.o_proj,
+            "gate_proj": layer.mlp.gate_proj, "up_proj": layer.mlp.up_proj, "down_proj": layer.mlp.down_proj}
+    handles = [m.register_forward_hook(hook(n)) for n, m in mods.items()]
+    with torch.no_grad():
+        logits = model(ids).logits
+    for h in handles:
+        h.remove()
+    assert set(captured) == set(mods)
+    for name, m in mods.items():
+        x, y, kernel = captured[name]
+        assert x.shape[0] == rows
+        w = m.weight
+        N, K = w.shape
+        packed, scale, shift = w._data._data.cpu().numpy(), to_numpy(w._scale), to_numpy(w._shift)
+        if kernel == "dequant_mfma":
+            # the large-M path does what the reference does: it multiplies the weight ROUNDED to bf16 (bit-identical to dequantize())
+            wr = O.dequantize_qbits_ref(packed, 4, scale, shift, 0, 128, (N, K), "bf16").astype(np.float64)
+            exact = np.matmul(to_numpy(x).astype(np.float64), wr.T)
+        else:
+            exact = O.qbits_mm_exact(to_numpy(x), packed, 4, scale, shift, 128, N, K)
+        assert_close_to_exact(to_numpy(y), exact, "bf16", f"Llama-3-8B layer, {name} ({rows} rows, {K}->{N}, {kernel})")
+    kernels = {n: captured[n][2] for n in mods}
+    if rows == 1:
+        assert kernels["q_proj"] == "gemv_multi" and kernels["gate_proj"] == "gemv_multi" and kernels["down_proj"] == "gemv", kernels
+    elif rows == 32:
+        assert kernels["q_proj"] == "skinny_multi" and kernels["down_proj"] == "skinny", kernels
+    else:
+        assert kernels["q_proj"] == "mfma_fused4" and kernels["down_proj"] == "mfma_fused4", kernels
+    if rows <= 4:  # GEMV launches: the fused launch is bit-identical to the separate calls, so the logits are too
+        assert torch.equal(logits, ref_logits)
+    else:
+        torch.testing.assert_close(logits.float(), ref_logits.float(), rtol=3e-2, atol=3e-2)

@@ -275,10 +275,12 @@ def test_qbits_naive_any_shape(dt, bits, gs, M, N, K, zp):
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("zp", [False, True])
 @pytest.mark.parametrize("M,N,K,gs", [(1, 256, 1024, 64), (2, 130, 2048, 32), (3, 64, 1152, 96), (4, 512, 4096, 64), (1, 1024, 4128, 32),
-                                      (1, 256, 960, 96), (1, 64, 160, None), (4, 200, 4096, None), (1, 4096, 4096, 64)])
+                                      (1, 256, 960, 96), (1, 64, 160, None), (4, 200, 4096, None), (1, 4096, 4096, 64),
+                                      (5, 256, 1024, 64), (13, 130, 2048, 32), (24, 512, 1152, 96), (9, 200, 4096, None), (17, 4096, 4096, 64)])
 def test_qbits_gemv_other_group_sizes(dt, zp, M, N, K, gs):
     """The decode GEMV for the group sizes the reference's QModuleMixin falls back to when in_features is not a multiple of 128
-    (nn/qmodule.py:121-129: 96 / 64 / 32) and for per-channel int4 (group_size=None): exact-math gate, AUTO must pick it."""
+    (nn/qmodule.py:121-129: 96 / 64 / 32) and for per-channel int4 (group_size=None): exact-math gate, AUTO must pick it - in
+    passes of 4 rows up to 24 rows (r3), so that batched decode with these formats no longer goes through dequantize + dense GEMM."""
     p = make_qbits_problem(M, N, K, dt, group_size=gs, zeropoint=zp, seed=N + K)
     y = _run_qbits(p, "auto")
     assert quanto_hip.lib.last_kernel() == "gemv"
@@ -291,7 +293,7 @@ def test_qbits_gemv_other_group_sizes(dt, zp, M, N, K, gs):
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("zp", [False, True])
 @pytest.mark.parametrize("M,N,K,gs", [(1, 256, 1024, 128), (2, 132, 2048, 64), (4, 512, 4096, 128), (1, 64, 160, None), (3, 1024, 1152, 96),
-                                      (1, 4096, 4096, 128)])
+                                      (1, 4096, 4096, 128), (6, 256, 1024, 128), (23, 512, 4096, 64)])
 def test_qbits_gemv_int2(dt, zp, M, N, K, gs):
     """qint2 weights (four planes per byte) on the same decode kernel: exact-math gate."""
     p = make_qbits_problem(M, N, K, dt, bits=2, group_size=gs, zeropoint=zp, seed=N + K + 2)
@@ -312,9 +314,12 @@ def test_qbits_auto_picks_fast_kernels():
     p = make_qbits_problem(32, 34, 1024, "bf16")  # N not a multiple of 64: GEMV passes
     _run_qbits(p, "auto")
     assert quanto_hip.lib.last_kernel() == "gemv"
-    p = make_qbits_problem(65, 256, 1024, "bf16")  # two passes of the streaming kernel
+    p = make_qbits_problem(64, 256, 1024, "bf16")  # one pass of the streaming kernel
     _run_qbits(p, "auto")
     assert quanto_hip.lib.last_kernel() == "skinny"
+    p = make_qbits_problem(65, 256, 1024, "bf16")  # r3: beyond 64 rows the fused int4 GEMM (64-token tiles) instead of two passes
+    _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "mfma_fused4"
     p = make_qbits_problem(40, 256, 512, "bf16", group_size=64)  # group size 64, small M: register-staged 128x128 kernel
     _run_qbits(p, "auto")
     assert quanto_hip.lib.last_kernel() == "mfma"
@@ -632,12 +637,13 @@ def test_cfg2_on_the_32x32x16_kernel(monkeypatch):
 
 @pytest.mark.parametrize("M", [32, 160])
 def test_batched_decode_llama_shapes(M):
-    """Streaming kernels (split-K, passes) on the Llama-3-8B layer shapes with the long K: sampled rows vs float64 math."""
+    """Batched decode / short prefill on the Llama-3-8B layer shapes with the long K (streaming kernels with split-K up to 64 rows, the
+    fused int4 GEMM beyond): vs float64 math."""
     for (N, K) in [(4096, 14336), (1024, 4096)]:
         p = make_qbits_problem(M, N, K, "bf16", seed=M + N)
         y = _run_qbits(p, "auto")
-        assert quanto_hip.lib.last_kernel() == "skinny"
-        assert_close_to_exact(y, _exact_qbits(p), "bf16", f"int4 skinny {M}x{K}x{N}")
+        assert quanto_hip.lib.last_kernel() == ("skinny" if M <= 64 else "mfma_fused4")
+        assert_close_to_exact(y, _exact_qbits(p), "bf16", f"int4 {quanto_hip.lib.last_kernel()} {M}x{K}x{N}")
         q = make_qbytes_problem(M, N, K, "bf16", None, seed=M + K)
         assert_close_to_exact(_run_qbytes(q, "auto"), O.qbytes_mm_exact(q["x"], q["data"], q["scale"]), "bf16", f"int8 {M}x{K}x{N}")
         assert quanto_hip.lib.last_kernel() in (("skinny",) if M <= 64 else ("skinny", "mfma_large"))
