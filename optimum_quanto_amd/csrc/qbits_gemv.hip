@@ -22,6 +22,7 @@
 // throughout, so the result is the exact-math value of the reference's integers/scales (no bf16
 // rounding of W).  Wave reductions use DPP adds (no LDS traffic).
 #include <cstdlib>
+#include <type_traits>
 
 #include "qh_common.h"
 
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(256)
   constexpr bool INT2 = (VARIANT & 16) != 0;
   constexpr int BITS = INT2 ? 2 : 4, PL = 8 / BITS;
   static_assert(!INT2 || (VARIANT & 8) != 0, "the int2 variant uses the per-lane scale fetch");
-  __shared__ float red[4][RR][PL][MT];
+  __shared__ float red[4][4][RR * PL * MT];  // [wave][16-lane row][value]
   constexpr bool EARLY_X = (VARIANT & 1) != 0, NT = (VARIANT & 2) != 0;
   constexpr bool ABLATE = (VARIANT & 4) != 0;  // measurement only (WRONG results): 1/4 of the arithmetic, all of the loads
   // bit 3: any group size the reference's QModuleMixin selects (nn/qmodule.py:121-129: 128, else 96 / 64 / 32 when in_features
@@ -315,34 +316,78 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int h = 0; h < PL; ++h)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-          acc[r][h][m] += s_r[r][h] * dot[h][m] - z_r[r][h] * xs[it][m];
+        for (int m = 0; m < MT; ++m) {
+          // two FMAs whose first factor is the quad broadcast: hipcc folds each v_mov_b32_dpp into its v_fmac_f32_dpp
+          acc[r][h][m] = __builtin_fmaf(s_r[r][h], dot[h][m], acc[r][h][m]);
+          acc[r][h][m] = __builtin_fmaf(-z_r[r][h], xs[it][m], acc[r][h][m]);
+        }
     }
   }
 
   // ---- 3. reduce over lanes (DPP), over the wpr waves (LDS), store -----------------------------------
+  // r3: the NV = RR * PL * MT partial sums of a lane are reduced TOGETHER.  Reducing each of them over the 64 lanes on its own is
+  // 6 DPP steps per value (with hipcc's SLP vectorizer in the way: v_mov_b32_dpp + v_pk_add_f32 + the moves that build the pairs -
+  // ~160 of the 565 instructions of an M = 1 wave, in a kernel whose fused gate+up launch is VALU-bound: 14 waves per SIMD x ~450 VALU
+  // x 4.5 cycles = its 13.9 us).  Halving instead: at step j a lane keeps the half of its values selected by bit j of its lane id,
+  // adds its partner's copy of that half (the lane that differs in exactly that bit) and forgets the other half - NV/2 + NV/4 + ... value-steps instead of 6 NV.  After the (up to four) steps
+  // inside a 16-lane DPP row the rows' sums meet in LDS, where the waves of a row group are combined anyway.
+  constexpr int NV = RR * PL * MT;
+  constexpr int HS = NV >= 16 ? 4 : 3;  // halving steps
+  constexpr int NKEEP = NV >> HS;                                       // values a lane is left with
+  float vals[NV];
 #pragma unroll
   for (int r = 0; r < RR; ++r)
 #pragma unroll
     for (int h = 0; h < PL; ++h)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[r][h][m] = wave_sum_lane63(acc[r][h][m]);
-  if (lane == 63) {
+      for (int m = 0; m < MT; ++m) vals[(r * PL + h) * MT + m] = acc[r][h][m];
+  auto halve = [&](auto step_tag, auto n_tag) {
+    constexpr int STEP = decltype(step_tag)::value, N = decltype(n_tag)::value, H = N / 2;
+    // the partner differs in bit STEP of the lane id and in nothing else: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_shl:4 (for the
+    // lanes whose bit is clear) / row_shr:4 (bit set), row_ror:8.  (row_half_mirror / row_mirror flip the lower bits as well: the
+    // partner would hold another half of the values.)
+    constexpr int CTRL_LO = STEP == 0 ? 0xB1 : (STEP == 1 ? 0x4E : (STEP == 2 ? 0x104 : 0x128));
+    constexpr int CTRL_HI = STEP == 0 ? 0xB1 : (STEP == 1 ? 0x4E : (STEP == 2 ? 0x114 : 0x128));
+    const bool up = (lane >> STEP) & 1;
 #pragma unroll
-    for (int r = 0; r < RR; ++r)
+    for (int i = 0; i < H; ++i) {
+      // both candidate sums (each one v_add_f32_dpp: the DPP source is a plain register), then the lane's pick
+      const float lo = vals[i] + dpp_f<CTRL_LO>(vals[i]), hi = vals[i + H] + dpp_f<CTRL_HI>(vals[i + H]);
+      vals[i] = up ? hi : lo;
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  static_assert(NV >= 8, "RR = 4 rows x at least 2 planes");
+  halve(I0{}, std::integral_constant<int, NV>{});
+  halve(I1{}, std::integral_constant<int, NV / 2>{});
+  halve(I2{}, std::integral_constant<int, NV / 4>{});
+  if constexpr (HS >= 4) halve(I3{}, std::integral_constant<int, NV / 8>{});
+  // lane l now holds, in vals[0 .. NKEEP), the sums over its HS-bit lane class of the values base(l) + i, base = sum_j bit_j(l) * (NV >> (j+1));
+  // NV = 8: bit 3 of the lane id is still to be summed - one all-reduce step with the lane that differs in that bit only
+  if constexpr (HS < 4) vals[0] += dpp_f<0x128>(vals[0]);
+  {
+    int base = 0;
 #pragma unroll
-      for (int h = 0; h < PL; ++h)
+    for (int j = 0; j < HS; ++j) base += ((lane >> j) & 1) * (NV >> (j + 1));
+    const bool writer = HS >= 4 || (lane & 15) < (1 << HS);  // one lane per class and row
+    if (writer) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) red[wave][r][h][m] = acc[r][h][m];
+      for (int i = 0; i < NKEEP; ++i) red[wave][lane >> 4][base + i] = vals[i];
+    }
   }
   __syncthreads();
-  static_assert(RR * PL * MT <= 64, "one lane per output of the block's row group");
-  if (slab0 == 0 && lane < RR * PL * MT) {
+  static_assert(NV <= 64, "one lane per output of the block's row group");
+  if (slab0 == 0 && lane < NV) {
     const int r = lane / (PL * MT), h = (lane / MT) % PL, m = lane % MT;
     const int p = p0 + r;
     if (p < P) {
       float v = 0.f;
-      for (int s = 0; s < wpr; ++s) v += red[wave + s][r][h][m];
+      for (int s = 0; s < wpr; ++s)
+#pragma unroll
+        for (int dr = 0; dr < 4; ++dr) v += red[wave + s][dr][lane];
       const int n = p + h * P;
       if (bias) v = E::to_f32(E::from_f32(v)) + E::to_f32(__builtin_bit_cast(T, bias[n]));
       y[(size_t)m * N + n] = __builtin_bit_cast(uint16_t, E::from_f32(v));
