@@ -99,7 +99,7 @@ struct GemvSegs {
 //          loads at the tail of the queue, no row can be processed before the wave's last weight byte has landed; at the
 //          head, row r is processed while rows r+1.. are still in flight.
 //   bit 1: non-temporal weight loads (each weight byte is read exactly once per call).
-template <int DT, int MT, int ITERS, bool INT_SHIFT, int VARIANT = 0, bool MULTI = false>
+template <int DT, int MT, int ITERS, bool INT_SHIFT, int VARIANT = 0, bool MULTI = false, int RRT = 4>
 __global__ void __launch_bounds__(256)
     qbits_gemv_g128_kernel(const uint16_t* __restrict__ x, const GemvSegs segs, int K,
                            int wpr_log2 /* log2 of the waves cooperating on one row group: 0, 1 or 2 */,
@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(256)
   using E = Elem<DT>;
   using T = typename E::T;
   using D2 = Dot2<DT>;
+  constexpr int RR = RRT;  // packed rows per wave pass: 4, or 8 for the long fused launches (r3, see the CLS flow below)
   // bit 4 (with bit 3): qint2 weights - four planes per byte (byte (p,k) = W[p,k] | W[p+N/4,k] << 2 | W[p+N/2,k] << 4 |
   // W[p+3N/4,k] << 6), 0x4300 | q is still exactly 128 + q: the same kernel with PL = 4 planes and a 2-bit mask
   constexpr bool INT2 = (VARIANT & 16) != 0;
@@ -148,7 +149,10 @@ __global__ void __launch_bounds__(256)
   int k0[ITERS];
   bool valid[ITERS];
   uint4 W[RR][ITERS];
-  float sq[ITERS][2], zq[ITERS][2];  // quad-shared fetch (int4, group size 128)
+  constexpr int KEEP = RR * PL / 8;  // (row, plane) pairs a lane class is left with after the group-local halving (CLS flow)
+  static_assert(RR * PL % 8 == 0, "the group-local halving leaves whole (row, plane) pairs");
+  const int cls = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
+  float sq[ITERS][KEEP], zq[ITERS][KEEP];  // CLS flow (int4, group size 128): scale / shift of this lane class's pairs
   uint4 xa[ITERS][MT], xb[ITERS][MT];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
@@ -195,18 +199,21 @@ __global__ void __launch_bounds__(256)
         }
       }
     } else {
-      // lane l fetches the entries of row (l & 3), group of its 16 bytes, both planes
-      const int rq = p0 + (lane & 3) < P ? p0 + (lane & 3) : P - 1;
+      // CLS flow (r3): the 8 lanes of a 128-byte group reduce their dot products among themselves BEFORE scale and shift are applied
+      // (halving over lane bits 0..2, section 2), after which lane class c = b0*4 + b1*2 + b2 is left with the sums of the (row, plane)
+      // pairs rp = c*KEEP + j: this lane fetches the entries of exactly those, for the group of its 16 bytes
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const size_t idx = (size_t)(rq + h * P) * G + (k0[it] >> 7);
-          sq[it][h] = E::to_f32(__builtin_bit_cast(T, scale[idx]));
+        for (int j = 0; j < KEEP; ++j) {
+          const int rp = cls * KEEP + j, r = rp / PL, h = rp % PL;
+          const int pr = p0 + r < P ? p0 + r : P - 1;
+          const size_t idx = (size_t)(pr + h * P) * G + (k0[it] >> 7);
+          sq[it][j] = E::to_f32(__builtin_bit_cast(T, scale[idx]));
           if constexpr (INT_SHIFT)
-            zq[it][h] = sq[it][h] * (float)(int8_t) reinterpret_cast<const uint8_t*>(shift_)[idx];
+            zq[it][j] = sq[it][j] * (float)(int8_t) reinterpret_cast<const uint8_t*>(shift_)[idx];
           else
-            zq[it][h] = E::to_f32(__builtin_bit_cast(T, reinterpret_cast<const uint16_t*>(shift_)[idx]));
+            zq[it][j] = E::to_f32(__builtin_bit_cast(T, reinterpret_cast<const uint16_t*>(shift_)[idx]));
         }
       }
     }
@@ -255,36 +262,49 @@ __global__ void __launch_bounds__(256)
   uint32_t kmask = INT2 ? 0x00030003u : 0x000F000Fu, kmagic = D2::MAGIC;
   asm volatile("" : "+s"(kmask));
   asm volatile("" : "+v"(kmagic));
-  float acc[RR][PL][MT];
+  // NV = RR * PL * MT partial sums per lane, value index (r * PL + h) * MT + m.  They are reduced TOGETHER (r3): reducing each of them
+  // over the 64 lanes on its own is 6 DPP steps per value (with hipcc's SLP vectorizer in the way: v_mov_b32_dpp + v_pk_add_f32 + the
+  // moves that build the pairs - ~160 of the 565 instructions of an M = 1 wave, in a kernel whose fused gate+up launch is VALU-bound:
+  // 14 waves per SIMD x ~450 VALU x 4.5 cycles = its 13.9 us).  Halving instead: at step j a lane keeps the half of its values
+  // selected by bit j of its lane id, adds its partner's copy of that half (the lane that differs in exactly that bit) and forgets the
+  // other half - NV/2 + NV/4 + ... value-steps instead of 6 NV.  After the (up to four) steps inside a 16-lane DPP row the rows' sums
+  // meet in LDS, where the waves of a row group are combined anyway.
+  constexpr int NV = RR * PL * MT;
+  static_assert(NV >= 8 && NV <= 64, "4 or 8 rows x at least 2 planes; one lane per output of the block's row group");
+  constexpr int HS = NV >= 16 ? 4 : 3;  // halving steps
+  constexpr int NKEEP = NV >> HS;       // values a lane is left with
+  auto halve = [&](float (&v)[NV], auto step_tag, auto n_tag) {
+    constexpr int STEP = decltype(step_tag)::value, N = decltype(n_tag)::value, H = N / 2;
+    // the partner differs in bit STEP of the lane id and in nothing else: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_shl:4 (for the
+    // lanes whose bit is clear) / row_shr:4 (bit set), row_ror:8.  (row_half_mirror / row_mirror flip the lower bits as well: the
+    // partner would hold another half of the values.)
+    constexpr int CTRL_LO = STEP == 0 ? 0xB1 : (STEP == 1 ? 0x4E : (STEP == 2 ? 0x104 : 0x128));
+    constexpr int CTRL_HI = STEP == 0 ? 0xB1 : (STEP == 1 ? 0x4E : (STEP == 2 ? 0x114 : 0x128));
+    const bool up = (lane >> STEP) & 1;
 #pragma unroll
-  for (int r = 0; r < RR; ++r)
+    for (int i = 0; i < H; ++i) {
+      // both candidate sums (each one v_add_f32_dpp: the DPP source is a plain register), then the lane's pick
+      const float lo = v[i] + dpp_f<CTRL_LO>(v[i]), hi = v[i + H] + dpp_f<CTRL_HI>(v[i + H]);
+      v[i] = up ? hi : lo;
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  auto halve_group = [&](float (&v)[NV]) {  // lane bits 0..2: the 8 lanes that hold one 128-byte group of a row
+    halve(v, I0{}, std::integral_constant<int, NV>{});
+    halve(v, I1{}, std::integral_constant<int, NV / 2>{});
+    halve(v, I2{}, std::integral_constant<int, NV / 4>{});
+  };
+
+  float vals[NV];  // GEN_GS: scaled sums of all values; CLS: [0, NV/8) scaled sums of this lane class's values (bits 0..2 already reduced)
 #pragma unroll
-    for (int h = 0; h < PL; ++h)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[r][h][m] = 0.f;
+  for (int v = 0; v < NV; ++v) vals[v] = 0.f;
 
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    float s_r[RR][PL], z_r[RR][PL];
-#pragma unroll
-    for (int h = 0; h < PL; ++h) {
-      if constexpr (GEN_GS) {
-#pragma unroll
-        for (int r = 0; r < RR; ++r) {
-          s_r[r][h] = sg[it][r][h];
-          z_r[r][h] = zg[it][r][h];
-        }
-      } else {
-        s_r[0][h] = quad_bcast<0>(sq[it][h]);
-        s_r[1][h] = quad_bcast<1>(sq[it][h]);
-        s_r[2][h] = quad_bcast<2>(sq[it][h]);
-        s_r[3][h] = quad_bcast<3>(sq[it][h]);
-        z_r[0][h] = quad_bcast<0>(zq[it][h]);
-        z_r[1][h] = quad_bcast<1>(zq[it][h]);
-        z_r[2][h] = quad_bcast<2>(zq[it][h]);
-        z_r[3][h] = quad_bcast<3>(zq[it][h]);
-      }
-    }
+    float dots[NV];
 #pragma unroll
     for (int r = 0; r < RR; ++r) {
       float dot[PL][MT];
@@ -317,54 +337,37 @@ __global__ void __launch_bounds__(256)
       for (int h = 0; h < PL; ++h)
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          // two FMAs whose first factor is the quad broadcast: hipcc folds each v_mov_b32_dpp into its v_fmac_f32_dpp
-          acc[r][h][m] = __builtin_fmaf(s_r[r][h], dot[h][m], acc[r][h][m]);
-          acc[r][h][m] = __builtin_fmaf(-z_r[r][h], xs[it][m], acc[r][h][m]);
+          const int v = (r * PL + h) * MT + m;
+          if constexpr (GEN_GS) {  // this lane's own scale / shift entries: scale first, reduce at the end
+            vals[v] = __builtin_fmaf(sg[it][r][h], dot[h][m], vals[v]);
+            vals[v] = __builtin_fmaf(-zg[it][r][h], xs[it][m], vals[v]);
+          } else {
+            dots[v] = dot[h][m];
+          }
         }
+    }
+    if constexpr (!GEN_GS) {
+      // CLS flow: the 8 lanes of the group add their dot products and their sums of x, then ONE scale / shift application per
+      // kept value instead of one per lane and value (and no fan-out of the scales through the quad)
+      halve_group(dots);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        float xg = xs[it][m];
+        xg += dpp_f<0xB1>(xg);
+        xg += dpp_f<0x4E>(xg);
+        xg += dpp_f<0x141>(xg);  // row_half_mirror: a lane of the other quad, which holds that quad's sum
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j) {
+          vals[j * MT + m] = __builtin_fmaf(sq[it][j], dots[j * MT + m], vals[j * MT + m]);
+          vals[j * MT + m] = __builtin_fmaf(-zq[it][j], xg, vals[j * MT + m]);
+        }
+      }
     }
   }
 
-  // ---- 3. reduce over lanes (DPP), over the wpr waves (LDS), store -----------------------------------
-  // r3: the NV = RR * PL * MT partial sums of a lane are reduced TOGETHER.  Reducing each of them over the 64 lanes on its own is
-  // 6 DPP steps per value (with hipcc's SLP vectorizer in the way: v_mov_b32_dpp + v_pk_add_f32 + the moves that build the pairs -
-  // ~160 of the 565 instructions of an M = 1 wave, in a kernel whose fused gate+up launch is VALU-bound: 14 waves per SIMD x ~450 VALU
-  // x 4.5 cycles = its 13.9 us).  Halving instead: at step j a lane keeps the half of its values selected by bit j of its lane id,
-  // adds its partner's copy of that half (the lane that differs in exactly that bit) and forgets the other half - NV/2 + NV/4 + ... value-steps instead of 6 NV.  After the (up to four) steps
-  // inside a 16-lane DPP row the rows' sums meet in LDS, where the waves of a row group are combined anyway.
-  constexpr int NV = RR * PL * MT;
-  constexpr int HS = NV >= 16 ? 4 : 3;  // halving steps
-  constexpr int NKEEP = NV >> HS;                                       // values a lane is left with
-  float vals[NV];
-#pragma unroll
-  for (int r = 0; r < RR; ++r)
-#pragma unroll
-    for (int h = 0; h < PL; ++h)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) vals[(r * PL + h) * MT + m] = acc[r][h][m];
-  auto halve = [&](auto step_tag, auto n_tag) {
-    constexpr int STEP = decltype(step_tag)::value, N = decltype(n_tag)::value, H = N / 2;
-    // the partner differs in bit STEP of the lane id and in nothing else: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_shl:4 (for the
-    // lanes whose bit is clear) / row_shr:4 (bit set), row_ror:8.  (row_half_mirror / row_mirror flip the lower bits as well: the
-    // partner would hold another half of the values.)
-    constexpr int CTRL_LO = STEP == 0 ? 0xB1 : (STEP == 1 ? 0x4E : (STEP == 2 ? 0x104 : 0x128));
-    constexpr int CTRL_HI = STEP == 0 ? 0xB1 : (STEP == 1 ? 0x4E : (STEP == 2 ? 0x114 : 0x128));
-    const bool up = (lane >> STEP) & 1;
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-      // both candidate sums (each one v_add_f32_dpp: the DPP source is a plain register), then the lane's pick
-      const float lo = vals[i] + dpp_f<CTRL_LO>(vals[i]), hi = vals[i + H] + dpp_f<CTRL_HI>(vals[i + H]);
-      vals[i] = up ? hi : lo;
-    }
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  using I3 = std::integral_constant<int, 3>;
-  static_assert(NV >= 8, "RR = 4 rows x at least 2 planes");
-  halve(I0{}, std::integral_constant<int, NV>{});
-  halve(I1{}, std::integral_constant<int, NV / 2>{});
-  halve(I2{}, std::integral_constant<int, NV / 4>{});
-  if constexpr (HS >= 4) halve(I3{}, std::integral_constant<int, NV / 8>{});
+  // ---- 3. finish the reduction over lanes (DPP), over the wpr waves (LDS), store -----------------------------------
+  if constexpr (GEN_GS) halve_group(vals);
+  if constexpr (HS >= 4) halve(vals, I3{}, std::integral_constant<int, NV / 8>{});
   // lane l now holds, in vals[0 .. NKEEP), the sums over its HS-bit lane class of the values base(l) + i, base = sum_j bit_j(l) * (NV >> (j+1));
   // NV = 8: bit 3 of the lane id is still to be summed - one all-reduce step with the lane that differs in that bit only
   if constexpr (HS < 4) vals[0] += dpp_f<0x128>(vals[0]);
@@ -423,7 +426,13 @@ static int gemv_launch_iters(const void* x, const GemvProblem& pb, int m0, int K
   const int wpr_log2 = wpr == 4 ? 2 : wpr - 1;
   const int iters = (nslab + wpr - 1) / wpr;
   if (iters > 4) return QUANTO_HIP_ENOTSUP;
-  const int rows_per_block = RR * (4 / wpr);
+  // packed rows per wave pass.  8 rows cut the instructions per weight byte by a quarter (612 per 8 KiB wave against 387 per 4 KiB:
+  // x slice, addresses and reduction tail are per wave) but halve the waves, and a wave is one batch of loads followed by its
+  // arithmetic: r3 A/B, us with 4 / 8 rows: north-star 4.06 / 4.00, cfg3 6.48 / 6.45, q/k/v in one launch 4.99 / 5.91, gate+up in one
+  // launch 12.0 / 12.9.  4 rows stay the product form; 8 is kept behind QUANTO_HIP_GEMV_RR=8 (parity-tested, same bits).
+  const bool rr8_ok = pb.gs == 128 && pb.bits == 4 && MT <= 2 && iters == 1;
+  const int rr = rr8_ok && env_int("QUANTO_HIP_GEMV_RR", 0) == 8 ? 8 : RR;
+  const int rows_per_block = rr * (4 / wpr);
   GemvSegs segs;
   int grid = 0;
   for (int i = 0; i < MAX_SEGS; ++i) {
@@ -440,8 +449,18 @@ static int gemv_launch_iters(const void* x, const GemvProblem& pb, int m0, int K
   auto xs = reinterpret_cast<const uint16_t*>(x) + (size_t)m0 * K;
   // group -> shift: 32 -> 5, 64 -> 6, 128 -> 7, per-channel -> 30 (always group 0), 96 -> -1 ((k >> 5) / 3)
   const int gshift = pb.gs == 0 ? 30 : pb.gs == 96 ? -1 : pb.gs == 32 ? 5 : pb.gs == 64 ? 6 : 7;
-#define QH_LAUNCH_VM(IT, V, MULTI) \
-  hipLaunchKernelGGL((qbits_gemv_g128_kernel<DT, MT, IT, INT_SHIFT, V, MULTI>), dim3(grid), dim3(256), 0, stream, xs, segs, K, wpr_log2, gshift)
+#define QH_LAUNCH_VM(IT, V, MULTI)                                                                                                     \
+  do {                                                                                                                                \
+    if constexpr (MT <= 2 && IT == 1 && ((V) == 0 || (V) == 2)) {                                                                     \
+      if (rr == 8) {                                                                                                                  \
+        hipLaunchKernelGGL((qbits_gemv_g128_kernel<DT, MT, IT, INT_SHIFT, V, MULTI, 8>), dim3(grid), dim3(256), 0, stream, xs, segs, K, \
+                           wpr_log2, gshift);                                                                                         \
+        break;                                                                                                                        \
+      }                                                                                                                               \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL((qbits_gemv_g128_kernel<DT, MT, IT, INT_SHIFT, V, MULTI>), dim3(grid), dim3(256), 0, stream, xs, segs, K,        \
+                       wpr_log2, gshift);                                                                                             \
+  } while (0)
 #define QH_LAUNCH_V(IT, V)                    \
   do {                                        \
     if constexpr (MT <= 4) {                  \

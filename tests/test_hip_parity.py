@@ -116,6 +116,21 @@ def test_qbits_gemv(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M", [1, 2])
+@pytest.mark.parametrize("N,K,zp", [(256, 1024, False), (512, 4096, True), (34, 2048, False), (11008, 4096, False), (96, 3072, True)])
+def test_qbits_gemv_eight_rows_per_wave(dt, M, N, K, zp, monkeypatch):
+    """The long fused decode launches give a wave 8 packed rows per pass (r3); forced here on small and ragged shapes: exact-math gate,
+    and the same bits as the 4-row form (both reduce a value over the same lane pairs in the same order)."""
+    p = make_qbits_problem(M, N, K, dt, zeropoint=zp, seed=N + K + M)
+    monkeypatch.setenv("QUANTO_HIP_GEMV_RR", "4")
+    y4 = _run_qbits(p, "gemv")
+    monkeypatch.setenv("QUANTO_HIP_GEMV_RR", "8")
+    y8 = _run_qbits(p, "gemv")
+    assert_close_to_exact(y8, _exact_qbits(p), dt, f"gemv, 8 rows per wave, {M}x{K}x{N}")
+    np.testing.assert_array_equal(y8, y4)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_qbits_gemv_zeropoint_and_bias(dt):
     p = make_qbits_problem(3, 256, 1024, dt, zeropoint=True, seed=11)
     bias = O.round_to(np.random.default_rng(1).standard_normal(256).astype(np.float32), dt)
