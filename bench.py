@@ -90,6 +90,7 @@ WORKLOADS = {
     "int4_decode8_70b": ("qbits_i4", 8, 8192, 8192, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(8,8192,8192)"),
     "int4_decode64": ("qbits_i4", 64, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(64,4096,4096)"),
     "int8_decode32": ("qbytes_i8", 32, 4096, 4096, "bf16 x int8 qbytes_mm, per-channel scale, batched decode (M,K,N)=(32,4096,4096)"),
+    "int4_decode1_down": ("qbits_i4", 1, 14336, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, decode (M,K,N)=(1,14336,4096) (Llama-3-8B down_proj)"),
     "int4_decode32_up": ("qbits_i4", 32, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,14336)"),
 }
 DEFAULT_SUB = ["northstar", "cfg3", "cfg4", "qkv_fused", "gateup_fused", "int4_decode32", "qkv_fused32", "int8_gateup_fused", "int4_prefill512"]

@@ -61,8 +61,10 @@ typedef enum {
   QUANTO_HIP_KERNEL_MFMA_LARGE = 4, /* 256x256 tile, LDS-DMA pipeline (prefill-sized M and N)    */
   QUANTO_HIP_KERNEL_SKINNY = 5, /* qbits_mm: weight-streaming MFMA kernel for M <= QUANTO_HIP_SKINNY_MAX_M */
   QUANTO_HIP_KERNEL_NATIVE8 = 6, /* qbytes_mm with quantized activations: int8 x int8 (i32 MFMA) / fp8 x fp8 (fp8 MFMA) */
-  QUANTO_HIP_KERNEL_DEQUANT_MFMA = 7, /* qbits_mm, large M: fused dequantize into the workspace + 256x256 dense MFMA GEMM */
-  QUANTO_HIP_KERNEL_MFMA_FUSED4 = 8,  /* qbits_mm, prefill-sized M: packed int4 -> MFMA operands in registers, per-group fp32 fold */
+  QUANTO_HIP_KERNEL_DEQUANT_MFMA = 7, /* qbits_mm, M beyond ~1-1.5 k rows (and formats the fused kernels do not take): fused dequantize into the
+                                       * workspace + dense MFMA GEMM - multiplies the weight rounded to the activation dtype, as the reference does */
+  QUANTO_HIP_KERNEL_MFMA_FUSED4 = 8,  /* qbits_mm, 64 < M <= ~1-1.5 k (AUTO: its own time model): packed int4 -> MFMA operands in registers,
+                                       * per-group fp32 fold, no dequantized weight; workspace only when K is split (plan / workspace_size say so) */
   QUANTO_HIP_KERNEL_MMV = 9           /* qbits_mm, 4 < M <= 16 (AUTO; the kernel itself accepts up to 32 rows): register-streaming MFMA kernel, K split over the waves of a block (no workspace) */
 } quanto_hip_kernel;
 
