@@ -51,9 +51,11 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     # above the streaming kernel's range, while one round of 128 x 128 tiles covers the problem: the fused int4 GEMM - no scratch when
     # the scale table of all groups fits the LDS, split-K scratch (counter region + fp32 partial tiles of 512 lanes x 128 B) otherwise
     assert lib.quanto_hip_qbits_mm_workspace_size(1024, 4096, 4096, 4, 128, 2, 0) == 0
-    assert lib.quanto_hip_qbits_mm_workspace_size(300, 256, 4096, 4, 128, 2, 0) == 0
-    # K = 14336: the scale table of 112 groups does not fit -> K split (here 4 ways: 64 tiles), counter region + fp32 partial tiles
-    assert lib.quanto_hip_qbits_mm_workspace_size(256, 4096, 14336, 4, 128, 2, 0) == 4096 + 64 * 4 * 512 * 128
+    # few tiles (5 x 2 of 64 tokens): K split 8 ways, counter region + fp32 partial tiles of 512 lanes x 64 B
+    assert lib.quanto_hip_qbits_mm_workspace_size(300, 256, 4096, 4, 128, 2, 0) == 4096 + 10 * 8 * 512 * 64
+    assert lib.quanto_hip_qbits_mm_workspace_size(128, 4096, 4096, 4, 128, 2, 0) == 4096 + 64 * 2 * 512 * 64
+    # K = 14336: the scale table of 112 groups does not fit -> K split (here 2 ways: 128 tiles of 64 tokens), counter region + fp32 partial tiles
+    assert lib.quanto_hip_qbits_mm_workspace_size(256, 4096, 14336, 4, 128, 2, 0) == 4096 + 128 * 2 * 512 * 64
     assert lib.quanto_hip_qbits_mm_pick(300, 256, 4096, 4, 128, 2) == 8
     assert lib.quanto_hip_qbits_mm_workspace_size(300, 256, 4096, 4, 128, 2, 7) == 256 * 4096 * 2  # DEQUANT_MFMA: the dequantized weight
     assert lib.quanto_hip_qbits_mm_workspace_size(40, 256, 512, 4, 64, 2, 0) == 8 * 128 * 4  # group size 64, small M: 128x128 kernel (row sums of x)
@@ -65,10 +67,9 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     lib.quanto_hip_qbits_mm_pick.restype = ctypes.c_int
     lib.quanto_hip_qbits_mm_pick.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 3
     assert lib.quanto_hip_qbits_mm_pick(64, 4096, 4096, 4, 128, 2) == 5 and lib.quanto_hip_qbits_mm_pick(1, 4096, 4096, 4, 128, 2) == 2
-    # streaming kernel up to 192 rows (256 for long K, where one dequantize pass costs more than its extra passes), flat path above
-    # streaming kernel up to 192 rows, fused int4 GEMM while one round of tiles covers the problem, dequantize + dense GEMM beyond
-    assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 4, 128, 2) for m in (192, 256, 1024, 2048)] == [5, 8, 8, 7]
-    assert lib.quanto_hip_qbits_mm_pick(256, 4096, 14336, 4, 128, 2) == 8  # K = 14336: fused with K split 4 ways (28 groups' scale table per workgroup)
+    # streaming kernel up to 64 rows, fused int4 GEMM while its modelled time stays within 1.2 rounds of 128-token tiles, dequantize + dense GEMM beyond
+    assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 4, 128, 2) for m in (64, 65, 192, 256, 1024, 2048)] == [5, 8, 8, 8, 8, 7]
+    assert lib.quanto_hip_qbits_mm_pick(256, 4096, 14336, 4, 128, 2) == 8  # K = 14336: fused with K split 2 ways (56 groups' scale table per workgroup)
     # small decode batches: the register-streaming kernel where one block per CU covers N, the LDS-streaming one elsewhere
     assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 4, 128, 2) for m in (4, 5, 16, 17)] == [2, 9, 9, 5]
     assert [lib.quanto_hip_qbits_mm_pick(8, n, k, 4, 128, 2) for n, k in ((1024, 4096), (14336, 4096), (4096, 14336), (5120, 5120))] == [9, 5, 5, 5]
