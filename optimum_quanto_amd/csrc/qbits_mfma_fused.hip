@@ -91,7 +91,7 @@ struct Args {
   int M, N, K, G;
   int S;               // K split: blockIdx.z handles groups [z * G / S, (z + 1) * G / S)
   int* counters;       // [tiles] arrival counters, zero on entry and on exit (S > 1)
-  float* partials;     // [tiles][S][512 lanes][MI] float4
+  float* partials;     // [tiles][S][MI][512 lanes] float4: every store / load instruction of a wave covers 1 KiB of whole lines
   // QUANTO_HIP_FUSED4_ABLATE (timing experiments, WRONG results): 1 at most two tiles of the K loop, 2 no output stores, 4 no table fill
   // (r3 also tried 8 = no DMA inside the K loop and 16 = no MFMA steps: (512,4096,4096) 38.8 -> 36.4 / 16.7 us - the step loop, not
   // the DMA, is what a tile waits for; those two knobs changed the code of the loop they were meant to measure and were removed)
@@ -388,10 +388,12 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
   // ---- split-K: fp32 partial tiles through the workspace, the last workgroup of a tile adds them in split order (qbits_skinny.hip) ----
   if (S > 1) {
     const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
-    float* mine = a.partials + ((size_t)(tile_id * S + sp) * (WAVES * 64) + tid) * (MI * 4);
+    // fragment-major: lane-major (64 B per lane) made every store instruction write a quarter of each line it touched, and partial
+    // lines are what the write-through path is slow at
+    float* mine = a.partials + ((size_t)(tile_id * S + sp) * MI * (WAVES * 64) + tid) * 4;
 #pragma unroll
     for (int i = 0; i < MI; ++i)  // s_nop: gfx9 hazard "VMEM store of > 64 bits, then VALU write of its data VGPRs"
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + i * 4), "v"(acc[i]) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + i * (WAVES * 64 * 4)), "v"(acc[i]) : "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem);
@@ -410,9 +412,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
 #pragma unroll
       for (int j = 0; j < QB; ++j) {
         const int q = q0 + j < S ? q0 + j : S - 1;
-        const float* theirs = a.partials + ((size_t)(tile_id * S + q) * (WAVES * 64) + tid) * (MI * 4);
+        const float* theirs = a.partials + ((size_t)(tile_id * S + q) * MI * (WAVES * 64) + tid) * 4;
 #pragma unroll
-        for (int e = 0; e < MI; ++e) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[j][e]) : "v"(theirs + e * 4) : "memory");
+        for (int e = 0; e < MI; ++e) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[j][e]) : "v"(theirs + e * (WAVES * 64 * 4)) : "memory");
       }
 #pragma unroll
       for (int j = 0; j < QB; ++j)
@@ -467,12 +469,13 @@ inline int tiles_of(int64_t M, int64_t N, int bm) { return (int)(((N / 2 + PR - 
 
 // Token tile and K split, chosen together from a small time model fitted to r3's sweeps (profiles/r03_fused_int4_gemm.md; us):
 //   t = 5.8 + rounds * groups_per_workgroup * t_tile + tail,   rounds = ceil(workgroups / 256 CUs),
-//   t_tile = 0.68 (64-token tiles) / 1.2 (128-token tiles),     tail = 4 + 1.2 per MB of fp32 partial tiles when K is split.
+//   t_tile = 0.68 (64-token tiles) / 1.2 (128-token tiles),     tail = 3.5 + 0.5 per MB of fp32 partial tiles when K is split
+//   (1.2 per MB until the partial tiles were laid out fragment-major: whole lines per write-through store instruction).
 // 128 tokens per workgroup halve the activation bytes per weight byte, but a short prefill then leaves CUs idle ((512,4096,4096) is
 // 128 tiles of 128 tokens on 256 CUs: 46.7 us against 28.5 with 64-token tiles); a split costs its tail (a 32 / 64 KiB partial tile
 // per workgroup through the fabric and back, arrival counter, one more round trip for the last workgroup), so it pays for few
-// tiles or long K only: (128,4096,4096) 27.5 / 24.4 / 23.4 us with 1 / 2 / 4 splits, (128,14336,4096) 82 / 52 / 41, but
-// (256,4096,4096) 27.7 / 28.1.  The scale tables of a workgroup's groups must fit the LDS next to the ring (K = 14336 with 128-token
+// tiles or long K only: (128,4096,4096) 27.6 / 20.0 / 16.2 / 17.9 us with 1 / 2 / 4 / 8 splits, (128,14336,4096) 83 / 48 / 34 / 34,
+// (256,4096,4096) 27.9 / 21.5 / 20.8 / 28.7, but (512,4096,4096) 29.4 / 36.1.  The scale tables of a workgroup's groups must fit the LDS next to the ring (K = 14336 with 128-token
 // tiles needs a split for that alone).
 struct Plan {
   int bm, S;
@@ -480,13 +483,13 @@ struct Plan {
 };
 inline float model_us(int tiles, int nk, int bm, int S) {
   const int wgs = tiles * S, rounds = (wgs + 255) / 256;
-  const float tail = S > 1 ? 4.f + 1.2f * (float)wgs * (float)(bm * 512) * 1e-6f : 0.f;
+  const float tail = S > 1 ? 3.5f + 0.5f * (float)wgs * (float)(bm * 512) * 1e-6f : 0.f;
   return 5.8f + (float)rounds * (float)nk * (bm == 64 ? 0.68f : 1.2f) + tail;
 }
 inline Plan make_plan(int64_t M, int64_t N, int G) {
   const int fbm = env_int("QUANTO_HIP_FUSED4_BM", 0), fs = env_int("QUANTO_HIP_FUSED4_SPLIT", 0);  // experiments / tests
   Plan best{0, 0, 0.f};
-  for (int bm = 128; bm >= 64; bm -= 64) {
+  for (int bm = 64; bm <= 128; bm += 64) {
     if ((fbm == 64 || fbm == 128) && bm != fbm) continue;
     const int tiles = tiles_of(M, N, bm);
     for (int S = 1; S <= 8; S *= 2) {
@@ -496,7 +499,7 @@ inline Plan make_plan(int64_t M, int64_t N, int G) {
       if (lds_bytes(nk, bm) > 160 * 1024) continue;
       if (S > 1 && (size_t)tiles * 4 > QUANTO_HIP_WS_COUNTER_BYTES) continue;
       const float us = model_us(tiles, nk, bm, S);
-      if (best.bm == 0 || us < best.us * 0.97f) best = Plan{bm, S, us};  // ties: fewer splits, the larger tile
+      if (best.bm == 0 || us < best.us * 0.97f) best = Plan{bm, S, us};  // ties: the smaller tile, fewer splits
     }
   }
   return best;  // bm == 0: no configuration fits (a forced split that does not divide the groups, tables that never fit)

@@ -102,7 +102,7 @@ struct Args {
   // of a feature block to arrive (atomic counter, zero on entry, reset to zero on exit) adds them up in split order and stores
   int S;
   int* counters;    // [N / (16*WAVES)]
-  float* partials;  // [blocks][WAVES*64 lanes][TF] float4
+  float* partials;  // [blocks][TF][WAVES*64 lanes] float4 (fragment-major: every store / load instruction covers whole lines)
   int nt;           // non-temporal weight DMA (single-pass calls: M <= 64)
   // QUANTO_HIP_SKINNY_ABLATE (timing experiments, WRONG results): 1 no split-K reduction, 2 no MFMA/LDS-read work,
   // 4 no activation DMA, 8 no weight DMA, 16 no scale/shift table
@@ -407,10 +407,10 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   if (S > 1 && (a.ablate & 1)) {
     if (sp != 0) return;
   } else if (S > 1) {
-    float* mine = a.partials + ((size_t)blockIdx.x * (WAVES * 64) + tid) * (TF * 4);
+    float* mine = a.partials + ((size_t)blockIdx.x * TF * (WAVES * 64) + tid) * 4;
 #pragma unroll
     for (int tf = 0; tf < TF; ++tf)  // s_nop: gfx9 hazard "VMEM store of > 64 bits, then VALU write of its data VGPRs" - hipcc cannot see into the asm
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + tf * 4), "v"(acc[tf]) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + tf * (WAVES * 64 * 4)), "v"(acc[tf]) : "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     probe(21);
     __syncthreads();
@@ -429,9 +429,9 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int q = q0 + j < S ? q0 + j : S - 1;
-        const float* theirs = a.partials + ((size_t)(fbg * S + q) * (WAVES * 64) + tid) * (TF * 4);
+        const float* theirs = a.partials + ((size_t)(fbg * S + q) * TF * (WAVES * 64) + tid) * 4;
 #pragma unroll
-        for (int tf = 0; tf < TF; ++tf) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[j][tf]) : "v"(theirs + tf * 4) : "memory");
+        for (int tf = 0; tf < TF; ++tf) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[j][tf]) : "v"(theirs + tf * (WAVES * 64 * 4)) : "memory");
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)

@@ -273,10 +273,10 @@ __global__ void __launch_bounds__(256) qbytes_skinny_kernel(Args a, const Segs s
 
   // ---- split-K reduction (see qbits_skinny.hip for the coherence argument) -----------------------------------------------------
   if (S > 1) {
-    float* mine = a.partials + ((size_t)blockIdx.x * 256 + tid) * (TF * 4);
+    float* mine = a.partials + ((size_t)blockIdx.x * TF * 256 + tid) * 4;  // fragment-major: whole lines per store instruction
 #pragma unroll
     for (int tf = 0; tf < TF; ++tf)
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + tf * 4), "v"(acc[tf]) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + tf * (256 * 4)), "v"(acc[tf]) : "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem);
@@ -287,10 +287,10 @@ __global__ void __launch_bounds__(256) qbytes_skinny_kernel(Args a, const Segs s
 #pragma unroll
     for (int tf = 0; tf < TF; ++tf) acc[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int q = 0; q < S; ++q) {
-      const float* theirs = a.partials + ((size_t)(fbg * S + q) * 256 + tid) * (TF * 4);
+      const float* theirs = a.partials + ((size_t)(fbg * S + q) * TF * 256 + tid) * 4;
       f32x4 v[TF];
 #pragma unroll
-      for (int tf = 0; tf < TF; ++tf) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[tf]) : "v"(theirs + tf * 4) : "memory");
+      for (int tf = 0; tf < TF; ++tf) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[tf]) : "v"(theirs + tf * (256 * 4)) : "memory");
 #pragma unroll
       for (int tf = 0; tf < TF; ++tf) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[tf])::"memory");
 #pragma unroll

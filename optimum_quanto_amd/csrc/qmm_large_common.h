@@ -92,7 +92,7 @@ struct Args {
   // workgroup of a tile to arrive adds them in split order (same protocol and workspace contract as qbits_skinny.hip)
   int S;
   int* counters;    // [tiles], zero on entry, zero on exit
-  float* partials;  // [tiles * S][threads][NJ * MI] float4
+  float* partials;  // [tiles * S][NJ * MI][threads] float4
 };
 
 // XCD-aware tile order.  Consecutive workgroup ids land on different XCDs (id % 8), so first give every XCD a contiguous

@@ -406,12 +406,14 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   if (S > 1) {
     // split-K reduction: system-coherent 16-byte stores / loads of the partial sums (no L2-wide fence), one arrival counter
     // per tile, the last workgroup to arrive sums in split order - see qbits_skinny.hip for the coherence argument
-    float* mine = a.partials + ((size_t)blockIdx.x * (NWAVES * 64) + tid) * (NJ * MI * 4);
+    // fragment-major layout: every store / load instruction of a wave covers 1 KiB of whole lines (lane-major - NJ*MI*16 bytes per lane -
+    // wrote 16 bytes into every second line per instruction, and partial lines are what the write-through path is slow at)
+    float* mine = a.partials + ((size_t)blockIdx.x * (NJ * MI) * (NWAVES * 64) + tid) * 4;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int i = 0; i < MI; ++i)
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + (j * MI + i) * 4), "v"(acc[j][i]) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + (j * MI + i) * (NWAVES * 64 * 4)), "v"(acc[j][i]) : "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem);
@@ -425,12 +427,12 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
 #pragma unroll
       for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int q = 0; q < S; ++q) {
-      const float* theirs = a.partials + ((size_t)(tile_id * S + q) * (NWAVES * 64) + tid) * (NJ * MI * 4);
+      const float* theirs = a.partials + ((size_t)(tile_id * S + q) * (NJ * MI) * (NWAVES * 64) + tid) * 4;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         f32x4 v[MI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[i]) : "v"(theirs + (j * MI + i) * 4) : "memory");
+        for (int i = 0; i < MI; ++i) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[i]) : "v"(theirs + (j * MI + i) * (NWAVES * 64 * 4)) : "memory");
 #pragma unroll
         for (int i = 0; i < MI; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[i])::"memory");
 #pragma unroll
@@ -557,15 +559,19 @@ bool qbytes_mfma_large_supported(int64_t M, int64_t N, int64_t K, int a_dtype, i
          K >= 2 * lt::BK && M >= 1 && M * K < (1ll << 30) && N * K < (1ll << 31) && M < (1 << 30) && N < (1 << 30);
 }
 
-// split-K for the 128-tile configuration, only when its tiles cover at most half of the CUs and K is very long: the partial
-// sums cost 64 KiB of system-coherent traffic per workgroup each way, ~12 us in all.  Measured with the weights-direct
-// loop (bf16 x int8, M = 512, N = 4096, split 1 -> 2): K = 4096 30 -> 42 us, K = 8192 55 -> 57 us, K = 14336 91 -> 80 us;
-// cfg4 (512, 8192, 8192; 256 tiles) 65 -> 100 us.
+// split-K for the 128-tile configuration when its tiles cover at most half of the CUs.  The partial sums cost 64 KiB of
+// system-coherent traffic per workgroup each way.  r3, with the partial tiles laid out fragment-major (whole lines per store
+// instruction; lane-major wrote 16 bytes into every second line and made a split cost ~12 us + 1 us per MB), bf16 x int8, us with
+// split 1 / 2 / 4: (128,4096,4096) 27.2 / 21.7 / 20.4, (256,4096,4096) 27.5 / 21.9 / 22.9, (512,4096,4096) 28.1 / 25.6 / 34.8,
+// (256,8192,8192) 49.8 / 38.5 / 46.7, (512,4096,14336) 85.2 / 59.0 / 67.6; with more tiles than half the CUs it loses:
+// (1024,4096,4096) 32.3 / 43.3, cfg4 (512,8192,8192; 256 tiles) 55.7 / 63.7 (r2 layout: 65 / 100).
 static int large_split(int64_t M, int64_t N, int64_t K) {
   const int forced = env_int("QUANTO_HIP_LARGE_SPLIT", 0);  // experiments
   const int64_t tiles256 = ((M + 255) / 256) * ((N + 255) / 256), tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
   int s = 1;
-  if (tiles128 <= 128 && K >= 10240 && (K / lt::BK) % 2 == 0) s = 2;
+  // halves (quarters for a single row of tiles) of a whole number of 4-tile ring turns (weights-direct loop)
+  if (tiles128 <= 128 && (K / lt::BK) % 8 == 0 && K / lt::BK >= 16) s = 2;
+  if (tiles128 <= 32 && (K / lt::BK) % 16 == 0 && K / lt::BK >= 32) s = 4;
   if (forced > 0 && tiles128 <= 512 && (K / lt::BK) % forced == 0 && K / lt::BK / forced >= 2) s = forced;
   (void)tiles256;
   if ((size_t)tiles128 * 4 > QUANTO_HIP_WS_COUNTER_BYTES) s = 1;  // one counter per 128-tile

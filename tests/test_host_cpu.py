@@ -53,8 +53,8 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.quanto_hip_qbits_mm_workspace_size(1024, 4096, 4096, 4, 128, 2, 0) == 0
     # few tiles (5 x 2 of 64 tokens): K split 8 ways, counter region + fp32 partial tiles of 512 lanes x 64 B
     assert lib.quanto_hip_qbits_mm_workspace_size(300, 256, 4096, 4, 128, 2, 0) == 4096 + 10 * 8 * 512 * 64
-    assert lib.quanto_hip_qbits_mm_workspace_size(128, 4096, 4096, 4, 128, 2, 0) == 4096 + 64 * 2 * 512 * 64
-    # K = 14336: the scale table of 112 groups does not fit -> K split (here 2 ways: 128 tiles of 64 tokens), counter region + fp32 partial tiles
+    assert lib.quanto_hip_qbits_mm_workspace_size(128, 4096, 4096, 4, 128, 2, 0) == 4096 + 64 * 4 * 512 * 64
+    # K = 14336: split 2 ways (128 tiles of 64 tokens), counter region + fp32 partial tiles
     assert lib.quanto_hip_qbits_mm_workspace_size(256, 4096, 14336, 4, 128, 2, 0) == 4096 + 128 * 2 * 512 * 64
     assert lib.quanto_hip_qbits_mm_pick(300, 256, 4096, 4, 128, 2) == 8
     assert lib.quanto_hip_qbits_mm_workspace_size(300, 256, 4096, 4, 128, 2, 7) == 256 * 4096 * 2  # DEQUANT_MFMA: the dequantized weight
@@ -108,8 +108,10 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert picks == {1: 2, 8: 5, 64: 5, 256: 4, 4096: 4}, picks                                  # gemv, skinny, skinny, large, large
     # one 128-row tile band beats the streaming kernel's passes of 64 rows from ~100 rows on, even on a handful of tiles
     assert [lib.quanto_hip_qbytes_mm_pick(m, 1024, 4096, 2, 3, 2) for m in (96, 128)] == [5, 4]
-    # split-K of the 128-tile grid only for very long K; (512, 4096, 4096) runs unsplit without workspace
-    assert lib.quanto_hip_qbytes_mm_workspace_size(512, 4096, 4096, 2, 3, 2, 0) == 0
+    # split-K of the 128-tile grid while its tiles cover at most half of the CUs: 2 ways, 4 ways for a single row of tiles
+    assert lib.quanto_hip_qbytes_mm_workspace_size(512, 4096, 4096, 2, 3, 2, 0) == 4096 + 128 * 2 * 128 * 128 * 4
+    assert lib.quanto_hip_qbytes_mm_workspace_size(128, 4096, 4096, 2, 3, 2, 0) == 4096 + 32 * 4 * 128 * 128 * 4
+    assert lib.quanto_hip_qbytes_mm_workspace_size(1024, 4096, 4096, 2, 3, 2, 0) == 0  # 256 tiles: every CU has one
     assert lib.quanto_hip_qbytes_mm_workspace_size(512, 4096, 14336, 2, 3, 2, 0) == 4096 + 128 * 2 * 128 * 128 * 4  # fixed counter region + fp32 partials
     assert lib.quanto_hip_qbytes_mm_pick(4096, 4096, 4096, 3, 3, 2) == 6                         # int8 activations: native8
 
