@@ -49,14 +49,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // LDS-DMA, 16 bytes per lane: wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset
 __device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-  uint32_t keep;
+  // M0 is written and not restored (qmm_large_common.h: nothing else in this kernel needs it; 2 SALU instructions per piece)
   asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %3\n\t"
+      "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
+      "global_load_lds_dwordx4 %0, %1"
+      :
       : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");
 }

@@ -30,28 +30,22 @@ constexpr int BK = 128;  // byte-columns (= k) per tile = one group
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
+  asm volatile(  // M0 is written and not restored (qmm_large_common.h: nothing else in this kernel needs it)
+      "s_mov_b32 m0, %1\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
+      "global_load_lds_dwordx4 %0, off"
+      :
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
 // non-temporal flavour for the weight stream: every weight byte is read once per pass (MI355X_MICROARCH.md "nt-weights":
 // issued -> landed 18 % sooner on one-shot streams)
 __device__ __forceinline__ void glds16_nt(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
+  asm volatile(  // M0 is written and not restored (qmm_large_common.h: nothing else in this kernel needs it)
+      "s_mov_b32 m0, %1\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off nt\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
+      "global_load_lds_dwordx4 %0, off nt"
+      :
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
