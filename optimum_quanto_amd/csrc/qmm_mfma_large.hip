@@ -543,7 +543,10 @@ static int launch(const Args& a, int cfg, hipStream_t stream) {
     if ((wd & 1) && (tiles * a.S <= 256 || (wd & 4)) && nk % 4 == 0 && nk >= 8) return launch_cfg<DT, FMT, 128, 128, 1, 4, 4>(a, stream);
     return launch_cfg<DT, FMT, 128, 128, 1, 4>(a, stream);
   }
-  // (tried: 128-tiles as eight waves of 128 x 16 with one workgroup per CU - LDS-bound, cfg4 90-98 us vs 86-90 us)
+  // (tried: 128-tiles as eight waves of 128 x 16 with one workgroup per CU - LDS-bound, cfg4 90-98 us vs 86-90 us;
+  //  r3: 128 tokens x 256 features as eight weights-direct waves of 128 x 32 - a third fewer fetched bytes per flop - with K split 2 ways
+  //  so that cfg4 still covers 256 CUs: 68.2 us against 59.7 on the same box (unsplit on 128 CUs 86 us: 64 % MFMA utilisation instead
+  //  of 50 %, but the partial-tile pass of 32 MB costs more than the better loop gains))
   if (cfg == CFG_256_4W) return launch_cfg<DT, FMT, 256, 256, 2, 2>(a, stream);
   if (cfg == CFG_256_1X8) return launch_cfg<DT, FMT, 256, 256, 1, 8>(a, stream);
   return launch_cfg<DT, FMT, 256, 256, 2, 4>(a, stream);
