@@ -97,6 +97,8 @@ struct Args {
   int S;
   int* counters;    // [N / (16*WAVES)]
   float* partials;  // [blocks][TF][WAVES*64 lanes] float4 (fragment-major: every store / load instruction covers whole lines)
+  // groups per 128-k tile: 1 (group size 128), 2 (64), 4 (32); per_channel: ONE scale / shift per feature (G = 1), the tables repeat it
+  int gpt, per_channel;
   int nt;           // non-temporal weight DMA (single-pass calls: M <= 64)
   // QUANTO_HIP_SKINNY_ABLATE (timing experiments, WRONG results): 1 no split-K reduction, 2 no MFMA/LDS-read work,
   // 4 no activation DMA, 8 no weight DMA, 16 no scale/shift table
@@ -127,7 +129,9 @@ struct Segs {
 // s_barrier) 59 % of their cycles, with nobody on the SIMD to use them.  The sets' sums are added through LDS at the end
 // (set 0 + set 1: fixed order) and set 0 runs the split-K tail.  DMA: per pair of tiles one weight piece + TF activation pieces
 // per wave.
-template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI = false, int SETS = 1>
+// GPT: quantization groups per 128-k tile - 1 (group size 128 and per-channel scales), 2 (64), 4 (32); the small group sizes are
+// instantiated for 64-feature blocks and the 4-stage ring only.
+template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI = false, int SETS = 1, int GPT = 1>
 __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a, const Segs segs) {
   static_assert(SETS == 1 || WAVES == 4, "two wave sets: 64-feature blocks only");
   using E = Elem<DT>;
@@ -170,7 +174,7 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   const int p0 = fb * ROWS;
   const int nk = K / BK / S;   // tiles (= groups) of this block's K-range
   const int kt0 = sp * nk;     // first global tile / group index
-  const int G = nk;            // groups held in the LDS tables
+  const int G = nk * GPT;      // groups held in the LDS tables
 
   // ---- per-lane DMA sources ---------------------------------------------------------------------------
   // weights: this wave's 8 rows x 128 B = 1 KiB per tile; lane -> row lane>>3, position lane&7 holds chunk pos ^ (row & 7)
@@ -251,7 +255,7 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   constexpr int NFP = NF + 4;
   for (int e = tid; e < ((a.ablate & 16) ? 0 : NF * G); e += WAVES * SETS * 64) {
     const int f = e / G, g = e - f * G;
-    const size_t idx = (size_t)(p0 + (f % ROWS) + (f / ROWS) * P) * a.G + kt0 + g;
+    const size_t idx = (size_t)(p0 + (f % ROWS) + (f / ROWS) * P) * a.G + (a.per_channel ? 0 : kt0 * GPT + g);
     sz[(g * 2 + 0) * NFP + f] = reinterpret_cast<const T*>(a.scale)[idx];
     if constexpr (INT_SHIFT)
       sz[(g * 2 + 1) * NFP + f] = E::from_f32((float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[idx]);
@@ -265,13 +269,19 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   int woff[2];  // 16-byte chunks fg and 4+fg of the lane's row
 #pragma unroll
   for (int h = 0; h < 2; ++h) woff[h] = wrow * 128 + (((4 * h + fg) ^ (wrow & 7)) << 4);
+  // group size 32 (GPT = 4): a k-step must stay inside ONE group, so k-step t is k = 32 t .. 32 t + 31 and lane group fg takes its bytes
+  // 8 fg .. 8 fg + 7: half fg & 1 of chunk 2 t + (fg >> 1) - four 8-byte reads instead of two 16-byte ones
+  int woff4[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) woff4[t] = wrow * 128 + (((2 * t + (fg >> 1)) ^ (wrow & 7)) << 4) + 8 * (fg & 1);
   const uint32_t nib_shift = (fi >> 3) * 4;  // high-nibble plane for lanes 8..15 of each 16
   int xoff[TF][4];
 #pragma unroll
   for (int tf = 0; tf < TF; ++tf) {
     const int row = tf * 16 + fi;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) xoff[tf][t] = W_BYTES + row * 256 + (((8 * (t >> 1) + 2 * fg + (t & 1)) ^ (row & 15)) << 4);
+    for (int t = 0; t < 4; ++t)
+      xoff[tf][t] = W_BYTES + row * 256 + (((GPT == 4 ? 4 * t + fg : 8 * (t >> 1) + 2 * fg + (t & 1)) ^ (row & 15)) << 4);
   }
   // this lane's 4 consecutive features inside the block: plane (fg>>1), local packed rows wave*8 + 4*(fg&1) + r
   const int floc = (fg >> 1) * ROWS + wave * 8 + 4 * (fg & 1);
@@ -287,54 +297,66 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   // without any VALU work or a pre-kernel; the matrix pipe is idle most of the time in this HBM-bound kernel.
   const V8 ones = __builtin_bit_cast(V8, make_uint4(ONE2<DT>(), ONE2<DT>(), ONE2<DT>(), ONE2<DT>()));
 
-  // One tile = one group: read the wave's weight bytes, 4 k-steps x (TF + TF) MFMAs, fold into acc.
+  // One tile = 128 k = GPT groups: read the wave's weight bytes, 4 k-steps x (TF + TF) MFMAs, one fold into acc per group (after
+  // 4 / GPT k-steps: group sizes 128, 64, 32)
   auto compute_tile = [&](const uint8_t* st, int kt) {
+    constexpr int KS = 4 / GPT;
     uint4 wr[2];
-    wr[0] = *reinterpret_cast<const uint4*>(st + woff[0]);
-    wr[1] = *reinterpret_cast<const uint4*>(st + woff[1]);
-    f32x4 accg[TF], accx[TF];
-#pragma unroll
-    for (int tf = 0; tf < TF; ++tf) {
-      accg[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
-      accx[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (GPT == 4) {
+      const uint2 q0 = *reinterpret_cast<const uint2*>(st + woff4[0]), q1 = *reinterpret_cast<const uint2*>(st + woff4[1]);
+      const uint2 q2 = *reinterpret_cast<const uint2*>(st + woff4[2]), q3 = *reinterpret_cast<const uint2*>(st + woff4[3]);
+      wr[0] = make_uint4(q0.x, q0.y, q1.x, q1.y);  // same register picture as below: k-step t = dwords 2 (t & 1), 2 (t & 1) + 1 of wr[t >> 1]
+      wr[1] = make_uint4(q2.x, q2.y, q3.x, q3.y);
+    } else {
+      wr[0] = *reinterpret_cast<const uint4*>(st + woff[0]);
+      wr[1] = *reinterpret_cast<const uint4*>(st + woff[1]);
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      // k-step t uses bytes 8*(t&1) .. +7 of chunk (t>>1): two dwords -> four operand dwords (natural k order)
-      const uint32_t d0 = (t & 1) ? wr[t >> 1].z : wr[t >> 1].x, d1 = (t & 1) ? wr[t >> 1].w : wr[t >> 1].y;
-      const uint32_t s0 = d0 >> nib_shift, s1 = d1 >> nib_shift;
-      uint32_t op[4];
-      op[0] = (__builtin_amdgcn_perm(0u, s0, 0x0C010C00u) & kmask) | kmagic;  // bytes 0,1
-      op[1] = (__builtin_amdgcn_perm(0u, s0, 0x0C030C02u) & kmask) | kmagic;  // bytes 2,3
-      op[2] = (__builtin_amdgcn_perm(0u, s1, 0x0C010C00u) & kmask) | kmagic;
-      op[3] = (__builtin_amdgcn_perm(0u, s1, 0x0C030C02u) & kmask) | kmagic;
-      const V8 wa = __builtin_bit_cast(V8, make_uint4(op[0], op[1], op[2], op[3]));
+    for (int gq = 0; gq < GPT; ++gq) {
+      f32x4 accg[TF], accx[TF];
 #pragma unroll
       for (int tf = 0; tf < TF; ++tf) {
-        const V8 xb = *reinterpret_cast<const V8*>(st + xoff[tf][t]);
-        accg[tf] = Mma<DT>::run(wa, xb, accg[tf]);
-        accx[tf] = Mma<DT>::run(ones, xb, accx[tf]);
+        accg[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        accx[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int t = gq * KS; t < (gq + 1) * KS; ++t) {
+        // k-step t uses bytes 8*(t&1) .. +7 of chunk (t>>1): two dwords -> four operand dwords (natural k order)
+        const uint32_t d0 = (t & 1) ? wr[t >> 1].z : wr[t >> 1].x, d1 = (t & 1) ? wr[t >> 1].w : wr[t >> 1].y;
+        const uint32_t s0 = d0 >> nib_shift, s1 = d1 >> nib_shift;
+        uint32_t op[4];
+        op[0] = (__builtin_amdgcn_perm(0u, s0, 0x0C010C00u) & kmask) | kmagic;  // bytes 0,1
+        op[1] = (__builtin_amdgcn_perm(0u, s0, 0x0C030C02u) & kmask) | kmagic;  // bytes 2,3
+        op[2] = (__builtin_amdgcn_perm(0u, s1, 0x0C010C00u) & kmask) | kmagic;
+        op[3] = (__builtin_amdgcn_perm(0u, s1, 0x0C030C02u) & kmask) | kmagic;
+        const V8 wa = __builtin_bit_cast(V8, make_uint4(op[0], op[1], op[2], op[3]));
+#pragma unroll
+        for (int tf = 0; tf < TF; ++tf) {
+          const V8 xb = *reinterpret_cast<const V8*>(st + xoff[tf][t]);
+          accg[tf] = Mma<DT>::run(wa, xb, accg[tf]);
+          accx[tf] = Mma<DT>::run(ones, xb, accx[tf]);
+        }
+      }
+      // fold the group: acc += s * acc_g - zz * XS
+      const int g = kt * GPT + gq;
+      T s4t[4], z4t[4];
+      *reinterpret_cast<uint2*>(s4t) = *reinterpret_cast<const uint2*>(sz + (g * 2 + 0) * NFP + floc);
+      *reinterpret_cast<uint2*>(z4t) = *reinterpret_cast<const uint2*>(sz + (g * 2 + 1) * NFP + floc);
+      float s4[4], z4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s4[r] = E::to_f32(s4t[r]);
+        const float z = E::to_f32(z4t[r]);
+        z4[r] = INT_SHIFT ? s4[r] * (z + Mma<DT>::OFFSET) : z + Mma<DT>::OFFSET * s4[r];
+      }
+#pragma unroll
+      for (int tf = 0; tf < TF; ++tf) {
+        const float xs = accx[tf][0];  // every row of the ones-product holds sum_k x[token, k] of this group
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[tf][r] += s4[r] * accg[tf][r] - z4[r] * xs;
       }
     }
-    // fold the group: acc += s * acc_g - zz * XS
-    T s4t[4], z4t[4];
-    *reinterpret_cast<uint2*>(s4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 0) * NFP + floc);
-    *reinterpret_cast<uint2*>(z4t) = *reinterpret_cast<const uint2*>(sz + (kt * 2 + 1) * NFP + floc);
-    float s4[4], z4[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      s4[r] = E::to_f32(s4t[r]);
-      const float z = E::to_f32(z4t[r]);
-      z4[r] = INT_SHIFT ? s4[r] * (z + Mma<DT>::OFFSET) : z + Mma<DT>::OFFSET * s4[r];
-    }
-#pragma unroll
-    for (int tf = 0; tf < TF; ++tf) {
-      const float xs = accx[tf][0];  // every row of the ones-product holds sum_k x[token, k] of this group
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[tf][r] += s4[r] * accg[tf][r] - z4[r] * xs;
-    }
   };
-
   // Tiles are consumed in PAIRS per barrier: twice the work between synchronisations and two independent MFMA/LDS
   // chains for the scheduler to interleave.  Ring of STAGES (even) stages; tiles kt.. are in flight up to kt+STAGES-1.
   int cur = 0;
@@ -473,17 +495,17 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
 constexpr int lds_bytes(int tf, int stages, int G, int waves) { return stages * (waves * 8 * BK + tf * 16 * BK * 2) + G * 2 * (16 * waves + 4) * 2; }
 
 // `segs` (with the total number of feature blocks) selects the multi-Linear launch; 64-feature blocks only, like the two-set form
-template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI, int SETS>
+template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI, int SETS, int GPT = 1>
 static int launch_k(const Args& a, hipStream_t stream, const Segs& segs, int grid, int lds) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS, GPT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS>), dim3(grid), dim3(WAVES * SETS * 64), lds, stream, a, segs);
+  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS, GPT>), dim3(grid), dim3(WAVES * SETS * 64), lds, stream, a, segs);
   return launch_status();
 }
 
 template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES>
 static int launch_s(const Args& a, hipStream_t stream, const Segs* segs = nullptr, int total_fb = 0) {
-  const int lds = lds_bytes(TF, STAGES, a.G / a.S, WAVES);
+  const int lds = lds_bytes(TF, STAGES, a.K / BK / a.S, WAVES);
   if constexpr (WAVES == 4) {
     // eight waves per block from two token fragments on (us, four -> eight waves: (32,4096,4096) 10.74 -> 10.21, (64,4096,4096)
     // 17.6 -> 15.7, (32,14336,4096) 18.5 -> 17.7, gate+up M = 32 in one launch 29.5 -> 26.6; but one fragment, q/k/v M = 8:
@@ -507,9 +529,9 @@ static int launch(const Args& a, hipStream_t stream, const Segs* segs = nullptr,
   const int budget = env_int("QUANTO_HIP_SKINNY_LDS_KB", 50) * 1024;
   constexpr int per_tile = 1 + TF * 4 / WAVES;  // DMA instructions per wave and tile; vmcnt counts at most 63 of them
   if constexpr ((8 - 4) * per_tile <= 60)
-    if (lds_bytes(TF, 8, a.G / a.S, WAVES) <= budget) return launch_s<DT, TF, 8, INT_SHIFT, WAVES>(a, stream, segs, total_fb);
+    if (lds_bytes(TF, 8, a.K / BK / a.S, WAVES) <= budget) return launch_s<DT, TF, 8, INT_SHIFT, WAVES>(a, stream, segs, total_fb);
   if constexpr ((6 - 4) * per_tile <= 60)
-    if (lds_bytes(TF, 6, a.G / a.S, WAVES) <= budget) return launch_s<DT, TF, 6, INT_SHIFT, WAVES>(a, stream, segs, total_fb);
+    if (lds_bytes(TF, 6, a.K / BK / a.S, WAVES) <= budget) return launch_s<DT, TF, 6, INT_SHIFT, WAVES>(a, stream, segs, total_fb);
   return launch_s<DT, TF, 4, INT_SHIFT, WAVES>(a, stream, segs, total_fb);
 }
 
@@ -534,8 +556,23 @@ static int launch_waves(const Args& a, hipStream_t stream, const Segs* segs = nu
   return launch<DT, TF, INT_SHIFT, 1>(a, stream);
 }
 
+// group sizes 64 / 32: 64-feature blocks, 4-stage ring, two wave sets from two token fragments on (as the group-size-128 form)
+template <int DT, bool INT_SHIFT, int TF, int GPT>
+static int launch_small_groups(const Args& a, hipStream_t stream) {
+  const int lds = lds_bytes(TF, 4, a.K / BK / a.S * GPT, 4);
+  return launch_k<DT, TF, 4, INT_SHIFT, 4, false, (TF >= 2 ? 2 : 1), GPT>(a, stream, Segs{}, a.N / 64 * a.S, lds);
+}
+template <int DT, bool INT_SHIFT, int GPT>
+static int launch_small_groups_tf(const Args& a, hipStream_t stream) {
+  if (a.M <= 16) return launch_small_groups<DT, INT_SHIFT, 1, GPT>(a, stream);
+  if (a.M <= 32) return launch_small_groups<DT, INT_SHIFT, 2, GPT>(a, stream);
+  return launch_small_groups<DT, INT_SHIFT, 4, GPT>(a, stream);
+}
+
 template <int DT, bool INT_SHIFT>
 static int launch_tf(const Args& a, hipStream_t stream, const Segs* segs = nullptr, int total_fb = 0) {
+  if (a.gpt == 2) return launch_small_groups_tf<DT, INT_SHIFT, 2>(a, stream);
+  if (a.gpt == 4) return launch_small_groups_tf<DT, INT_SHIFT, 4>(a, stream);
   if (a.M <= 16) return launch_waves<DT, INT_SHIFT, 1>(a, stream, segs, total_fb);
   if (a.M <= 32) return launch_waves<DT, INT_SHIFT, 2>(a, stream, segs, total_fb);
   return launch_waves<DT, INT_SHIFT, 4>(a, stream, segs, total_fb);
@@ -552,8 +589,9 @@ static int skinny_split(const PackedGeom& g, int64_t M) {
   const int tf = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
   const int blocks = (int)(g.N / (16 * skinny::pick_waves((int)g.N, tf)));
   int s = 1;
-  while (s < 8 && blocks * s * 2 <= 512 && g.G % (s * 2) == 0 && g.G / (s * 2) >= 8) s *= 2;
-  if (forced > 0 && g.G % forced == 0) s = forced;
+  const int tiles = (int)(g.K / 128);  // 128-k tiles (= groups of 128)
+  while (s < 8 && blocks * s * 2 <= 512 && tiles % (s * 2) == 0 && tiles / (s * 2) >= 8) s *= 2;
+  if (forced > 0 && tiles % forced == 0) s = forced;
   if ((size_t)blocks * 4 > QUANTO_HIP_WS_COUNTER_BYTES) s = 1;  // one counter per feature block
   return s;
 }
@@ -565,9 +603,14 @@ static size_t skinny_counter_bytes(const PackedGeom&) { return QUANTO_HIP_WS_COU
 bool qbits_skinny_supported(int64_t M, const PackedGeom& g, int dtype) {
   const int64_t Mp = M > 64 ? 64 : M;  // rows per pass
   const int tf = Mp <= 16 ? 1 : (Mp <= 32 ? 2 : 4);
-  return g.bits == 4 && g.C == 128 && (g.N % 16 == 0) && (g.K % 128 == 0) && M >= 1 && M <= QUANTO_HIP_SKINNY_MAX_M &&
+  // group sizes 128, 64, 32 (1, 2, 4 groups per 128-k tile) and per-channel scales (r3: the formats nn/qmodule.py:121-129 selects
+  // when in_features is not a multiple of 128 or the caller asks for them no longer leave the streaming kernel)
+  const bool per_channel = g.C == g.K && g.C != 128;
+  const bool grouped = g.C == 128 || ((g.C == 64 || g.C == 32) && g.N % 64 == 0);
+  const int groups = per_channel ? (int)(g.K / 128) : (int)g.G;
+  return g.bits == 4 && (grouped || per_channel) && (g.N % 16 == 0) && (g.K % 128 == 0) && M >= 1 && M <= QUANTO_HIP_SKINNY_MAX_M &&
          (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30) && g.K < (1 << 30) &&
-         skinny::lds_bytes(tf, 4, (int)g.G, skinny::pick_waves((int)g.N)) <= 160 * 1024;
+         skinny::lds_bytes(tf, 4, groups, skinny::pick_waves((int)g.N)) <= 160 * 1024;
 }
 
 // [counters (zero on entry, zero on exit) | fp32 partial sums]; 0 when the problem is not split
@@ -585,6 +628,7 @@ int qbits_mm_skinny(const void* x, const uint8_t* packed, const void* scale, con
   // split-K only with a workspace (whose counter words the caller guarantees to be zero); without one: one block per feature block
   int S = skinny_split(g, M > 64 ? 64 : M);
   if (S > 1 && (!workspace || workspace_bytes < qbits_skinny_workspace(M, g) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
+  const bool per_channel = g.C == g.K && g.C != 128;
   const size_t esize = 2;  // bf16 / fp16
   for (int64_t m0 = 0; m0 < M; m0 += 64) {  // passes of up to 64 rows (stream-ordered: each pass leaves the counters zero)
     const int64_t rows = M - m0 < 64 ? M - m0 : 64;
@@ -592,6 +636,7 @@ int qbits_mm_skinny(const void* x, const uint8_t* packed, const void* scale, con
                    reinterpret_cast<uint8_t*>(y) + (size_t)m0 * g.N * esize, (int)rows, (int)g.N, (int)g.K, (int)g.G, S,
                    reinterpret_cast<int*>(workspace),
                    S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr,
+                   per_channel ? 1 : (int)(128 / g.C), per_channel ? 1 : 0,
                    // later passes of a multi-pass call re-read the weights from the Infinity Cache: keep them cacheable there
                    env_int("QUANTO_HIP_SKINNY_NT", M <= 64 ? 1 : 0), env_int("QUANTO_HIP_SKINNY_ABLATE", 0),
                    reinterpret_cast<unsigned long long*>(env_ptr("QUANTO_HIP_SKINNY_TIMELINE"))};
@@ -651,7 +696,7 @@ int qbits_mm_skinny_multi(const void* x, int nseg, const uint8_t* const* packed,
   if (S > 1 && (!workspace || workspace_bytes < qbits_skinny_workspace(M, g) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
   skinny::Args a{x, packed[0], scale[0], shift[0], bias ? bias[0] : nullptr, y[0], (int)M, (int)N[0], (int)K, (int)g.G, S,
                  reinterpret_cast<int*>(workspace),
-                 S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr,
+                 S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr, 1, 0,
                  env_int("QUANTO_HIP_SKINNY_NT", 1), 0, nullptr};
   if (dtype == QUANTO_HIP_BF16)
     return int_shift ? skinny::launch_tf<QUANTO_HIP_BF16, true>(a, stream, &segs, fb) : skinny::launch_tf<QUANTO_HIP_BF16, false>(a, stream, &segs, fb);

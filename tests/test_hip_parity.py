@@ -297,12 +297,34 @@ def test_qbits_gemv_other_group_sizes(dt, zp, M, N, K, gs):
     (nn/qmodule.py:121-129: 96 / 64 / 32) and for per-channel int4 (group_size=None): exact-math gate, AUTO must pick it - in
     passes of 4 rows up to 24 rows (r3), so that batched decode with these formats no longer goes through dequantize + dense GEMM."""
     p = make_qbits_problem(M, N, K, dt, group_size=gs, zeropoint=zp, seed=N + K)
-    y = _run_qbits(p, "auto")
-    assert quanto_hip.lib.last_kernel() == "gemv"
+    ya = _run_qbits(p, "auto")
+    # r3: from 5 rows on the streaming MFMA kernel serves group sizes 64 / 32 (64-feature blocks) and per-channel scales too
+    streaming = M > 4 and K % 128 == 0 and ((gs in (64, 32) and N % 64 == 0) or (gs is None and N % 16 == 0))
+    assert quanto_hip.lib.last_kernel() == ("skinny" if streaming else "gemv")
+    assert_close_to_exact(ya, _exact_qbits(p), dt, f"auto group_size={gs} {M}x{K}x{N}")
+    y = _run_qbits(p, "gemv")
     assert_close_to_exact(y, _exact_qbits(p), dt, f"gemv group_size={gs} {M}x{K}x{N}")
     # bias: rounded product + bias, rounded again (the reference's order) - bit for bit against the kernel's own bias-free output
     bias = O.round_to(np.random.default_rng(5).standard_normal(N).astype(np.float32), dt)
     np.testing.assert_array_equal(_run_qbits(p, "gemv", bias), O.round_to((y + bias).astype(np.float32), dt))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("zp", [False, True])
+@pytest.mark.parametrize("M", [5, 16, 17, 33, 64, 130])
+@pytest.mark.parametrize("N,K,gs", [(256, 1024, 64), (512, 4096, 32), (64, 128, 32), (192, 14336, 64), (128, 384, None), (1024, 1024, None),
+                                    (4096, 4096, 64)])
+def test_qbits_skinny_small_groups_and_per_channel(dt, zp, M, N, K, gs):
+    """Streaming MFMA kernel with 2 / 4 quantization groups per 128-k tile (group sizes 64 / 32: one fold per group) and with per-channel
+    scales (one table entry per feature, repeated): 1 / 2 / 4 token fragments, passes of 64 rows, K split over workgroups (N = 512,
+    K = 4096), long K (448 table rows of 64 features), integer zero-points; exact-math gate and the bias-add sequence."""
+    p = make_qbits_problem(M, N, K, dt, group_size=gs, zeropoint=zp, seed=M + N + K)
+    y = _run_qbits(p, "skinny")
+    assert quanto_hip.lib.last_kernel() == "skinny"
+    assert_close_to_exact(y, _exact_qbits(p), dt, f"skinny group_size={gs} {M}x{K}x{N}")
+    if M in (16, 33):
+        bias = O.round_to(np.random.default_rng(7).standard_normal(N).astype(np.float32), dt)
+        np.testing.assert_array_equal(_run_qbits(p, "skinny", bias), O.round_to((y + bias).astype(np.float32), dt))
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
@@ -335,7 +357,10 @@ def test_qbits_auto_picks_fast_kernels():
     p = make_qbits_problem(65, 256, 1024, "bf16")  # r3: beyond 64 rows the fused int4 GEMM (64-token tiles) instead of two passes
     _run_qbits(p, "auto")
     assert quanto_hip.lib.last_kernel() == "mfma_fused4"
-    p = make_qbits_problem(40, 256, 512, "bf16", group_size=64)  # group size 64, small M: register-staged 128x128 kernel
+    p = make_qbits_problem(40, 256, 512, "bf16", group_size=64)  # group size 64: the streaming kernel with two groups per tile (r3)
+    _run_qbits(p, "auto")
+    assert quanto_hip.lib.last_kernel() == "skinny"
+    p = make_qbits_problem(40, 200, 512, "bf16", group_size=64)  # ... which needs 64-feature blocks: register-staged 128x128 kernel
     _run_qbits(p, "auto")
     assert quanto_hip.lib.last_kernel() == "mfma"
     p = make_qbits_problem(2048, 1024, 256, "bf16")  # 8 x 4 tiles of 256x256: dequantize once + dense GEMM

@@ -58,7 +58,8 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.quanto_hip_qbits_mm_workspace_size(256, 4096, 14336, 4, 128, 2, 0) == 4096 + 128 * 2 * 512 * 64
     assert lib.quanto_hip_qbits_mm_pick(300, 256, 4096, 4, 128, 2) == 8
     assert lib.quanto_hip_qbits_mm_workspace_size(300, 256, 4096, 4, 128, 2, 7) == 256 * 4096 * 2  # DEQUANT_MFMA: the dequantized weight
-    assert lib.quanto_hip_qbits_mm_workspace_size(40, 256, 512, 4, 64, 2, 0) == 8 * 128 * 4  # group size 64, small M: 128x128 kernel (row sums of x)
+    assert lib.quanto_hip_qbits_mm_workspace_size(40, 200, 512, 4, 64, 2, 0) == 8 * 128 * 4  # group size 64, N not in 64-feature blocks: 128x128 kernel (row sums of x)
+    assert lib.quanto_hip_qbits_mm_workspace_size(40, 256, 512, 4, 64, 2, 0) == 0  # group size 64: streaming kernel, too few tiles to split
     # streaming MFMA kernel, N = 4096: 256 waves -> K split 4 ways; the fixed 4 KiB counter region (QUANTO_HIP_WS_COUNTER_BYTES) + fp32 partials (TF = 4)
     assert lib.quanto_hip_qbits_mm_workspace_size(64, 4096, 4096, 4, 128, 2, 0) == 4096 + 256 * 4 * 64 * 4 * 16
     # N = 14336: 224 blocks of 64 features -> split 2 (448 blocks, two to three per CU)
