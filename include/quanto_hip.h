@@ -59,7 +59,8 @@ typedef enum {
   QUANTO_HIP_KERNEL_GEMV = 2,  /* weight-streaming kernel for M <= QUANTO_HIP_GEMV_MAX_M[_QBITS] */
   QUANTO_HIP_KERNEL_MFMA = 3,  /* LDS-tiled MFMA kernel, 128x128 tile (any M)                   */
   QUANTO_HIP_KERNEL_MFMA_LARGE = 4, /* 256x256 tile, LDS-DMA pipeline (prefill-sized M and N)    */
-  QUANTO_HIP_KERNEL_SKINNY = 5, /* qbits_mm: weight-streaming MFMA kernel for M <= QUANTO_HIP_SKINNY_MAX_M */
+  QUANTO_HIP_KERNEL_SKINNY = 5, /* qbits_mm (int4; group sizes 128 / 64 / 32, per-channel scales) and qbytes_mm: weight-streaming MFMA kernel for
+                                 * M <= QUANTO_HIP_SKINNY_MAX_M; K split over workgroups when a workspace is given */
   QUANTO_HIP_KERNEL_NATIVE8 = 6, /* qbytes_mm with quantized activations: int8 x int8 (i32 MFMA) / fp8 x fp8 (fp8 MFMA) */
   QUANTO_HIP_KERNEL_DEQUANT_MFMA = 7, /* qbits_mm, M beyond ~1-1.5 k rows (and formats the fused kernels do not take): fused dequantize into the
                                        * workspace + dense MFMA GEMM - multiplies the weight rounded to the activation dtype, as the reference does */
@@ -78,7 +79,7 @@ typedef enum {
 #define QUANTO_HIP_GEMV_MAX_M 8         /* qbytes_mm: rows of x the GEMV kernel accepts                    */
 #define QUANTO_HIP_SKINNY_MAX_M 256      /* qbits_mm: rows of x the streaming MFMA kernel accepts (passes of 64) */
 #define QUANTO_HIP_GEMV_MAX_M_QBITS 64  /* qbits_mm: ditto (passes of up to 8 rows; weights re-read from MALL) */
-#define QUANTO_HIP_GEMV_MAX_M_OTHER 24  /* qbits_mm, group sizes 32 / 64 / 96, per-channel, qint2: passes of 4 rows */
+#define QUANTO_HIP_GEMV_MAX_M_OTHER 24  /* qbits_mm, group size 96, qint2 (and 64 / 32 / per-channel where the streaming kernel's block shape does not fit): passes of 4 rows */
 
 int quanto_hip_abi_version(void);
 const char* quanto_hip_status_string(int status);
