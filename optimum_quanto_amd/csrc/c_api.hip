@@ -106,11 +106,11 @@ static size_t dequant_mfma_workspace(const PackedGeom& g) { return (size_t)g.N *
 //   N = 1024, K = 4096:  M = 128 18.5 / 47 / 25.7, 512 22.5 / 49.5, 1024 26.6 / 48.7
 // The fused kernel's time is rounds of tiles x groups (its own model picks 64- or 128-token tiles and the K split, qbits_mfma_fused.hip);
 // dequantize + dense is flat in M up to ~1 k rows (one dequantize pass + a dense GEMM that cannot fill the chip) and wins once the
-// fused kernel needs more than ~1.2 rounds of 128-token tiles.  QUANTO_HIP_FUSED4_MAX_COST (x 100) / _MIN_M override the limits in experiments.
+// fused kernel needs more than ~1.6 rounds of 128-token tiles (1.2 until two 64-token workgroups shared a CU: (1536,4096,4096) 71.5 / 81.4).  QUANTO_HIP_FUSED4_MAX_COST (x 100) / _MIN_M override the limits in experiments.
 float qbits_mfma_fused_cost(int64_t, const PackedGeom&);
 static bool fused4_wins(int64_t M, const PackedGeom& g) {
   if (M <= env_int("QUANTO_HIP_FUSED4_MIN_M", 64)) return false;
-  return qbits_mfma_fused_cost(M, g) * 100.f <= (float)env_int("QUANTO_HIP_FUSED4_MAX_COST", 120);
+  return qbits_mfma_fused_cost(M, g) * 100.f <= (float)env_int("QUANTO_HIP_FUSED4_MAX_COST", 160);
 }
 
 // The register-streaming kernel (K split inside the block, no split-K tail) against the LDS-streaming one, us per launch:

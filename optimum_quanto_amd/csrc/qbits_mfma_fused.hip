@@ -19,8 +19,8 @@
 // the high plane); wave w = ALL BM tokens x 16 features (packed rows 8w .. 8w+7, both planes: lanes 0-7 of every 16 keep the low
 // nibbles, lanes 8-15 the high nibbles of the same 8 rows - the decode kernels' mapping); K-tile = one group (128 k).  Every weight
 // is turned into an MFMA operand exactly once per workgroup (r2's 2 x 4 layout built every operand in both token halves and spent
-// 2.2 VALU per MFMA on it; here 8 VALU serve 4 k-steps x MI MFMAs).  Activations AND weights travel by LDS-DMA into a ring of three
-// stages, two tiles ahead (256-byte activation rows, chunk ^ (row & 15) on the DMA source, undone on the read; 128-byte weight rows,
+// 2.2 VALU per MFMA on it; here 8 VALU serve 4 k-steps x MI MFMAs).  Activations AND weights travel by LDS-DMA into a ring of two
+// stages, one tile ahead (256-byte activation rows, chunk ^ (row & 15) on the DMA source, undone on the read; 128-byte weight rows,
 // chunk ^ (row & 7)).  Scales / shifts of the workgroup's 128 features for its groups are parked in LDS once (16-byte loads, issued
 // in front of the first tiles' DMA).  Split-K where the scale table does not fit (K = 14336 with 128-token tiles) and, with 64-token
 // tiles, to fill the chip: fp32 partial tiles through the workspace, write-through stores, arrival counter, the last workgroup adds
@@ -34,7 +34,11 @@ namespace fused4 {
 
 // Token tile: BM = 128 (MI = 8 fragments per wave) for grids that fill the chip - 32 KiB of activations per 8 KiB of packed weights
 // and tile -, BM = 64 (MI = 4) for short prefills whose 128-token tiles would leave CUs idle ((512,4096,4096): 128 -> 256 workgroups).
-constexpr int BK = 128, PR = 64, WAVES = 8, DEPTH = 2, STAGES = 3;
+// Ring of TWO stages, one tile ahead (r3, end of round; three stages / two ahead before): a 64-token workgroup then needs 65 KiB of LDS with
+// the tables of 32 groups and TWO workgroups share a CU (the kernel's 106-124 VGPRs always allowed four waves per SIMD) - out of phase, they
+// fill each other's barrier and wait slots: (1024,4096,4096) as 512 workgroups of 64 tokens 56.7 -> 49.5 us, (1536,...) 79.3 -> 73.3, (2048,...)
+// 98 -> 92.6; grids of one workgroup per CU do not notice the shallower ring ((512,4096,4096) 29.4 -> 29.3, (128,...) unsplit 27.6 -> 26.1).
+constexpr int BK = 128, PR = 64, WAVES = 8, DEPTH = 1, STAGES = 2;
 constexpr int W_BYTES = PR * BK;  // 8 KiB
 template <int BM>
 struct Geo {
@@ -124,7 +128,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
   T* sz = reinterpret_cast<T*>(smem + STAGES * STAGE_BYTES + 2 * BM * 4);
 
   // ---- memory pipeline.  A tile lasts under a microsecond, a load from L2 / HBM under load 1-2 us: activations AND weights travel
-  // by LDS-DMA into a ring of three stages, DEPTH = 2 tiles ahead.  The loop contains no other vector-memory instruction, so the
+  // by LDS-DMA into a ring of STAGES stages, DEPTH tiles ahead.  The loop contains no other vector-memory instruction, so the
   // hand-counted s_waitcnt below is the only wait on that queue (hipcc counts only the loads it can see and would drain the DMA
   // queue at each of its own waits).  Every tile issues the same OPS DMA instructions; tiles past the end re-request the last tile
   // (harmless), so the count never changes.  XS[m, g] comes from the matrix pipe: an extra MFMA per k-step against an all-ones operand

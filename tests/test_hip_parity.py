@@ -238,15 +238,15 @@ def test_qbits_mfma_fused4(dt, M, N, K, zp, bm, monkeypatch):
 def test_qbits_mfma_fused4_llama_prefill():
     """What AUTO picks for short prefills of a Llama-3-8B layer (one round of tiles; 64-token tiles, K split to fill the chip, from
     65 rows on): the fused kernel; whole output against exact math."""
-    for M, N, K in ((512, 4096, 4096), (256, 14336, 4096), (1024, 4096, 4096), (128, 4096, 4096), (200, 1024, 4096)):
-        p = make_qbits_problem(M, N, K, "bf16", seed=N + K)
+    for M, N, K in ((512, 4096, 4096), (256, 14336, 4096), (1024, 4096, 4096), (128, 4096, 4096), (200, 1024, 4096), (1536, 4096, 4096)):
+        p = make_qbits_problem(M, N, K, "bf16", seed=N + K)  # 1536 rows: 768 workgroups of 64 tokens, two per CU (r3)
         y = _run_qbits(p, "auto")
         assert quanto_hip.lib.last_kernel() == "mfma_fused4"
         assert_close_to_exact(y, _exact_qbits(p), "bf16", f"auto -> mfma_fused4 {M}x{K}x{N}")
-    p = make_qbits_problem(512, 4096, 14336, "bf16", seed=7)  # K = 14336: the scale table fits once K is split over two workgroups
+    p = make_qbits_problem(512, 4096, 14336, "bf16", seed=7)  # K = 14336: 112 groups' scale tables next to the two-stage ring
     y = _run_qbits(p, "auto")
     assert quanto_hip.lib.last_kernel() == "mfma_fused4"
-    assert_close_to_exact(y, _exact_qbits(p), "bf16", "auto -> mfma_fused4 (split-K) 512x14336x4096")
+    assert_close_to_exact(y, _exact_qbits(p), "bf16", "auto -> mfma_fused4 512x14336x4096")
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
