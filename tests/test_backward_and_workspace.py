@@ -188,7 +188,7 @@ def test_auto_dispatch_accepts_misaligned_views(M):
 @pytest.mark.gpu
 def test_c_api_multi_fallback_restores_the_counter_words_behind_scratch_members():
     """quanto_hip_qbits_mm_multi_ws falls back to separate calls that share ONE workspace.  Member 0 (N = 4096, K = 4096,
-    M = 1100) resolves to DEQUANT_MFMA and writes the dequantized weight from offset 0 - over the arrival counters; member 1 (N = 256)
+    M = 1800) resolves to DEQUANT_MFMA and writes the dequantized weight from offset 0 - over the arrival counters; member 1 (N = 256)
     resolves to the split-K form of the fused int4 GEMM and needs those counters to be zero.  Straight through the C ABI with one
     caller-owned buffer (the Python binding keeps zeroed and scratch buffers apart, so only a C caller can hit this)."""
     import ctypes
@@ -197,7 +197,7 @@ def test_c_api_multi_fallback_restores_the_counter_words_behind_scratch_members(
 
     lib, dev = quanto_hip.lib, "cuda"
     c = lib._c
-    M, K, Ns = 1100, 4096, [4096, 256]
+    M, K, Ns = 1800, 4096, [4096, 256]
     BF16, DEQUANT, FUSED4 = 2, 7, 8
     c.quanto_hip_qbits_mm_pick.argtypes = [ctypes.c_int64] * 3 + [ctypes.c_int] * 3
     assert [c.quanto_hip_qbits_mm_pick(M, n, K, 4, 128, BF16) for n in Ns] == [DEQUANT, FUSED4]
