@@ -289,11 +289,14 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
     acc[i][r] = v;
   };
 
-  int stage = 0;
+  static_assert(STAGES == 2 && DEPTH == 1, "the stage of a tile is its parity: a compile-time tag below");
   constexpr int XR = 6, XD = 4;  // activation fragments: ring of 6 registers sets, fetched 4 steps ahead of their MFMA (one MFMA per step)
   // One tile (= one group) accumulating into cg while the previous tile's pg is folded.
-  auto tile = [&](int kt, f32x4 (&cg)[MI], const f32x4 (&pg)[MI], auto have_prev_tag) {
+  // stage_tag: with two stages the stage of tile kt is kt & 1 - known where the tile is instantiated, so every LDS address of the tile is
+  // (lane offset register) + immediate instead of one v_add per fragment offset and tile
+  auto tile = [&](int kt, f32x4 (&cg)[MI], const f32x4 (&pg)[MI], auto have_prev_tag, auto stage_tag) {
     constexpr bool have_prev = decltype(have_prev_tag)::value;
+    constexpr int stage = decltype(stage_tag)::value;
     // requests of tile kt (issued two tiles ago) have landed once at most the one younger group is outstanding.  (Tiles 0 and 1:
     // completed by the prologue; fewer groups are outstanding than the count allows, the wait falls through.)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * OPS) : "memory");
@@ -302,7 +305,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
     asm volatile("" ::: "memory");
     {
       const int tn = kt + DEPTH < nk ? kt + DEPTH : last;
-      const int sn = stage + DEPTH >= STAGES ? stage + DEPTH - STAGES : stage + DEPTH;
+      constexpr int sn = 1 - stage;
       issue_tile(tn, sn);
     }
     const uint8_t* st = smem + stage * STAGE_BYTES;
@@ -361,7 +364,6 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
       for (int t = 0; t < 4; ++t) cx = Mma<DT>::run(ones, *reinterpret_cast<const V8*>(st + xoff[t] + my_xs * 4096), cx);
       if (lane < 16) xs_slot[(kt & 1) * BM + my_xs * 16 + lane] = cx[0];
     }
-    stage = stage + 1 == STAGES ? 0 : stage + 1;
   };
   auto final_fold = [&](const f32x4 (&pg)[MI]) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -373,14 +375,16 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_mfma_fused_kernel(const A
     for (int q = 0; q < 4 * MI; ++q) fold_slice(pg, q);
   };
   using yes = std::integral_constant<bool, true>;
-  tile(0, accgA, accgB, std::integral_constant<bool, false>{});
+  using st0 = std::integral_constant<int, 0>;
+  using st1 = std::integral_constant<int, 1>;
+  tile(0, accgA, accgB, std::integral_constant<bool, false>{}, st0{});
   int kt = 1;
   for (; kt + 2 <= nk_run; kt += 2) {
-    tile(kt, accgB, accgA, yes{});
-    tile(kt + 1, accgA, accgB, yes{});
+    tile(kt, accgB, accgA, yes{}, st1{});
+    tile(kt + 1, accgA, accgB, yes{}, st0{});
   }
   if (kt < nk_run) {
-    tile(kt, accgB, accgA, yes{});  // nk even: the last tile landed in set B
+    tile(kt, accgB, accgA, yes{}, st1{});  // nk even: the last tile landed in set B
     final_fold(accgB);
   } else {
     final_fold(accgA);
