@@ -19,6 +19,7 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # quanto_hip_dtype (include/quanto_hip.h)
 F32, F16, BF16, I8, U8, F8_E4M3FN, F8_E5M2, F8_E4M3FNUZ = range(8)
+WS_COUNTER_BYTES = 4096  # QUANTO_HIP_WS_COUNTER_BYTES
 KERNEL_AUTO, KERNEL_NAIVE, KERNEL_GEMV, KERNEL_MFMA, KERNEL_MFMA_LARGE, KERNEL_SKINNY, KERNEL_NATIVE8, KERNEL_DEQUANT_MFMA, KERNEL_MFMA_FUSED4, KERNEL_MMV = range(10)
 KERNELS = {"auto": KERNEL_AUTO, "naive": KERNEL_NAIVE, "gemv": KERNEL_GEMV, "mfma": KERNEL_MFMA, "mfma_large": KERNEL_MFMA_LARGE, "skinny": KERNEL_SKINNY,
            "mfma_native8": KERNEL_NATIVE8, "dequant_mfma": KERNEL_DEQUANT_MFMA, "mfma_fused4": KERNEL_MFMA_FUSED4, "mmv": KERNEL_MMV}
@@ -127,7 +128,7 @@ class _Bindings:
 
     def _zeroed_workspace(self, device: torch.device, nbytes: int, stream) -> torch.Tensor:
         """Split-K workspace: [QUANTO_HIP_WS_COUNTER_BYTES of arrival counters | fp32 partial sums] (include/quanto_hip.h).
-        One buffer per (device, stream, capture): zero-filled once when (re)allocated and only ever handed to kernels that
+        One buffer per (device, stream, capture): its counter region zero-filled once when (re)allocated and only ever handed to kernels that
         restore the counter words they use.  Launches on one stream reuse it in stream order; launches on different streams
         of one device may overlap, so each stream gets its own counters.  A buffer allocated while the stream is being
         captured lives in that graph's memory pool and its zero-fill is a node of that graph (re-run on every replay): it is
@@ -142,7 +143,11 @@ class _Bindings:
             if len(cache) > 64:  # stream handles / capture ids come and go: do not keep dead buffers alive forever
                 for k in [k for k in cache if k[2] != 0 and k != key]:
                     del cache[k]
-            buf = torch.zeros((max(nbytes, 8 << 20),), dtype=torch.uint8, device=device)
+            # only the counter region has to be zero (include/quanto_hip.h: QUANTO_HIP_WS_COUNTER_BYTES; the kernels restore what they
+            # use, the partial sums behind it are never read before they are written): 4 KiB of fill - under capture a 4 KiB memset
+            # node per replay instead of one over the whole buffer (8-17 MB)
+            buf = torch.empty((max(nbytes, 8 << 20),), dtype=torch.uint8, device=device)
+            buf[:WS_COUNTER_BYTES].zero_()
             cache[key] = buf
         return buf
 
