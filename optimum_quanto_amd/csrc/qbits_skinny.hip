@@ -9,7 +9,7 @@
 //   * wave w owns packed rows 8w..8w+7.  Its MFMA A operand is 16 FEATURES = those 8 rows x both nibble planes: lane
 //     (i = lane & 15, g = lane >> 4) reads 16 bytes of row i%8 and keeps the low nibbles (i < 8) or the high nibbles
 //     (i >= 8) - lanes i and i+8 read the same LDS address (broadcast).  128+q is built exactly as a bf16/fp16 number
-//     (v_perm + v_and_or), 1 VALU op per weight;
+//     (shift + mask per raw dword, one v_perm per pair of weights), 1 VALU op per weight;
 //   * the activation tile (16*TF tokens x 128 k) is shared by the 4 waves; D[feature][token] accumulates one group in
 //     fp32, then   acc += s[f,g]*acc_g - (z[f,g] + 128 s[f,g]) * XS[token,g],  with XS[token,g] = sum_k x from one extra
 //     MFMA per k-step against an all-ones operand (no pre-kernel, no workspace).  The scales/shifts of the block's 64
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   f32x4 acc[TF];
 #pragma unroll
   for (int tf = 0; tf < TF; ++tf) acc[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
-  uint32_t kmask = 0x000F000Fu, kmagic = Mma<DT>::MAGIC;
+  uint32_t kmask = 0x0F0F0F0Fu, kmagic = Mma<DT>::MAGIC;
   asm volatile("" : "+s"(kmask));
   asm volatile("" : "+v"(kmagic));
 
@@ -323,12 +323,14 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
       for (int t = gq * KS; t < (gq + 1) * KS; ++t) {
         // k-step t uses bytes 8*(t&1) .. +7 of chunk (t>>1): two dwords -> four operand dwords (natural k order)
         const uint32_t d0 = (t & 1) ? wr[t >> 1].z : wr[t >> 1].x, d1 = (t & 1) ? wr[t >> 1].w : wr[t >> 1].y;
-        const uint32_t s0 = d0 >> nib_shift, s1 = d1 >> nib_shift;
+        // 8 VALU per 8 weights (r3, as qbits_mfma_fused.hip): the lane's nibble plane shifted down and masked once per raw dword, then ONE
+        // v_perm per pair of weights interleaves their bytes with the exponent byte of 128 (bf16 0x43) / 1024 (fp16 0x64)
+        const uint32_t s0 = (d0 >> nib_shift) & kmask, s1 = (d1 >> nib_shift) & kmask;
         uint32_t op[4];
-        op[0] = (__builtin_amdgcn_perm(0u, s0, 0x0C010C00u) & kmask) | kmagic;  // bytes 0,1
-        op[1] = (__builtin_amdgcn_perm(0u, s0, 0x0C030C02u) & kmask) | kmagic;  // bytes 2,3
-        op[2] = (__builtin_amdgcn_perm(0u, s1, 0x0C010C00u) & kmask) | kmagic;
-        op[3] = (__builtin_amdgcn_perm(0u, s1, 0x0C030C02u) & kmask) | kmagic;
+        op[0] = __builtin_amdgcn_perm(kmagic, s0, 0x07010500u);  // bytes 0,1 -> (q0, exp, q1, exp)
+        op[1] = __builtin_amdgcn_perm(kmagic, s0, 0x07030502u);  // bytes 2,3
+        op[2] = __builtin_amdgcn_perm(kmagic, s1, 0x07010500u);
+        op[3] = __builtin_amdgcn_perm(kmagic, s1, 0x07030502u);
         const V8 wa = __builtin_bit_cast(V8, make_uint4(op[0], op[1], op[2], op[3]));
 #pragma unroll
         for (int tf = 0; tf < TF; ++tf) {
