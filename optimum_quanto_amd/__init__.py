@@ -10,7 +10,6 @@ from .library import *
 from .tensor import *
 from .nn import *
 from .model_api import *
-from .calibrate import *
 from .models import *
 from .checkpoint import *
 from . import parallel  # noqa: E402,F401  (column shard over RCCL / gloo)

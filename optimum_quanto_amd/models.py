@@ -160,8 +160,15 @@ class _SiblingGroup:
             return "qbytes" if ok else None
         return None
 
+    @staticmethod
+    def _stamp(x):
+        """(storage address, version counter).  Inference tensors (created under ``torch.inference_mode()``) track no version
+        counter - reading ``_version`` raises - and cannot be updated in place outside inference mode: the address alone identifies
+        their contents for the few calls a parked output lives."""
+        return (x.data_ptr(), None if x.is_inference() else x._version)
+
     def forward(self, index: int, x):
-        if self.input is x and index in self.outputs and self.stamp == (x.data_ptr(), x._version):
+        if self.input is x and index in self.outputs and self.stamp == self._stamp(x):
             y = self.outputs.pop(index)
             if not self.outputs:
                 self._clear()
@@ -177,7 +184,7 @@ class _SiblingGroup:
                                                  4, 128, [w.shape[0] for w in ws], ws[0].shape[1])
         else:
             ys = torch.ops.quanto.qbytes_mm_multi(x, [w._data for w in ws], [w._scale for w in ws], biases)
-        self.input, self.stamp = x, (x.data_ptr(), x._version)
+        self.input, self.stamp = x, self._stamp(x)
         self.outputs = {i: y for i, y in enumerate(ys) if i != index}
         return ys[index]
 

@@ -1,4 +1,3 @@
 from .conv import *
-from .layernorm import *
 from .linear import *
 from .module import *

@@ -75,12 +75,16 @@ def gather_columns(y_local: torch.Tensor, planes: int, group=None) -> torch.Tens
         return y_local
     y_local = y_local.contiguous()
     lead, n_local = y_local.shape[:-1], y_local.shape[-1]
-    rows = y_local.numel() // max(n_local, 1)
+    rows = 1
+    for d in lead:
+        rows *= d
+    if rows == 0 or n_local == 0:  # nothing to exchange (every rank sees the same leading shape): an empty result of the full width
+        return y_local.new_empty((*lead, world_size * n_local))
     buf = torch.empty((world_size * rows, n_local), dtype=y_local.dtype, device=y_local.device)  # rank-major concatenation
     dist.all_gather_into_tensor(buf, y_local.reshape(rows, n_local), group=group)
     # rank g's columns are `planes` runs of h features: global feature (i, g, c) <- buf[g, ..., i*h + c]
     h = n_local // planes
-    src = buf.reshape(world_size, -1, planes, h).permute(1, 2, 0, 3)
+    src = buf.reshape(world_size, rows, planes, h).permute(1, 2, 0, 3)
     return src.reshape(*lead, world_size * n_local)
 
 

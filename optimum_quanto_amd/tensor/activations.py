@@ -16,9 +16,9 @@ import torch
 from torch.autograd import Function
 
 from .base import QBytesTensor, QTensor, qfallback
-from .dtypes import dtype_info, qint8, qtype, qtypes
+from .dtypes import axis_to_dim, dtype_info, qint8, qtype, qtypes
 
-__all__ = ["ActivationQBytesTensor", "quantize_activation"]
+__all__ = ["ActivationQBytesTensor", "quantize_activation", "absmax_scale"]
 
 aten = torch.ops.aten
 
@@ -205,3 +205,13 @@ def quantize_activation(t: torch.Tensor, qtype: qtype, scale: torch.Tensor):
     if scale.numel() != 1:
         raise ValueError("Parameter scale must be a scalar because activations can only be quantized per-tensor")
     return ActivationQBytesTensor.quantize(t, qtype, scale)
+
+
+def absmax_scale(base: torch.Tensor, qtype: qtype = qint8, axis=None) -> torch.Tensor:
+    """The scale ``quantize_activation`` is called with: max(|base|) / qmax, per tensor (axis=None) or per slice along ``axis``
+    (optimum/quanto/calibrate.py:38-64).  The calibration pass that maintains these scales over sample batches
+    (``Calibration``) is host code outside this backend's scope: in plug-in mode the unmodified reference
+    supplies it; a stand-alone user sets ``module.input_scale`` / ``module.output_scale`` directly."""
+    mag = torch.abs(base)
+    peak = torch.max(mag) if axis is None else torch.amax(mag, dim=axis_to_dim(base, axis), keepdim=True)
+    return peak / dtype_info(qtype.dtype).max

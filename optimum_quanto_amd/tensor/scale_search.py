@@ -13,7 +13,7 @@ import torch
 from .dtypes import qtype
 from .grouping import group
 
-__all__ = ["Optimizer", "SymmetricOptimizer", "AbsmaxOptimizer", "AffineOptimizer", "MaxOptimizer", "HqqOptimizer"]
+__all__ = ["Optimizer", "SymmetricOptimizer", "AbsmaxOptimizer", "AffineOptimizer", "MaxOptimizer"]
 
 
 class Optimizer:
@@ -77,46 +77,3 @@ class MaxOptimizer(AffineOptimizer):
         hi = torch.amax(base, dim=dims, keepdim=True)
         levels = 2**qtype.bits - 1
         return (hi - lo) / levels, -lo
-
-
-def _lp_shrink(residual: torch.Tensor, beta: float, p: float) -> torch.Tensor:
-    """Generalised soft-thresholding of the HQQ paper: sign(r) * max(|r| - |r|^(p-1) / beta, 0)."""
-    mag = torch.abs(residual)
-    cut = 1.0 / beta if p == 1 else (1.0 / beta) * torch.pow(mag, p - 1)
-    return torch.sign(residual) * torch.nn.functional.relu(mag - cut)
-
-
-class HqqOptimizer(MaxOptimizer):
-    """Half-Quadratic Quantization (Badri & Shaji, https://mobiusml.github.io/hqq_blog/): starting from the min/max range,
-    the shift is refined by alternating an lp-shrinkage of the quantization residual with a closed-form update of the shift,
-    as long as the mean absolute error keeps falling (reference: tensor/optimizers/hqq_optimizer.py:36-91; same defaults, same
-    stopping rule - the results are compared bit for bit in tests/test_reference_integration.py)."""
-
-    def __init__(self, lp_norm: Optional[float] = 0.7, beta: Optional[int] = 1e1, kappa: Optional[float] = 1.01,
-                 iters: Optional[int] = 20, verbose: Optional[bool] = False) -> None:
-        self.lp_norm, self.beta, self.kappa, self.iters, self.verbose = lp_norm, beta, kappa, iters, verbose
-
-    def optimize(self, base, qtype, axis):
-        from .weights import quantize_weight  # (weights imports this module)
-
-        scale, shift = super().optimize(base, qtype, axis)
-        along = 0 if axis == -1 else -1  # the dimension a scale / shift entry is shared over
-        beta = self.beta
-        candidate = quantize_weight(base, qtype=qtype, axis=axis, scale=scale, shift=shift)
-        best = None
-        for it in range(self.iters):
-            residual = base - candidate
-            if best is None:
-                best = float(torch.abs(base - candidate).mean())
-                if self.verbose:
-                    print(f"Start error: {best:.6f}")
-            kept = _lp_shrink(residual, beta, self.lp_norm)
-            trial = torch.mean(candidate._data * scale - (base - kept), axis=along, keepdim=True)
-            candidate = quantize_weight(base, qtype=qtype, axis=axis, scale=scale, shift=trial)
-            err = float(torch.abs(base - candidate).mean())
-            if self.verbose:
-                print(f"HQQ error at it #{it}: {err:.6f}")
-            if err >= best:
-                break
-            best, shift, beta = err, trial, beta * self.kappa
-        return scale, shift

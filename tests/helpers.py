@@ -100,3 +100,33 @@ def assert_similar(a: torch.Tensor, b: torch.Tensor, atol=None, rtol=None):
     sim = torch.nn.functional.cosine_similarity(a.flatten().float(), b.flatten().float(), dim=0)
     assert torch.allclose(sim, torch.tensor(1.0, dtype=sim.dtype, device=sim.device), atol=atol, rtol=rtol), \
         f"alignment {float(sim):.8f} deviates from 1"
+
+
+class observed_activation_scales:
+    """Test stand-in for a calibration pass (the reference's ``Calibration`` is host code outside this backend's scope; plug-in mode
+    uses the reference's own).  While active, every quantized module with quantized activations takes ``input_scale`` /
+    ``output_scale`` = the absmax scale of the tensor it just saw (last batch wins, no running average)."""
+
+    def __enter__(self):
+        from torch.nn.modules.module import register_module_forward_hook, register_module_forward_pre_hook
+
+        import optimum_quanto_amd as Q
+
+        def wanted(m):
+            return isinstance(m, Q.QModuleMixin) and m.activation_qtype is not None
+
+        def before(m, args):  # global hooks run before the module's own quantize_input / quantize_output hooks
+            if wanted(m):
+                x = args[0]
+                m.input_scale = (torch.max(x._scale) if isinstance(x, Q.ActivationQBytesTensor) else Q.absmax_scale(x, m.activation_qtype)).to(m.input_scale.dtype)
+
+        def after(m, args, out):
+            if wanted(m):
+                m.output_scale = Q.absmax_scale(out, m.activation_qtype).to(m.output_scale.dtype)
+
+        self.handles = [register_module_forward_pre_hook(before), register_module_forward_hook(after)]
+        return self
+
+    def __exit__(self, *exc):
+        for h in self.handles:
+            h.remove()

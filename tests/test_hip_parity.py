@@ -368,6 +368,20 @@ def test_qbits_auto_picks_fast_kernels():
     assert quanto_hip.lib.last_kernel() == "dequant_mfma"
 
 
+def _assert_reference_output(y, want, dt, what):
+    """Gate against the REFERENCE's own outputs (golden vectors), as opposed to exact math.
+
+    fp32 cases are SURVEY 8c gate G2 / the north star's "<= 1e-3 rel vs the CPU reference": relative Frobenius and relative max
+    error <= 1e-3 (measured ~1e-6: both sides accumulate the same fp32 products in a different order).  For bf16 / fp16 the
+    reference's own output is several 1e-3 away from exact math (it rounds the dequantized weight to the 16-bit type),
+    so those keep the reference's test tolerance (tests/tensor/weights/weight_helpers.py:33-37, rel-max < 2e-2)."""
+    yd, wd = y.double(), want.double()
+    rel_max = ((yd - wd).abs().max() / wd.abs().max()).item()
+    rel_fro = ((yd - wd).norm() / wd.norm()).item()
+    tol = 1e-3 if dt == "fp32" else 2e-2
+    assert rel_max <= tol and rel_fro <= tol, f"{what}: rel_max={rel_max:.3e} rel_fro={rel_fro:.3e} (gate {tol:g})"
+
+
 def test_qbits_golden_linear(golden):
     """F.linear on weights moved to the device reproduces the reference outputs within its own test tolerance."""
     for tag in ["int4_g128_fp16", "int4_g128_bf16", "int4_g128_bf16_bias", "int4_g128_fp16_zp", "int2_g128_bf16",
@@ -387,8 +401,7 @@ def test_qbits_golden_linear(golden):
             y = torch.nn.functional.linear(to_torch(golden[key], dt, DEV), qw, bias)
             want = to_torch(golden[k + f"/y{M}"], dt, DEV)
             assert_similar(want, y)
-            err = (y.float() - want.float()).abs().max() / want.float().abs().max()
-            assert err < 2e-2  # tests/tensor/weights/weight_helpers.py:33-37 (cuda tolerance)
+            _assert_reference_output(y, want, dt, f"{tag} M={M}")
 
 
 # ------------------------------------------------------------------------------------------------ qbytes_mm
@@ -560,7 +573,7 @@ def test_qbytes_golden_linear(golden):
             y = torch.nn.functional.linear(to_torch(golden[key], dt, DEV), qw, bias)
             want = to_torch(golden[k + f"/y{M}"], dt, DEV)
             assert_similar(want, y)
-            assert (y.float() - want.float()).abs().max() / want.float().abs().max() < 2e-2
+            _assert_reference_output(y, want, dt, f"{tag} M={M}")
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE sizes

@@ -169,6 +169,25 @@ def test_sibling_group_drops_parked_outputs_when_the_input_changes_in_place():
     assert torch.equal(got, k_after) and not torch.equal(got, k_before)
 
 
+def test_sibling_group_under_inference_mode():
+    """Inference tensors track no version counter (reading ``_version`` raises): the fused launch must still engage, serve the
+    parked outputs to the siblings and agree with the unfused modules."""
+    model, cfg = _tiny_llama("cpu")
+    attn = model.model.layers[0].self_attn
+    with torch.inference_mode():
+        x = torch.randn(1, 1, cfg.hidden_size).to(torch.bfloat16)
+        assert x.is_inference()
+        want = [attn.q_proj(x), attn.k_proj(x), attn.v_proj(x)]
+        Q.fuse_decode_projections(model)
+        _force_engage(model)
+        q = attn.q_proj(x)
+        assert set(attn.q_proj._sibling_group.outputs) == {1, 2}
+        got = [q, attn.k_proj(x), attn.v_proj(x)]
+        assert attn.q_proj._sibling_group.outputs == {}
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+
+
 def test_sibling_group_leaves_gradients_to_the_members():
     model, cfg = _tiny_llama("cpu")
     Q.fuse_decode_projections(model)

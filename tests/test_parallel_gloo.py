@@ -31,9 +31,13 @@ def _worker(rank, world, port, weights, dtype, out):
             sharded = ColumnParallelQLinear.from_qlinear(model[0])
             assert sharded.weight.shape == (128 // world, 256)
             y = sharded(x)
-        assert y.shape == ref.shape
-        err = (y.float() - ref.float()).abs().max().item() / ref.float().abs().max().item()
-        out[rank] = err
+            empty = sharded(x[:0])  # an empty activation keeps the full output width (no collective is needed for it)
+        assert y.shape == ref.shape and empty.shape == (0, ref.shape[1])
+        # the shard is a pure slice of the same integers and scales (test_shard_layout_is_a_pure_slice): the only freedom left is
+        # the CPU GEMM's summation order for a different N.  Distance in units of the output dtype's last place at each element
+        yf, rf = y.double(), ref.double()
+        ulp = torch.finfo(dtype).eps * torch.maximum(rf.abs(), torch.full_like(rf, torch.finfo(dtype).tiny)) 
+        out[rank] = ((yf - rf).abs() / ulp).max().item() if not torch.equal(y, ref) else 0.0
     finally:
         dist.destroy_process_group()
 
@@ -45,7 +49,9 @@ def test_column_shard_matches_unsharded(weights, dtype):
     port = _free_port()
     out = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(world, port, weights, dtype, out), nprocs=world, join=True)
-    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    # fp32: bit-identical or within a few last places of the fp32 sum (a different blocking of the same dot products);
+    # bf16: at most one last place of the rounded output
+    tol = 4.0 if dtype == torch.float32 else 1.0
     assert len(out) == world and all(e <= tol for e in out.values()), dict(out)
 
 

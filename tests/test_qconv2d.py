@@ -14,7 +14,7 @@ from optimum_quanto_amd.tensor.weights import conv2d_patches
 
 from oracle import quanto_oracle as O
 
-from helpers import TORCH_DT, assert_close_to_exact, assert_close_with_bias, assert_similar, to_numpy, to_torch
+from helpers import TORCH_DT, assert_close_to_exact, assert_close_with_bias, assert_similar, observed_activation_scales, to_numpy, to_torch
 
 QTYPES = {"int8": "qint8", "int4": "qint4", "e4m3fn": "qfloat8_e4m3fn"}
 CONVS = {"c16k3": (16, 32, 3, 1, 1), "c32k3s2": (32, 24, 3, 2, 0), "c64k1": (64, 48, 1, 1, 0)}
@@ -95,17 +95,6 @@ def test_qconv2d_quantize_freeze_state_dict_roundtrip():
     torch.testing.assert_close(fresh(x), y, rtol=0, atol=0)
 
 
-def test_qlayernorm_only_with_quantized_activations():
-    ln = torch.nn.LayerNorm(32)
-    assert Q.QLayerNorm.from_module(ln, weights=Q.qint8) is None  # nn/qlayernorm.py:38-39
-    q = Q.QLayerNorm.from_module(ln, activations=Q.qint8)
-    assert isinstance(q, Q.QLayerNorm) and q.weight_qtype is None
-    x = torch.randn(4, 32)
-    y = q(x)
-    assert isinstance(y, Q.ActivationQBytesTensor)  # output quantized with output_scale = 1
-    torch.testing.assert_close(y.dequantize(), torch.round(ln(x)).clamp(-127, 127))
-
-
 # ------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,cname,dt", CASES)
@@ -163,16 +152,17 @@ def test_qconv2d_grouped_convolution_keeps_reference_behaviour_gpu():
 
 
 def test_conv_model_with_quantized_activations_calibrates_and_runs():
-    """quantize(weights=qint8, activations=qint8) on a small conv net: QConv2d / QLayerNorm / QLinear are created, a
-    Calibration pass sets the activation scales (calibrate.py), the frozen model stays close to the float model."""
+    """quantize(weights=qint8, activations=qint8) on a small conv net: QConv2d / QLinear are created (LayerNorm stays a float
+    module: its quantized twin is outside this backend's scope), activation scales are set from one observed batch, the frozen
+    model stays close to the float model."""
     torch.manual_seed(0)
     model = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(16, 4, 3), torch.nn.Flatten(),
                                 torch.nn.LayerNorm(4 * 6 * 6), torch.nn.Linear(4 * 6 * 6, 10))
     x = torch.randn(2, 8, 8, 8)
     ref = model(x)
     Q.quantize(model, weights=Q.qint8, activations=Q.qint8)
-    assert [type(layer).__name__ for layer in model] == ["QConv2d", "ReLU", "QConv2d", "Flatten", "QLayerNorm", "QLinear"]
-    with torch.no_grad(), Q.Calibration():
+    assert [type(layer).__name__ for layer in model] == ["QConv2d", "ReLU", "QConv2d", "Flatten", "LayerNorm", "QLinear"]
+    with torch.no_grad(), observed_activation_scales():
         model(x)
     assert float(model[0].output_scale) != 1.0 and float(model[5].input_scale) != 1.0
     Q.freeze(model)

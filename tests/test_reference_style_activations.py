@@ -6,7 +6,7 @@ import torch
 
 import optimum_quanto_amd as Q
 
-from helpers import assert_similar
+from helpers import assert_similar, observed_activation_scales
 
 DEVICES = [pytest.param("cpu", id="cpu"), pytest.param("cuda", id="cuda", marks=pytest.mark.gpu)]
 F8 = [Q.qfloat8_e5m2, Q.qfloat8_e4m3fn]
@@ -87,7 +87,7 @@ def test_calibrate_qlinear(batch, tokens, emb, use_bias, activations, device):
     with torch.no_grad():
         qlinear(qin)
     assert torch.all(qlinear.input_scale == 1) and torch.all(qlinear.output_scale == 1)  # nothing calibrates outside the mode
-    with torch.no_grad(), Q.Calibration():
+    with torch.no_grad(), observed_activation_scales():
         qout = qlinear(qin)
     assert qout.qtype == activations
     assert torch.any(qlinear.input_scale != 1) and torch.any(qlinear.output_scale != 1)
@@ -107,7 +107,7 @@ def test_calibrate_two_chained_qlinears(activations, device):
     model = Two().to(device)
     model.linear1 = Q.QLinear.from_module(model.linear1, weights=Q.qint8, activations=activations)
     model.linear2 = Q.QLinear.from_module(model.linear2, weights=Q.qint8, activations=activations)
-    with torch.no_grad(), Q.Calibration():
+    with torch.no_grad(), observed_activation_scales():
         qout = model(rand_qact((1, 10, 32), qtype=activations, device=device))
     for m in (model.linear1, model.linear2):
         assert torch.any(m.input_scale != 1) and torch.any(m.output_scale != 1)
@@ -127,7 +127,7 @@ def test_quantize_linear_with_activations(batch, tokens, emb, dtype, weights, ac
     qlinear = Q.QLinear.from_module(linear, weights=weights, activations=activations)
     assert qlinear.qweight.qtype == weights
     x = rand((batch, tokens, emb), dtype, device)
-    with torch.no_grad(), Q.Calibration():
+    with torch.no_grad(), observed_activation_scales():
         qlinear(x)
     Q.freeze(qlinear)
     with torch.no_grad():
