@@ -30,7 +30,25 @@ when ``--gpus N`` is given with no launcher around it, from bench.py itself (it 
 column-sharded over the ranks with ``ColumnParallelQLinear``, compute-only and compute + ``all_gather_into_tensor`` (RCCL over xGMI),
 ``"scaling": "strong"`` - SURVEY.md 8(e); ``--shard`` makes that the headline line instead.
 
-The printed line is kept under ~6 KB (the driver keeps an 8 KB stdout tail): sub-results are compact records (name, shape, us,
+Round 4 additions to the default line (all measured in the same process / on the same box as the headline):
+  * ``roofline.frac`` is computed from the SAME host-bracketed time as ``value`` (``ms_per_step``); the device-event time of the same
+    replay is ``event_us`` (r3 divided by the event time: 0.5544 next to a value that said 0.548);
+  * ``kernel_us`` / ``kernel_us_min``: kernel-only duration from a ``rocprofv3 --kernel-trace`` pass of this same file (a child
+    process, ``--trace-child``), next to the launch-inclusive ``us_per_step``; ``traffic`` = fabric bytes per step from two more child
+    passes (``--pmc FETCH_SIZE`` / ``--pmc WRITE_SIZE``, corrected as MI355X_MICROARCH.md prescribes); when rocprofv3 is not usable the
+    committed ``profiles/pmc_*.json`` figure is reported with ``traffic_stale: true``;
+  * ``ref_rocm_us``: the op sequence the UNMODIFIED reference issues for the same call on a ROCm device (elementwise dequantize +
+    hipBLASLt: library/qbytes_mm.py:25-33,73-88; library/unpack.py:21-54 + tensor/qbits.py:27-49 + tensor/function.py:41-47), timed
+    with the same graph / ramp discipline on the same tensors;
+  * ``layer_decode`` records: the seven int4 QLinears of one Llama-3-8B layer as the FOUR launches the product issues at decode time
+    (q/k/v in one, o, gate/up in one, down), > 512 MB of layer weights rotated, B = 1 and B = 32: sum of us, algorithmic bytes, layer-level
+    HBM fraction, kernel-only sum, and the same sequence with the next launch's weights prefetched into the Infinity Cache from a side
+    stream (``quanto_hip_prefetch``) - labelled as such;
+  * ``cfg5``: BASELINE configs[4] end to end - Llama-3-8B random-init bf16, weights=qint4 with lm_head excluded, the reference's
+    method (bench/generation/metrics/latency.py:24-105: ``generate`` 512 prompt + 512 new tokens, greedy, eos disabled), tokens/s at
+    batch 1 and batch 32 (``--no-cfg5`` skips it).
+
+The printed line is kept under ~7.5 KB (the driver keeps an 8 KB stdout tail): sub-results are compact records (name, shape, us,
 kernel, fraction, algorithmic bytes / flops, counter traffic, CPU seconds), the prose that explains the CPU paths is printed once
 (``cpu_paths``); ``--verbose`` prints every sub-result in full on stderr.
 """
@@ -93,7 +111,8 @@ WORKLOADS = {
     "int4_decode1_down": ("qbits_i4", 1, 14336, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, decode (M,K,N)=(1,14336,4096) (Llama-3-8B down_proj)"),
     "int4_decode32_up": ("qbits_i4", 32, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,14336)"),
 }
-DEFAULT_SUB = ["northstar", "cfg3", "cfg4", "qkv_fused", "gateup_fused", "int4_decode32", "qkv_fused32", "int8_gateup_fused", "int4_prefill512"]
+DEFAULT_SUB = ["northstar", "cfg3", "cfg4", "qkv_fused", "gateup_fused", "int4_decode32", "qkv_fused32", "int8_gateup_fused", "int4_prefill512",
+               "layer_decode_b1", "layer_decode_b32"]
 # printed ONCE per JSON line (r2's line repeated this prose in every sub-result, grew past the driver's 8 KB stdout tail and lost
 # its first two sub-results): what cpu_baseline.kind == "reference" and each cpu_baseline.path code stand for
 CPU_BASELINE_NOTE = {
@@ -218,6 +237,85 @@ def make_step(kind, x, sets, K, N):
     return step
 
 
+REF_ROCM_FOR = ("cfg2", "cfg3", "northstar", "cfg4", "int4_prefill", "int4_prefill512")
+
+
+def make_ref_rocm_step(kind, x, wset, K, N):
+    """What the UNMODIFIED reference executes for this call on a ROCm device (it has no fused kernel there: only ``unpack`` is
+    native, library/extensions/hip/__init__.py:25-36): dequantize the whole weight elementwise, then a dense hipBLASLt matmul.
+    8-bit: library/qbytes_mm.py:25-33 (reached from :73-88 for float activations).  4-bit: quanto::unpack (library/unpack.py:21-54:
+    mask, shift, cat - the reference's one-pass HIP unpack kernel yields the same tensor), ``scale * data``, ``-= shift``
+    (tensor/qbits.py:41-45), ungroup = reshape for axis 0 (tensor/grouped.py:39-44), matmul (tensor/function.py:44)."""
+    if kind == "qbits_i4":
+        packed, scale, shift = wset
+
+        def step():
+            data = torch.cat([packed & 0x0F, (packed & 0xF0) >> 4]).to(torch.uint8)
+            dqt = scale * data
+            dqt -= shift
+            return torch.matmul(x, dqt.reshape(N, K).t())
+    else:
+        w, scale = wset
+
+        def step():
+            a = x.to(scale.dtype)
+            ww = w.to(scale.dtype) if w.dtype.is_floating_point else w
+            return torch.matmul(a, (scale * ww).t())
+    return step
+
+
+def timed_replay(step, steps, args, dist, device, warmup=None):
+    """W untimed warm-up steps, the K steps captured in ONE hipGraph (or issued eagerly with --eager), the clock ramp, then the
+    timed region: barrier + synchronize on both sides, host clock around it and a device-event pair on the launch stream inside it;
+    max over ranks.  Returns (elapsed_s, event_ms)."""
+    for _ in range(args.warmup if warmup is None else warmup):
+        step()
+    torch.cuda.synchronize()
+    graph = None
+    if not args.eager:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(steps):
+                    step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()  # untimed: uploads the executable graph
+        torch.cuda.synchronize()
+
+    def run():
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(steps):
+                step()
+
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+        run()
+        torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        tt = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms = float(tt[0]), float(tt[1])
+    del graph
+    return elapsed, dev_ms
+
+
 def cpu_baseline(kind, M, K, N, x, wset, budget_s):
     """The reference's CPU path (ATen kernels, reference order) on the full shape and the very tensors the GPU just used."""
     from oracle import reference_cpu_path as R
@@ -268,56 +366,16 @@ def run_workload(name, args, device, rank, world, dist, steps, with_cpu):
     x, sets = build_inputs(kind, M, K, N, device, n_weights, seed=1234 + rank)
     step = make_step(kind, x, sets, K, N)
 
-    for _ in range(args.warmup):
-        step()
+    step()
     torch.cuda.synchronize()
     kernel_name = lib.last_kernel()
-    graph = None
-    if not args.eager:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                for _ in range(steps):
-                    step()
-        torch.cuda.current_stream().wait_stream(side)
-        graph.replay()  # untimed: uploads the executable graph
-        torch.cuda.synchronize()
-    t_ramp = time.perf_counter()
-    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
-        if graph is not None:
-            graph.replay()
-        else:
-            for _ in range(steps):
-                step()
-        torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(steps):
-            step()
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    if dist is not None:
-        tt = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(tt[0]), float(tt[1])
+    elapsed, dev_ms = timed_replay(step, steps, args, dist, device)
     if rank != 0:
         return None
 
     ms_per_step = elapsed * 1e3 / steps
-    launch_ms = dev_ms / steps  # device-side average per launch (events on the launch stream)
+    launch_ms = ms_per_step     # the roofline fraction uses the SAME time as `value` (host clock around barrier + synchronize) ...
+    event_ms = dev_ms / steps   # ... the device-event pair inside that region is reported next to it (event_us)
     compute_bound = M > 64
     if compute_bound:
         value = flops * world / (elapsed / steps) / 1e12
@@ -334,12 +392,15 @@ def run_workload(name, args, device, rank, world, dist, steps, with_cpu):
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
     roof["kernel"] = kernel_name
     roof["launch_us"] = round(launch_ms * 1e3, 3)
+    roof["event_us"] = round(event_ms * 1e3, 3)
+    roof["kernel_us"] = roof["kernel_us_min"] = None  # kernel-only duration: filled from the rocprofv3 kernel-trace child pass
     roof["algorithmic_bytes"] = nbytes
     roof["algorithmic_flops"] = flops
     pmc = os.path.join(ROOT, "profiles", f"pmc_{name}.json")
     if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (profiles/README.md)
         rec = json.load(open(pmc))
         roof["traffic"] = rec.get("hbm_bytes_per_launch")
+        roof["traffic_stale"] = True  # replaced by this run's own counter passes when rocprofv3 is usable (apply_profile)
         roof["traffic_source"] = f"profiles/pmc_{name}.json ({rec.get('round', 'r01')} builder-run rocprofv3 --pmc passes, not this run)"
     out = {
         "metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -352,9 +413,14 @@ def run_workload(name, args, device, rank, world, dist, steps, with_cpu):
         "gbps": round(nbytes * world / (elapsed / steps) / 1e9, 1),
         "roofline": roof,
     }
+    if name in REF_ROCM_FOR and not args.no_ref_rocm:
+        ref_step = make_ref_rocm_step(kind, x, sets[0], K, N)
+        with torch.no_grad():
+            r_elapsed, _ = timed_replay(ref_step, 10 if M > 64 else 20, args, None, device, warmup=2)
+        out["ref_rocm_us"] = round(r_elapsed * 1e6 / (10 if M > 64 else 20), 2)
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(kind, M, K, N, x, sets[0], args.cpu_budget)
-    del sets, graph
+    del sets
     torch.cuda.empty_cache()
     return out
 
@@ -440,13 +506,297 @@ def run_stub(args, rank, world, dist):
             "vs_baseline": None, "dtype": "f32", "data": "stub", "config": {"workload": "CPU stub over gloo (test only)"}}
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# One Llama-3-8B decoder layer at decode time: the seven int4 QLinears as the FOUR launches the product issues
+# ------------------------------------------------------------------------------------------------------------------------
+LAYER_LAUNCHES = (("qkv", "qbits_i4_multi", 4096, LLAMA3_QKV), ("o", "qbits_i4", 4096, 4096),
+                  ("gate_up", "qbits_i4_multi", 4096, LLAMA3_GATE_UP), ("down", "qbits_i4", 14336, 4096))
+LAYER_WORKLOADS = {"layer_decode_b1": 1, "layer_decode_b32": 32}
+
+
+def layer_algorithmic_bytes(B):
+    return sum(algorithmic_work(kind, B, K, N)[1] for _, kind, K, N in LAYER_LAUNCHES)
+
+
+def build_layer(B, device, seed):
+    """Weights of ONE layer per rotation set (109 MB of int4 + scales), enough sets for > 512 MB; the four inputs are independent
+    random activations (the ops between the Linears - attention, norms, SiLU - are the model's, not this library's)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    rnd = lambda *shape: torch.randn(shape, generator=g, device=device, dtype=torch.float32)  # noqa: E731
+    layer_bytes = sum((sum(N) if isinstance(N, tuple) else N) * K // 2 for _, _, K, N in LAYER_LAUNCHES)
+    nsets = max(1, -(-(512 << 20) // layer_bytes))
+    xs = [rnd(B, K).to(torch.bfloat16).contiguous() for _, _, K, _ in LAYER_LAUNCHES]
+    sets = []
+    for _ in range(nsets):
+        one = []
+        for _, kind, K, N in LAYER_LAUNCHES:
+            Ns = N if isinstance(N, tuple) else (N,)
+            one.append([quantize_int4((rnd(n, K) * 0.02).to(torch.bfloat16).float()) for n in Ns])
+        sets.append(one)
+    return xs, sets
+
+
+def make_layer_step(xs, sets, prefetch_stream=None, prefetch_wgs=0):
+    """One decode step of the layer: q/k/v (one launch), o, gate/up (one launch), down.  With ``prefetch_stream``: while launch j
+    runs, that stream touches the weights of launch j + 1 (the next layer's q/k/v behind ``down``) - quanto_hip_prefetch."""
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    lib = quanto_hip.lib
+    state = {"i": 0}
+    none = {1: [None], 2: [None] * 2, 3: [None] * 3}
+
+    def tensors_of(members):
+        return [t for m in members for t in m]
+
+    def step():
+        i = state["i"]
+        state["i"] += 1
+        cur, nxt = sets[i % len(sets)], sets[(i + 1) % len(sets)]
+        main = torch.cuda.current_stream()
+        for j, (_, kind, K, N) in enumerate(LAYER_LAUNCHES):
+            if prefetch_stream is not None:
+                target = cur[j + 1] if j + 1 < len(LAYER_LAUNCHES) else nxt[0]
+                prefetch_stream.wait_stream(main)  # starts once launch j - 1 is done, i.e. together with launch j
+                lib.prefetch(*tensors_of(target), workgroups=prefetch_wgs, stream=prefetch_stream)
+            m = cur[j]
+            if kind == "qbits_i4_multi":
+                torch.ops.quanto.qbits_mm_multi(xs[j], [p for p, _, _ in m], [sc for _, sc, _ in m], [sh for _, _, sh in m], none[len(m)], 4, 128,
+                                                list(N), K)
+            else:
+                p, sc, sh = m[0]
+                torch.ops.quanto.qbits_mm(xs[j], p, sc, sh, None, 4, 128, N, K)
+        if prefetch_stream is not None:
+            main.wait_stream(prefetch_stream)  # join (a captured side branch must rejoin; costs nothing: the touch kernel is done long before)
+    return step
+
+
+def run_layer_decode(name, args, device, rank, world, dist, steps):
+    B = LAYER_WORKLOADS[name]
+    xs, sets = build_layer(B, device, seed=4321 + rank)
+    nbytes = layer_algorithmic_bytes(B)
+    with torch.no_grad():
+        elapsed, dev_ms = timed_replay(make_layer_step(xs, sets), steps, args, dist, device)
+        pre = None
+        if not args.no_prefetch:
+            try:
+                ps = torch.cuda.Stream(priority=0)
+                p_elapsed, _ = timed_replay(make_layer_step(xs, sets, ps, args.prefetch_wgs), steps, args, dist, device)
+                pre = p_elapsed * 1e6 / steps
+            except Exception as e:  # a side-stream capture problem must not take the plain record down
+                pre = f"error: {repr(e)[:120]}"
+    if rank != 0:
+        return None
+    us = elapsed * 1e6 / steps
+    out = {"name": name, "B": B, "launches": [n for n, _, _, _ in LAYER_LAUNCHES], "us_per_layer": round(us, 3), "event_us": round(dev_ms * 1e3 / steps, 3),
+           "alg_bytes": int(nbytes), "GBs": round(nbytes * world / us / 1e3, 1), "bound": "hbm", "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
+           "rot": len(sets), "steps": steps, "kernel_us": None, "kernel_us_min": None, "traffic": None}
+    if isinstance(pre, float):
+        out["prefetch_us_per_layer"] = round(pre, 3)
+        out["prefetch_frac"] = round(nbytes / pre / 1e3 / HBM_PEAK_GBS, 4)
+    elif pre is not None:
+        out["prefetch_us_per_layer"] = pre
+    del sets
+    torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: Llama-3-8B random-init, weights=qint4 with lm_head excluded, end-to-end tokens/s at batch 1 and 32
+# ------------------------------------------------------------------------------------------------------------------------
+def run_cfg5(args, device, batches=(1, 32), prompt=512, new=512):
+    """The reference's method, call for call (bench/generation/metrics/latency.py:24-105): ``model.generate`` with
+    ``max_new_tokens = min_new_tokens = 512``, greedy, eos disabled, a random 512-token prompt and an all-ones mask; device events
+    around the whole call (prefill inside the figure, as in the reference); one timed call per batch size after a short warm-up call.
+    The model is created from a config on the device (no network), quantized and frozen by this package
+    (``QuantizedModelForCausalLM.quantize(weights=qint4, exclude="lm_head")``), sibling projections share launches
+    (``fuse_decode_projections``)."""
+    from transformers import GenerationConfig, LlamaConfig, LlamaForCausalLM
+
+    import optimum_quanto_amd as Q
+
+    t0 = time.perf_counter()
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
+                      vocab_size=128256, max_position_embeddings=8192, rope_theta=500000.0, tie_word_embeddings=False)
+    torch.manual_seed(0)
+    with torch.device(device):
+        model = LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+    Q.QuantizedModelForCausalLM.quantize(model, weights="qint4", exclude="lm_head")
+    linked = Q.fuse_decode_projections(model)
+    torch.cuda.synchronize()
+    out = {"name": "cfg5", "model": "Llama-3-8B random-init bf16, qint4 g128, lm_head excluded", "prompt": prompt, "new_tokens": new,
+           "method": "generate(), greedy, eos off, prefill included (latency.py:24-105)", "fused_groups": linked,
+           "build_s": round(time.perf_counter() - t0, 1), "int4_bytes_per_token": 32 * sum((sum(N) if isinstance(N, tuple) else N) * (K // 2 + K // 128 * 4) for _, _, K, N in LAYER_LAUNCHES)}
+    if getattr(model, "generation_config", None) is not None:
+        model.generation_config.eos_token_id = None
+    with torch.no_grad():
+        for b in batches:
+            try:
+                ids = torch.randint(1, cfg.vocab_size - 1, size=(b, prompt)).to(device)
+                mask = torch.ones(b, prompt, dtype=torch.int32).to(device)
+                warm = GenerationConfig(max_new_tokens=4, min_new_tokens=4, use_cache=True, pad_token_id=0, num_beams=1, do_sample=False, eos_token_id=None)
+                model.generate(ids, attention_mask=mask, generation_config=warm)
+                gen = GenerationConfig(max_new_tokens=new, min_new_tokens=new, use_cache=True, pad_token_id=0, num_beams=1, do_sample=False, eos_token_id=None)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                res = model.generate(ids, attention_mask=mask, generation_config=gen)
+                e1.record()
+                torch.cuda.synchronize()
+                assert res.shape[1] == prompt + new
+                ms = e0.elapsed_time(e1)
+                out[f"b{b}_tok_s"] = round(b * new / (ms * 1e-3), 1)
+                out[f"b{b}_ms_per_token"] = round(ms / new, 3)
+            except Exception as e:
+                out[f"b{b}_error"] = repr(e)[:160]
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# rocprofv3 child passes: kernel-only durations and fabric traffic measured by THIS run (not copied from profiles/)
+# ------------------------------------------------------------------------------------------------------------------------
+MARKER = "prefetch_touch_kernel"  # one launch of the library's own touch kernel separates the workloads in a trace
+TRACE_STEPS = 12
+
+
+def trace_child(names, args, device):
+    """``--trace-child``: run under rocprofv3.  Every workload: marker launch, 3 + TRACE_STEPS eager steps, synchronize."""
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    lib = quanto_hip.lib
+    tag = torch.zeros(64, dtype=torch.uint8, device=device)
+    for name in names:
+        if name in LAYER_WORKLOADS:
+            xs, sets = build_layer(LAYER_WORKLOADS[name], device, seed=4321)
+            step = make_layer_step(xs, sets)
+        else:
+            kind, M, K, N, _ = WORKLOADS[name]
+            Nt = sum(N) if isinstance(N, tuple) else N
+            wb = Nt * K // 2 if kind.startswith("qbits") else Nt * K
+            n_weights = max(1, -(-(512 << 20) // wb)) if M <= 64 else 1
+            x, sets = build_inputs(kind, M, K, N, device, min(n_weights, 3 + TRACE_STEPS), seed=1234)
+            step = make_step(kind, x, sets, K, N)
+        torch.cuda.synchronize()
+        lib.prefetch(tag)
+        with torch.no_grad():
+            for _ in range(3 + TRACE_STEPS):
+                step()
+        torch.cuda.synchronize()
+        del sets, step
+        torch.cuda.empty_cache()
+    lib.prefetch(tag)
+    torch.cuda.synchronize()
+
+
+def _rocprof_pass(names, mode, timeout_s):
+    """One child run of this file under rocprofv3 (``mode``: "trace" = --kernel-trace, or a counter name for --pmc).  Returns the
+    per-dispatch rows [(kernel_name, start_ns, end_ns, counter_value or None)] in dispatch order, or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    out_dir = tempfile.mkdtemp(prefix="qh_bench_prof_", dir="/tmp")
+    flags = ["--kernel-trace"] if mode == "trace" else ["--pmc", mode]
+    cmd = [exe, *flags, "--output-format", "csv", "-d", out_dir, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--trace-child", *names]
+    env = dict(os.environ, TMPDIR="/tmp", QH_BENCH_CHILD="1")
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, capture_output=True)
+        pat = "*kernel_trace.csv" if mode == "trace" else "*counter_collection.csv"
+        files = glob.glob(os.path.join(out_dir, "**", pat), recursive=True)
+        if not files:
+            return None
+        rows = []
+        for r in csv.DictReader(open(files[0])):
+            val = float(r["Counter_Value"]) if mode != "trace" else None
+            rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), val))
+        rows.sort()
+        return [(k, a, b, v) for _, k, a, b, v in rows]
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def _segments(rows, names):
+    """Split the dispatch list at the marker launches: segment i belongs to names[i]; only the library's kernels (qh::) are kept."""
+    segs, cur = [], None
+    for k, a, b, v in rows:
+        if MARKER in k:
+            if cur is not None:
+                segs.append(cur)
+            cur = []
+        elif cur is not None and "qh::" in k:
+            cur.append((k, a, b, v))
+    return dict(zip(names, segs)) if len(segs) == len(names) else None
+
+
+def collect_profiles(names, timeout_s=240):
+    """kernel-only us per step (average and sum-of-minima over the kernels a step launches) and fabric bytes per step for every
+    workload in ``names``; {} when rocprofv3 cannot be used here (the caller then keeps the committed figures, marked stale)."""
+    if os.environ.get("QH_BENCH_CHILD"):
+        return {}
+    res = {}
+    trace = _rocprof_pass(names, "trace", timeout_s)
+    segs = _segments(trace, names) if trace else None
+    if segs:
+        for n, seg in segs.items():
+            per_step = len(seg) // (3 + TRACE_STEPS)
+            if per_step == 0:
+                continue
+            timed = seg[3 * per_step:(3 + TRACE_STEPS) * per_step]
+            by_slot = [[(b - a) / 1e3 for (_, a, b, _) in timed[j::per_step]] for j in range(per_step)]  # slot j of a step over the steps
+            res[n] = {"kernel_us": round(sum(sum(v) / len(v) for v in by_slot), 3), "kernel_us_min": round(sum(min(v) for v in by_slot), 3),
+                      "kernels_per_step": per_step}
+    traffic = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        rows = _rocprof_pass(names, counter, timeout_s)
+        segs = _segments(rows, names) if rows else None
+        if not segs:
+            return res
+        for n, seg in segs.items():
+            per_step = len(seg) // (3 + TRACE_STEPS)
+            if per_step:
+                timed = seg[3 * per_step:(3 + TRACE_STEPS) * per_step]
+                traffic.setdefault(n, {})[counter] = sum(v for *_, v in timed) / TRACE_STEPS  # KB per step
+    for n, t in traffic.items():
+        if len(t) == 2:
+            # gfx950: FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes -> x 2 (MI355X_MICROARCH.md, HBM section)
+            res.setdefault(n, {})["traffic"] = int(t["FETCH_SIZE"] * 1024 * 2 + t["WRITE_SIZE"] * 1024)
+    return res
+
+
+def apply_profile(rec, prof, compacted):
+    """Fill kernel_us / traffic of a result from this run's own rocprofv3 passes."""
+    if not prof:
+        return
+    roof = rec if compacted else rec["roofline"]
+    for k in ("kernel_us", "kernel_us_min"):
+        if k in prof:
+            roof[k] = prof[k]
+    if "traffic" in prof:
+        roof["traffic"] = prof["traffic"]
+        roof.pop("traffic_stale", None)
+        if not compacted:
+            roof["traffic_source"] = "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of bench.py (eager, same inputs), FETCH x2 (gfx950)"
+
+
 def compact(r):
     """A sub-result in ~300 bytes: everything the reader needs to recompute the roofline fraction, nothing repeated."""
     roof, cfg = r["roofline"], r["config"]
-    out = {"name": cfg["name"], "M": cfg["M"], "K": cfg["K"], "N": cfg["N"], "value": r["value"], "unit": r["unit"], "steps": r["steps"],
-           "us_per_step": round(r["ms_per_step"] * 1e3, 3), "launch_us": roof["launch_us"], "kernel": roof["kernel"], "bound": roof["bound"],
+    out = {"name": cfg["name"], "M": cfg["M"], "K": cfg["K"], "N": cfg["N"], "value": r["value"], "unit": r["unit"],
+           "us_per_step": round(r["ms_per_step"] * 1e3, 3), "kernel": roof["kernel"], "bound": roof["bound"],
            "frac": roof["frac"], "alg_bytes": int(roof["algorithmic_bytes"]), "alg_flops": int(roof["algorithmic_flops"]),
-           "traffic": roof["traffic"], "rot": cfg["weight_buffers_rotated"]}
+           "traffic": roof["traffic"], "rot": cfg["weight_buffers_rotated"], "event_us": roof["event_us"], "kernel_us": None, "kernel_us_min": None}
+    if roof.get("traffic_stale"):
+        out["traffic_stale"] = True
+    if "ref_rocm_us" in r:
+        out["ref_rocm_us"] = r["ref_rocm_us"]
     if "cpu_baseline" in r:
         c = r["cpu_baseline"]
         out["cpu"] = {"v": c["value"], "unit": c["unit"], "s": c["seconds_per_call"], "iqr_s": c["iqr_s"], "path": c["path"]}
@@ -457,24 +807,22 @@ def compact(r):
 
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` with no launcher around it: start N ranks of this same command, one per GPU."""
-    import socket
     import subprocess
 
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun picks (and holds) a free rendezvous port itself - probing one here and closing the socket left a window
+    # for another process to take it
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE when a launcher set it, else 1")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))  # sub-results may also name layer_decode_b1 / _b32
     ap.add_argument("--sub", nargs="*", default=None, help="workloads reported under sub_results (default: the int4 decode half of the metric)")
     ap.add_argument("--no-sub", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -485,8 +833,16 @@ def main():
                     help="untimed: keep the device busy with the same steps for this long before the timed region (clock ramp)")
     ap.add_argument("--verbose", action="store_true", help="also print every sub-result in full on stderr")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # test-only: CPU + gloo skeleton run (run_stub)
+    ap.add_argument("--no-ref-rocm", action="store_true", help="skip timing the reference's ROCm op sequence (ref_rocm_us)")
+    ap.add_argument("--no-prefetch", action="store_true", help="layer_decode: skip the side-stream weight-prefetch variant")
+    ap.add_argument("--prefetch-wgs", type=int, default=0, help="layer_decode: workgroups of the touch kernel (0 = library default)")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip BASELINE configs[4] (Llama-3-8B end-to-end tokens/s, ~1 min)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the rocprofv3 child passes (kernel_us, traffic)")
+    ap.add_argument("--trace-child", nargs="+", default=None, help=argparse.SUPPRESS)  # the child run of collect_profiles
     args = ap.parse_args()
 
+    if args.gpus is None:  # an external launcher's WORLD_SIZE is enough (torchrun --nproc-per-node 8 bench.py --shard)
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_torchrun(args.gpus))
 
@@ -519,15 +875,24 @@ def main():
 
     import optimum_quanto_amd  # noqa: F401  registers the quanto:: ops; raises if the HIP library cannot be loaded later
 
+    if args.trace_child is not None:
+        trace_child(args.trace_child, args, device)
+        return
     if args.shard:
         out = run_sharded(args, device, rank, world, dist)
     else:
         with_cpu = not args.no_cpu_baseline and world == 1  # the host baseline is reported at N = 1 only
         out = run_workload(args.workload, args, device, rank, world, dist, args.steps, with_cpu)
+        default_run = args.workload == "cfg2" and args.sub is None and not args.no_sub
         subs = [] if args.no_sub else (args.sub if args.sub is not None else (DEFAULT_SUB if args.workload == "cfg2" else []))
         sub_results = []
         for name in subs:
             # decode launches last a few microseconds: time at least 200 of them so that the event pair brackets milliseconds
+            if name in LAYER_WORKLOADS:
+                r = run_layer_decode(name, args, device, rank, world, dist, max(args.steps, 100))
+                if r is not None:
+                    sub_results.append(r)
+                continue
             r = run_workload(name, args, device, rank, world, dist, max(args.steps, 200), with_cpu)
             if r is not None:
                 if args.verbose:
@@ -540,8 +905,26 @@ def main():
                 sub_results.append({"name": "cfg4_sharded", "scaling": "strong", "n_gpus": world, "value": r["value"], "unit": r["unit"],
                                     "compute_only_us": r["compute_only_us"], "with_all_gather_us": r["with_all_gather_us"],
                                     "compute_only_tflops": r["compute_only_tflops"], "parallelism": r["config"]["parallelism"]})
+        if world == 1 and rank == 0 and not args.no_profile and out is not None:
+            # this run's own kernel-only durations and counter traffic (child processes under rocprofv3; nothing here is timed)
+            names = [args.workload] + [sr["name"] for sr in sub_results if sr["name"] in WORKLOADS or sr["name"] in LAYER_WORKLOADS]
+            t_prof = time.perf_counter()
+            prof = collect_profiles(names)
+            apply_profile(out, prof.get(args.workload), compacted=False)
+            for sr in sub_results:
+                apply_profile(sr, prof.get(sr["name"]), compacted=True)
+            out["profile_passes"] = {"ok": bool(prof), "seconds": round(time.perf_counter() - t_prof, 1),
+                                     "what": "rocprofv3 --kernel-trace, --pmc FETCH_SIZE, --pmc WRITE_SIZE child runs of this file"}
+        if world == 1 and rank == 0 and default_run and not args.no_cfg5 and out is not None:
+            try:
+                sub_results.append(run_cfg5(args, device))
+            except Exception as e:  # transformers missing / out of memory: the GEMM records stand on their own
+                sub_results.append({"name": "cfg5", "error": repr(e)[:200]})
         if out is not None and sub_results:
             out["sub_results"] = sub_results
+            if any(sr["name"] in LAYER_WORKLOADS for sr in sub_results):
+                out["layer_decode_note"] = ("one Llama-3-8B layer's int4 QLinears as 4 launches (q/k/v fused, o, gate/up fused, down); prefetch_*: same "
+                                            "launches while a side stream touches launch j+1's weights (quanto_hip_prefetch -> Infinity Cache)")
         if out is not None and "cpu_baseline" in out:
             out["cpu_baseline"]["how"] = CPU_BASELINE_NOTE["reference"]
             used = {out["cpu_baseline"]["path"]} | {sr["cpu"]["path"] for sr in sub_results if "cpu" in sr}

@@ -589,7 +589,8 @@ static int launch_tf(const Args& a, hipStream_t stream, const Segs* segs = nullp
 static int skinny_split(const PackedGeom& g, int64_t M) {
   const int forced = env_int("QUANTO_HIP_SKINNY_SPLIT", 0);  // experiments
   const int tf = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
-  const int blocks = (int)(g.N / (16 * skinny::pick_waves((int)g.N, tf)));
+  // group sizes 64 / 32 always launch 64-feature blocks (launch_small_groups), whatever the wave knob says
+  const int blocks = (g.C == 64 || g.C == 32) ? (int)(g.N / 64) : (int)(g.N / (16 * skinny::pick_waves((int)g.N, tf)));
   int s = 1;
   const int tiles = (int)(g.K / 128);  // 128-k tiles (= groups of 128)
   while (s < 8 && blocks * s * 2 <= 512 && tiles % (s * 2) == 0 && tiles / (s * 2) >= 8) s *= 2;

@@ -52,7 +52,14 @@ def quantize(model: torch.nn.Module, weights: Optional[Union[str, qtype]] = None
 
 def requantize(model: torch.nn.Module, state_dict: Dict[str, Any], quantization_map: Dict[str, Dict[str, str]],
                device: torch.device = None):
-    """Rebuild a frozen model from a flattened state dict + ``quantization_map`` (quantize.py:101-140)."""
+    """Rebuild a frozen model from a flattened state dict + ``quantization_map`` (quantize.py:101-140).
+
+    One deliberate divergence from the reference: when the checkpoint's float dtype differs from the dtype ``model`` was built in
+    (an fp32 checkpoint opened as a bf16 skeleton), the reference keeps the deserialized scale / shift as they are
+    (nn/qmodule.py:161-207) and the module then mixes dtypes (its ``forward`` raises on fp32 scale x bf16 bias).  Here the rebuilt
+    weight's scale and float shift are cast to the model's dtype - integers untouched - and a ``UserWarning`` names the modules:
+    the dequantized weights are then the checkpoint's values re-rounded to the model dtype, not bit-identical to what was saved.
+    Build the skeleton in the checkpoint's dtype to get the reference's bits."""
     if device is None:
         device = next(model.parameters()).device
         if device.type == "meta":
@@ -92,9 +99,16 @@ def requantize(model: torch.nn.Module, state_dict: Dict[str, Any], quantization_
     for k, v in list(model.named_parameters()) + list(model.named_buffers()):
         if k in want and type(v.data) is torch.Tensor and v.is_floating_point() and v.dtype != want[k]:
             v.data = v.data.to(want[k])
+    recast = []
     for name, m in model.named_modules():
         if name in qdtype and isinstance(m.weight, QTensor) and m.weight._scale.dtype != qdtype[name]:
+            recast.append(f"{name} ({m.weight._scale.dtype} -> {qdtype[name]})")
             m.weight = torch.nn.Parameter(_cast_qweight(m.weight, qdtype[name]), requires_grad=False)
+    if recast:
+        import warnings
+
+        warnings.warn("requantize: the checkpoint's scale dtype differs from the model's; scale / shift of " + ", ".join(recast[:4]) +
+                      (f" and {len(recast) - 4} more" if len(recast) > 4 else "") + " were cast to the model dtype (see the docstring)", UserWarning)
     model.to(device)
 
 

@@ -44,7 +44,8 @@ def test_default_line_fits_the_driver_tail():
         kind, M, K, N, desc = bench.WORKLOADS[name]
         flops, nbytes = bench.algorithmic_work(kind, M, K, N)
         roof = {"bound": "hbm", "achieved": 1234.5, "peak": 8000.0, "unit": "GB/s", "frac": 0.1543, "traffic": 123456789, "kernel": "skinny_multi",
-                "launch_us": 12.345, "algorithmic_bytes": nbytes, "algorithmic_flops": flops, "traffic_source": "x" * 90}
+                "launch_us": 12.345, "event_us": 12.123, "kernel_us": 10.123, "kernel_us_min": 9.876, "algorithmic_bytes": nbytes,
+                "algorithmic_flops": flops, "traffic_source": "x" * 150}
         cpu = {"kind": "reference", "cores": 128, "path": "int4_generic", "value": 1.23456, "unit": "GB/s", "sample": "full call, 50 timed calls after 3 warm-up",
                "seconds_per_call": 0.123456, "iqr_s": 0.012345, "calls_timed": 50,
                "tinygemm": {"seconds_per_call": 0.000123, "iqr_s": 1e-6, "calls": 200, "value": 123.456, "unit": "GB/s"}}
@@ -52,14 +53,35 @@ def test_default_line_fits_the_driver_tail():
                 "ms_per_step": 0.01234, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": desc, "name": name, "M": M, "K": K, "N": list(N) if isinstance(N, tuple) else N, "weight_buffers_rotated": 58,
                            "launch": "hipGraph replay of the K steps", "clock_ramp_ms": 300.0, "parallelism": "replicas x1 (no data-path collective)"},
-                "tflops": 1.234, "gbps": 1234.5, "roofline": roof, "cpu_baseline": cpu}
+                "tflops": 1.234, "gbps": 1234.5, "roofline": roof, "cpu_baseline": cpu, "ref_rocm_us": 123.45}
+
+    def fake_layer(name):
+        return {"name": name, "B": 32, "launches": ["qkv", "o", "gate_up", "down"], "us_per_layer": 123.456, "event_us": 123.456, "alg_bytes": 123456789,
+                "GBs": 1234.5, "bound": "hbm", "frac": 0.1234, "rot": 5, "steps": 100, "kernel_us": 12.345, "kernel_us_min": 12.345, "traffic": 123456789,
+                "prefetch_us_per_layer": 123.456, "prefetch_frac": 0.1234}
 
     out = fake("cfg2")
     out["cpu_baseline"]["how"] = bench.CPU_BASELINE_NOTE["reference"]
-    out["sub_results"] = [bench.compact(fake(n)) for n in bench.DEFAULT_SUB]
+    out["sub_results"] = [fake_layer(n) if n in bench.LAYER_WORKLOADS else bench.compact(fake(n)) for n in bench.DEFAULT_SUB]
+    for sr in out["sub_results"]:
+        bench.apply_profile(sr, {"kernel_us": 12.345, "kernel_us_min": 11.234, "traffic": 123456789}, compacted=True)
+    out["sub_results"].append({"name": "cfg5", "model": "Llama-3-8B random-init bf16, qint4 g128, lm_head excluded", "prompt": 512,
+                               "new_tokens": 512, "method": "generate(), greedy, eos off, prefill included (latency.py:24-105)",
+                               "fused_groups": 64, "build_s": 12.3, "int4_bytes_per_token": 3706716160, "b1_tok_s": 123.4, "b1_ms_per_token": 12.345,
+                               "b32_tok_s": 1234.5, "b32_ms_per_token": 12.345})
+    out["profile_passes"] = {"ok": True, "seconds": 123.4, "what": "rocprofv3 --kernel-trace, --pmc FETCH_SIZE, --pmc WRITE_SIZE child runs of this file"}
     out["cpu_paths"] = dict(bench.CPU_BASELINE_NOTE)
+    out["layer_decode_note"] = "x" * 230
     line = json.dumps(out, separators=(",", ":"))
-    assert len(line) < 6500, len(line)
+    assert len(line) < 7600, len(line)  # the driver keeps an 8 KB stdout tail
     for sr in out["sub_results"]:  # enough to recompute every fraction from the line alone
-        assert {"name", "launch_us", "frac", "alg_bytes", "alg_flops", "kernel", "traffic", "cpu"} <= set(sr)
-    assert {"northstar", "cfg3", "cfg4"} <= {sr["name"] for sr in out["sub_results"]}
+        if sr["name"] in bench.WORKLOADS:
+            assert {"name", "us_per_step", "event_us", "kernel_us", "frac", "alg_bytes", "alg_flops", "kernel", "traffic", "cpu"} <= set(sr)
+    assert {"northstar", "cfg3", "cfg4", "layer_decode_b1", "layer_decode_b32", "cfg5"} <= {sr["name"] for sr in out["sub_results"]}
+
+
+def test_world_size_from_the_launcher_is_enough():
+    """`torchrun --nproc-per-node N bench.py` without --gpus: the flag defaults to WORLD_SIZE (r3 exited on the mismatch)."""
+    r = _run("--stub", "--steps", "2", "--warmup", "0", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["n_gpus"] == 1

@@ -288,7 +288,8 @@ def test_qlinear_quantize_freeze_state_dict_roundtrip():
         lazy = torch.nn.Sequential(torch.nn.Linear(256, 128), torch.nn.ReLU(), torch.nn.Linear(128, 64, bias=False)).to(torch.bfloat16)
     torch.empty_like = spy
     try:
-        Q.requantize(lazy, sd, qmap, device=torch.device("cpu"))
+        with pytest.warns(UserWarning, match="cast to the model dtype"):  # fp32 checkpoint, bf16 skeleton: announced, not silent
+            Q.requantize(lazy, sd, qmap, device=torch.device("cpu"))
     finally:
         torch.empty_like = real_empty_like
     assert (128, 256) not in allocated and (64, 128) in allocated, allocated
