@@ -714,9 +714,10 @@ def _rocprof_pass(names, mode, timeout_s):
         rows = []
         for r in csv.DictReader(open(files[0])):
             val = float(r["Counter_Value"]) if mode != "trace" else None
-            rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), val))
-        rows.sort()
-        return [(k, a, b, v) for _, k, a, b, v in rows]
+            start = int(r["Start_Timestamp"])
+            rows.append((start, int(r.get("Dispatch_Id") or 0), r["Kernel_Name"], start, int(r["End_Timestamp"]), val))
+        rows.sort()  # one in-order queue: start time = dispatch order
+        return [(k, a, b, v) for _, _, k, a, b, v in rows]
     except Exception:
         return None
     finally:
@@ -837,7 +838,8 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true", help="layer_decode: skip the side-stream weight-prefetch variant")
     ap.add_argument("--prefetch-wgs", type=int, default=0, help="layer_decode: workgroups of the touch kernel (0 = library default)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip BASELINE configs[4] (Llama-3-8B end-to-end tokens/s, ~1 min)")
-    ap.add_argument("--no-profile", action="store_true", help="skip the rocprofv3 child passes (kernel_us, traffic)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the rocprofv3 child passes (kernel_us, traffic) of the default run")
+    ap.add_argument("--profile", action="store_true", help="run the rocprofv3 child passes for a non-default selection of workloads too")
     ap.add_argument("--trace-child", nargs="+", default=None, help=argparse.SUPPRESS)  # the child run of collect_profiles
     args = ap.parse_args()
 
@@ -905,7 +907,7 @@ def main():
                 sub_results.append({"name": "cfg4_sharded", "scaling": "strong", "n_gpus": world, "value": r["value"], "unit": r["unit"],
                                     "compute_only_us": r["compute_only_us"], "with_all_gather_us": r["with_all_gather_us"],
                                     "compute_only_tflops": r["compute_only_tflops"], "parallelism": r["config"]["parallelism"]})
-        if world == 1 and rank == 0 and not args.no_profile and out is not None:
+        if world == 1 and rank == 0 and (default_run or args.profile) and not args.no_profile and out is not None:
             # this run's own kernel-only durations and counter traffic (child processes under rocprofv3; nothing here is timed)
             names = [args.workload] + [sr["name"] for sr in sub_results if sr["name"] in WORKLOADS or sr["name"] in LAYER_WORKLOADS]
             t_prof = time.perf_counter()
