@@ -42,8 +42,9 @@ Round 4 additions to the default line (all measured in the same process / on the
     with the same graph / ramp discipline on the same tensors;
   * ``layer_decode`` records: the seven int4 QLinears of one Llama-3-8B layer as the FOUR launches the product issues at decode time
     (q/k/v in one, o, gate/up in one, down), > 512 MB of layer weights rotated, B = 1 and B = 32: sum of us, algorithmic bytes, layer-level
-    HBM fraction, kernel-only sum, and the same sequence with the next launch's weights prefetched into the Infinity Cache from a side
-    stream (``quanto_hip_prefetch``) - labelled as such;
+    HBM fraction, kernel-only sum, and - labelled as such - the same sequence over a working set that stays resident in the 256 MiB
+    Infinity Cache (two layers' weights, 218 MB: what a perfect weight prefetcher running under the model's non-library kernels could
+    deliver; a side-stream touch kernel inside the hipGraph was measured in r4 and is 5 x SLOWER: profiles/r04_side_stream_prefetch_negative.txt);
   * ``cfg5``: BASELINE configs[4] end to end - Llama-3-8B random-init bf16, weights=qint4 with lm_head excluded, the reference's
     method (bench/generation/metrics/latency.py:24-105: ``generate`` 512 prompt + 512 new tokens, greedy, eos disabled), tokens/s at
     batch 1 and batch 32 (``--no-cfg5`` skips it).
@@ -536,28 +537,15 @@ def build_layer(B, device, seed):
     return xs, sets
 
 
-def make_layer_step(xs, sets, prefetch_stream=None, prefetch_wgs=0):
-    """One decode step of the layer: q/k/v (one launch), o, gate/up (one launch), down.  With ``prefetch_stream``: while launch j
-    runs, that stream touches the weights of launch j + 1 (the next layer's q/k/v behind ``down``) - quanto_hip_prefetch."""
-    from optimum_quanto_amd.library.hip import quanto_hip
-
-    lib = quanto_hip.lib
+def make_layer_step(xs, sets):
+    """One decode step of the layer: q/k/v (one launch), o, gate/up (one launch), down - the calls the product issues."""
     state = {"i": 0}
     none = {1: [None], 2: [None] * 2, 3: [None] * 3}
 
-    def tensors_of(members):
-        return [t for m in members for t in m]
-
     def step():
-        i = state["i"]
+        cur = sets[state["i"] % len(sets)]
         state["i"] += 1
-        cur, nxt = sets[i % len(sets)], sets[(i + 1) % len(sets)]
-        main = torch.cuda.current_stream()
         for j, (_, kind, K, N) in enumerate(LAYER_LAUNCHES):
-            if prefetch_stream is not None:
-                target = cur[j + 1] if j + 1 < len(LAYER_LAUNCHES) else nxt[0]
-                prefetch_stream.wait_stream(main)  # starts once launch j - 1 is done, i.e. together with launch j
-                lib.prefetch(*tensors_of(target), workgroups=prefetch_wgs, stream=prefetch_stream)
             m = cur[j]
             if kind == "qbits_i4_multi":
                 torch.ops.quanto.qbits_mm_multi(xs[j], [p for p, _, _ in m], [sc for _, sc, _ in m], [sh for _, _, sh in m], none[len(m)], 4, 128,
@@ -565,8 +553,6 @@ def make_layer_step(xs, sets, prefetch_stream=None, prefetch_wgs=0):
             else:
                 p, sc, sh = m[0]
                 torch.ops.quanto.qbits_mm(xs[j], p, sc, sh, None, 4, 128, N, K)
-        if prefetch_stream is not None:
-            main.wait_stream(prefetch_stream)  # join (a captured side branch must rejoin; costs nothing: the touch kernel is done long before)
     return step
 
 
@@ -576,25 +562,16 @@ def run_layer_decode(name, args, device, rank, world, dist, steps):
     nbytes = layer_algorithmic_bytes(B)
     with torch.no_grad():
         elapsed, dev_ms = timed_replay(make_layer_step(xs, sets), steps, args, dist, device)
-        pre = None
-        if not args.no_prefetch:
-            try:
-                ps = torch.cuda.Stream(priority=0)
-                p_elapsed, _ = timed_replay(make_layer_step(xs, sets, ps, args.prefetch_wgs), steps, args, dist, device)
-                pre = p_elapsed * 1e6 / steps
-            except Exception as e:  # a side-stream capture problem must not take the plain record down
-                pre = f"error: {repr(e)[:120]}"
+        # the same launches over TWO layers' weights (218 MB): the working set stays in the 256 MiB Infinity Cache - the rate a perfect
+        # prefetcher (next layer's weights pulled in while the model's own kernels run) would give these launches.  NOT an HBM number.
+        m_elapsed, _ = timed_replay(make_layer_step(xs, sets[:2]), steps, args, dist, device)
     if rank != 0:
         return None
-    us = elapsed * 1e6 / steps
+    us, mall_us = elapsed * 1e6 / steps, m_elapsed * 1e6 / steps
     out = {"name": name, "B": B, "launches": [n for n, _, _, _ in LAYER_LAUNCHES], "us_per_layer": round(us, 3), "event_us": round(dev_ms * 1e3 / steps, 3),
            "alg_bytes": int(nbytes), "GBs": round(nbytes * world / us / 1e3, 1), "bound": "hbm", "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
-           "rot": len(sets), "steps": steps, "kernel_us": None, "kernel_us_min": None, "traffic": None}
-    if isinstance(pre, float):
-        out["prefetch_us_per_layer"] = round(pre, 3)
-        out["prefetch_frac"] = round(nbytes / pre / 1e3 / HBM_PEAK_GBS, 4)
-    elif pre is not None:
-        out["prefetch_us_per_layer"] = pre
+           "rot": len(sets), "steps": steps, "kernel_us": None, "kernel_us_min": None, "traffic": None,
+           "cache_resident_us_per_layer": round(mall_us, 3), "cache_resident_GBs": round(nbytes / mall_us / 1e3, 1)}
     del sets
     torch.cuda.empty_cache()
     return out
@@ -656,7 +633,7 @@ def run_cfg5(args, device, batches=(1, 32), prompt=512, new=512):
 # ------------------------------------------------------------------------------------------------------------------------
 # rocprofv3 child passes: kernel-only durations and fabric traffic measured by THIS run (not copied from profiles/)
 # ------------------------------------------------------------------------------------------------------------------------
-MARKER = "prefetch_touch_kernel"  # one launch of the library's own touch kernel separates the workloads in a trace
+MARKER = "unpack_scalar_kernel"  # one 3-byte quanto::unpack launch (a kernel no bench workload uses) separates the workloads in a trace
 TRACE_STEPS = 12
 
 
@@ -665,7 +642,7 @@ def trace_child(names, args, device):
     from optimum_quanto_amd.library.hip import quanto_hip
 
     lib = quanto_hip.lib
-    tag = torch.zeros(64, dtype=torch.uint8, device=device)
+    tag = torch.zeros(3, dtype=torch.uint8, device=device)  # 3 bytes: the scalar unpack kernel (the vectorised one needs multiples of 16)
     for name in names:
         if name in LAYER_WORKLOADS:
             xs, sets = build_layer(LAYER_WORKLOADS[name], device, seed=4321)
@@ -678,14 +655,14 @@ def trace_child(names, args, device):
             x, sets = build_inputs(kind, M, K, N, device, min(n_weights, 3 + TRACE_STEPS), seed=1234)
             step = make_step(kind, x, sets, K, N)
         torch.cuda.synchronize()
-        lib.prefetch(tag)
+        lib.unpack(tag, 4)
         with torch.no_grad():
             for _ in range(3 + TRACE_STEPS):
                 step()
         torch.cuda.synchronize()
         del sets, step
         torch.cuda.empty_cache()
-    lib.prefetch(tag)
+    lib.unpack(tag, 4)
     torch.cuda.synchronize()
 
 
@@ -835,8 +812,6 @@ def main():
     ap.add_argument("--verbose", action="store_true", help="also print every sub-result in full on stderr")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # test-only: CPU + gloo skeleton run (run_stub)
     ap.add_argument("--no-ref-rocm", action="store_true", help="skip timing the reference's ROCm op sequence (ref_rocm_us)")
-    ap.add_argument("--no-prefetch", action="store_true", help="layer_decode: skip the side-stream weight-prefetch variant")
-    ap.add_argument("--prefetch-wgs", type=int, default=0, help="layer_decode: workgroups of the touch kernel (0 = library default)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip BASELINE configs[4] (Llama-3-8B end-to-end tokens/s, ~1 min)")
     ap.add_argument("--no-profile", action="store_true", help="skip the rocprofv3 child passes (kernel_us, traffic) of the default run")
     ap.add_argument("--profile", action="store_true", help="run the rocprofv3 child passes for a non-default selection of workloads too")
@@ -925,8 +900,8 @@ def main():
         if out is not None and sub_results:
             out["sub_results"] = sub_results
             if any(sr["name"] in LAYER_WORKLOADS for sr in sub_results):
-                out["layer_decode_note"] = ("one Llama-3-8B layer's int4 QLinears as 4 launches (q/k/v fused, o, gate/up fused, down); prefetch_*: same "
-                                            "launches while a side stream touches launch j+1's weights (quanto_hip_prefetch -> Infinity Cache)")
+                out["layer_decode_note"] = ("one Llama-3-8B layer's int4 QLinears as 4 launches (q/k/v fused, o, gate/up fused, down), 5 layers' weights "
+                                            "rotated (HBM); cache_resident_*: 2 layers rotated = Infinity-Cache hits, the bound for a weight prefetcher")
         if out is not None and "cpu_baseline" in out:
             out["cpu_baseline"]["how"] = CPU_BASELINE_NOTE["reference"]
             used = {out["cpu_baseline"]["path"]} | {sr["cpu"]["path"] for sr in sub_results if "cpu" in sr}

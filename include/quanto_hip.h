@@ -266,16 +266,6 @@ int quanto_hip_quantize_affine_packed(const void* base, const void* scale, const
  */
 int quanto_hip_pack(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int64_t cols, int bits, void* stream);
 
-/*
- * Pull [ptr, ptr + bytes) into the memory-side Infinity Cache ahead of the kernel that will stream it (one dword touched per 64
- * bytes from `workgroups` workgroups of 256 threads, 0 = default 32; data dropped, nothing written).  Meant for a side stream next
- * to the compute stream: the int4 weights of a whole Llama-3-8B layer (109 MB) fit the 256 MiB cache, and between two quantized
- * Linears of a decode step the model's own kernels leave the HBM idle.  A hint: results never depend on it.
- *   no reference counterpart - the reference's decode path (bench/generation/metrics/latency.py:57-94 -> nn/qlinear.py:49-50)
- *   dequantizes every weight per call on ROCm and has no streaming kernel to feed.
- */
-int quanto_hip_prefetch(const void* ptr, size_t bytes, int workgroups, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,6 @@ int quantize_symmetric(const void*, const void*, void*, int64_t, int64_t, int, i
 int quantize_affine(const void*, const void*, const void*, void*, int64_t, int64_t, int, int, bool, hipStream_t);
 int quantize_affine_packed(const void*, const void*, const void*, void*, int64_t, int64_t, int, int, bool, hipStream_t);
 int pack_weights(const uint8_t*, uint8_t*, int64_t, int64_t, int, hipStream_t);
-int prefetch_range(const void*, size_t, int, hipStream_t);
 int qbytes_mm_gemv_multi(const void*, int, const void* const*, const void* const*, const void* const*, void* const*, const int64_t*, int64_t,
                          int64_t, int, int, hipStream_t);
 bool qbytes_skinny_multi_supported(int, const int64_t*, int64_t, int64_t, int, int, int);
@@ -564,12 +563,6 @@ int quanto_hip_pack(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int6
   if (rows == 0 || cols == 0) return QUANTO_HIP_OK;
   if (!unpacked || !packed) return QUANTO_HIP_EINVAL;
   return pack_weights(unpacked, packed, rows, cols, bits, reinterpret_cast<hipStream_t>(stream));
-}
-
-int quanto_hip_prefetch(const void* ptr, size_t bytes, int workgroups, void* stream) {
-  if (bytes > 0 && !ptr) return QUANTO_HIP_EINVAL;
-  if (workgroups < 0) return QUANTO_HIP_EINVAL;
-  return prefetch_range(ptr, bytes, workgroups, reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -106,8 +106,6 @@ class _Bindings:
         c.quanto_hip_quantize_affine_packed.argtypes = [vp, vp, vp, vp, i64, i64, ci, ci, ci, ci, vp]
         c.quanto_hip_pack.restype = ci
         c.quanto_hip_pack.argtypes = [vp, vp, i64, i64, ci, vp]
-        c.quanto_hip_prefetch.restype = ci
-        c.quanto_hip_prefetch.argtypes = [vp, sz, ci, vp]
         self._c = c
         if c.quanto_hip_abi_version() != 1:
             raise QuantoHipError("libquanto_hip.so ABI version mismatch: rebuild with __graft_entry__.build()")
@@ -240,21 +238,6 @@ class _Bindings:
         with torch.cuda.device(t.device):
             self._check(self._c.quanto_hip_pack(_ptr(t), _ptr(out), rows, cols, bits, self._stream(t)), "pack")
         return out
-
-    # -- weight prefetch (Infinity Cache) ---------------------------------------------------------------
-    def prefetch(self, *tensors, workgroups: int = 0, stream=None) -> None:
-        """Touch the storage of ``tensors`` (dense device tensors: packed weights, scales, shifts) so that the kernel that streams
-        them next finds them in the Infinity Cache.  Launches on ``stream`` (default: torch's current stream) - pass a side stream
-        to overlap it with compute.  A hint only: nothing is written, results never depend on it."""
-        self._require_cuda(*tensors)
-        for t in tensors:
-            if t is None or t.numel() == 0:
-                continue
-            if not t.is_contiguous():
-                raise QuantoHipError("prefetch expects contiguous tensors")
-            s = ctypes.c_void_p(stream.cuda_stream) if stream is not None else self._stream(t)
-            with torch.cuda.device(t.device):
-                self._check(self._c.quanto_hip_prefetch(_ptr(t), t.numel() * t.element_size(), workgroups, s), "prefetch")
 
     # -- quanto::unpack ---------------------------------------------------------------------------
     def unpack(self, t: torch.Tensor, bits: int) -> torch.Tensor:
@@ -445,7 +428,7 @@ class QuantoHipExtension(NativeLibrary):
             "quanto_hip",
             root_dir=csrc,
             lib_path=os.path.join(_PKG_DIR, "lib", "libquanto_hip.so"),
-            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qmm_mfma_large.hip", "qmm_mfma_large32.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbytes_skinny.hip", "qmm_native8.hip", "quantize.hip", "prefetch.hip",
+            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qmm_mfma_large.hip", "qmm_mfma_large32.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbytes_skinny.hip", "qmm_native8.hip", "quantize.hip",
                      "qh_common.h", os.path.join("..", "..", "include", "quanto_hip.h")],
         )
         self._bindings = None

@@ -58,7 +58,7 @@ def test_default_line_fits_the_driver_tail():
     def fake_layer(name):
         return {"name": name, "B": 32, "launches": ["qkv", "o", "gate_up", "down"], "us_per_layer": 123.456, "event_us": 123.456, "alg_bytes": 123456789,
                 "GBs": 1234.5, "bound": "hbm", "frac": 0.1234, "rot": 5, "steps": 100, "kernel_us": 12.345, "kernel_us_min": 12.345, "traffic": 123456789,
-                "prefetch_us_per_layer": 123.456, "prefetch_frac": 0.1234}
+                "cache_resident_us_per_layer": 123.456, "cache_resident_GBs": 12345.6}
 
     out = fake("cfg2")
     out["cpu_baseline"]["how"] = bench.CPU_BASELINE_NOTE["reference"]
