@@ -66,7 +66,10 @@ typedef enum {
                                        * workspace + dense MFMA GEMM - multiplies the weight rounded to the activation dtype, as the reference does */
   QUANTO_HIP_KERNEL_MFMA_FUSED4 = 8,  /* qbits_mm, 64 < M <= ~1-1.5 k (AUTO: its own time model): packed int4 -> MFMA operands in registers,
                                        * per-group fp32 fold, no dequantized weight; workspace only when K is split (plan / workspace_size say so) */
-  QUANTO_HIP_KERNEL_MMV = 9           /* qbits_mm, 4 < M <= 16 (AUTO; the kernel itself accepts up to 32 rows): register-streaming MFMA kernel, K split over the waves of a block (no workspace) */
+  QUANTO_HIP_KERNEL_MMV = 9,          /* qbits_mm, 4 < M <= 16 (AUTO; the kernel itself accepts up to 32 rows): register-streaming MFMA kernel, K split over the waves of a block (no workspace) */
+  QUANTO_HIP_KERNEL_MFMA_LARGE4 = 10  /* qbits_mm (int4, group size a multiple of 64 or per-channel), prefill-sized M: packed int4 -> registers -> MFMA
+                                         operands with the reference's rounding sequence (the product multiplies exactly the reference's dequantized
+                                         weight), 256 x 256 tiles, no workspace, no dense weight in memory */
 } quanto_hip_kernel;
 
 /* Split-K workspaces (SKINNY and MFMA_LARGE kernels) all share ONE layout: the first QUANTO_HIP_WS_COUNTER_BYTES bytes are

@@ -66,6 +66,9 @@ size_t qbits_mfma_fused_workspace(int64_t, const PackedGeom&);
 int qbits_mm_mfma_fused(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, void*,
                         size_t, hipStream_t);
 
+bool qbits_mfma_large_supported(int64_t, const PackedGeom&, int);
+int qbits_mm_mfma_large(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, hipStream_t);
+
 static bool is_float_dtype(int dt) { return dt == QUANTO_HIP_F32 || dt == QUANTO_HIP_F16 || dt == QUANTO_HIP_BF16; }
 
 static int check_qbits(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype, int shift_dtype, bool* int_shift) {
@@ -288,6 +291,10 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
     case QUANTO_HIP_KERNEL_MFMA_FUSED4:
       r = qbits_mm_mfma_fused(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, workspace, workspace_bytes, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("mfma_fused4");
+      return r;
+    case QUANTO_HIP_KERNEL_MFMA_LARGE4:
+      r = qbits_mm_mfma_large(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, stream);
+      if (r == QUANTO_HIP_OK) set_last_kernel("mfma_large4");
       return r;
   }
   return QUANTO_HIP_EINVAL;

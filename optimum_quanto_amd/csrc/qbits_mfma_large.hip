@@ -1,0 +1,445 @@
+// qbits_mm for prefill-sized M, no dense weight anywhere: int4-packed weights -> registers -> bf16 / fp16 MFMA operands with the
+// REFERENCE's rounding sequence (bit-identical to dequantize_qbits_kernel, i.e. to the reference's dequantize()), 256 x 256 tiles.
+//
+//   y[M,N] = x[M,K] @ W^T,   W[n,k] = T(T(scale[n,g] * q[n,k]) - shift[n,g])           (tensor/qbits.py:27-49: two roundings to T)
+//                            W[n,k] = T(scale[n,g] * (q[n,k] - zp[n,g]))                (integer zero-point: one rounding)
+//
+// What it replaces: QUANTO_HIP_KERNEL_DEQUANT_MFMA (a dequantize pass that writes N*K*2 bytes into a workspace + a dense GEMM that
+// reads them back: 5.1 x the algorithmic traffic at 4096^3, and the structure the reference itself has on ROCm).  The fused exact-math
+// kernel (qbits_mfma_fused.hip) pays 2 fp32 FMAs per output and group for its fold and loses beyond ~1.6 rounds of tiles; here the
+// per-group scale / shift go into the OPERAND (as the reference does) and the K loop is qmm_mfma_large.hip's: one software-pipelined
+// MFMA stream per wave, one barrier per K-tile.  Functional analogs on CUDA: awq/v2/gemm_cuda.cu:924-1026, marlin/marlin_cuda_kernel.cu:191-720.
+//
+// Workgroup = 8 waves, 256 tokens x 128 PACKED rows (= 256 features: byte (p,k) = W[p,k] | W[p+N/2,k] << 4, so the output tile is two
+// 128-wide column blocks, at p0 and at N/2 + p0).  All waves side by side along the features (1 x 8): wave w owns packed rows
+// 16w..16w+15 (32 features, both nibble planes) and ALL 256 tokens - every weight is converted exactly once per workgroup, which is
+// what makes the conversion affordable (7 VALU per pair of weights: 2 cvt_f32_ubyte, pk_mul, 2 roundings, pk_add, cvt_pk; ~1.9 VALU
+// per MFMA; a 2 x 4 layout would convert everything twice).
+//   * activations: LDS-DMA ring of three 32 KiB stages (global_load_lds_dwordx4, swizzled as in qmm_mfma_large.hip), fragments two
+//     steps ahead through a ring of four;
+//   * weights never touch the LDS: a wave reads only its own 16 packed rows, so lane (r = lane & 15, g = lane >> 4) loads its 16 bytes
+//     (k = 16g..16g+15 of the K-tile, both planes) straight into a register ring, two K-tiles ahead;
+//   * scale / shift: a 32-group window per workgroup in LDS ({s, z} pairs, 32 KiB; K = 4096 never refills), refilled 8 groups at a time while the loop runs (K = 14336
+//     has 112 groups); a lane re-reads its two entries once per K-tile;
+//   * step (kk, i), 32 per K-tile: 2 MFMAs (both planes) x token fragment i; phase kk = 0 converts this tile's k-half-1 operands,
+//     phase kk = 1 the next tile's k-half-0 operands - one pair of weights every step;
+//   * epilogue: the tile is parked in LDS and stored as whole 256-byte rows per column block.
+// Group sizes: multiples of 64 and per-channel (a K-tile lies inside one group).  int4 only.
+#include <type_traits>
+
+#include "qmm_large_common.h"
+
+namespace qh {
+namespace l4 {
+
+using lt::BK;  // 64
+using lt::glds16;
+using lt::lds_ptr_t;
+using lt::Mma;
+using lt::swz_a;
+
+constexpr int BM = 256;           // tokens per workgroup
+constexpr int BP = 128;           // packed rows per workgroup (256 features)
+constexpr int NW = 8;             // waves
+constexpr int MI = BM / 16;       // token fragments per wave (all of them)
+constexpr int STEPS = 2 * MI;     // (k-half, token fragment)
+constexpr int STAGES = 3;
+constexpr int A_BYTES = BM * BK * 2;          // 32 KiB per stage
+constexpr int APIECES = BM / 8 / NW;          // 4 activation DMA pieces (8 rows x 128 B) per wave and K-tile
+constexpr int TG = 32, TH = 8;                // groups in the table window / per refill unit
+constexpr int TAB_BYTES = TG * 2 * BP * 4;    // [slot][plane][row] {scale, shift} as two T: 32 KiB
+constexpr int OUT_PITCH = 2 * BP * 2 + 16;    // parked output row: 256 features of T + padding
+constexpr int LOOP_BYTES = STAGES * A_BYTES + TAB_BYTES;                                 // 128 KiB while the K loop runs
+constexpr int LDS_BYTES = LOOP_BYTES > BM * OUT_PITCH ? LOOP_BYTES : BM * OUT_PITCH;     // 132 KiB: the epilogue parks the output tile over the ring + table
+
+struct Args {
+  const void* x;
+  const uint8_t* w;     // packed [N/2, K]
+  const void* scale;    // [N * G]
+  const void* shift;    // [N * G]: T (float shift) or uint8 / int8 (zero-point)
+  const void* bias;     // [N] or null
+  void* y;
+  int M, N, K;
+  int C;                // group size (K for per-channel)
+  int G;                // groups per feature
+  int group_m;          // tile raster (lt::tile_coords)
+};
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+// T(v) as an fp32 number: the first of the reference's two roundings, kept in fp32 for the subtraction that follows.
+// bf16: v_cvt_pk_bf16_f32 with a zero LOW half is the fp32 image of the rounded value - one instruction.  (Written as C++ - a bf16x2 with a
+// zero element, bit-cast to float - hipcc converts into the low half and moves it up with a v_perm: two instructions.)
+template <int DT>
+__device__ __forceinline__ float round_to_T(float v) {
+  if constexpr (DT == QUANTO_HIP_BF16) {
+    float r;
+    asm("v_cvt_pk_bf16_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+  } else {
+    return (float)(_Float16)v;
+  }
+}
+
+// byte B of `v` as a float (v_cvt_f32_ubyteB: hipcc otherwise extracts the byte first - v_and_b32_sdwa + v_cvt_f32_ubyte0)
+template <int B>
+__device__ __forceinline__ float ubyte_to_f32(uint32_t v) {
+  float r;
+  if constexpr (B == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(v));
+  if constexpr (B == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(v));
+  if constexpr (B == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(v));
+  if constexpr (B == 3) asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
+// two fp32 -> one dword of T, round to nearest even (lt::Mma<F16>::pack rounds toward zero: exact only for the 8-bit formats it serves)
+template <int DT>
+__device__ __forceinline__ uint32_t pack_rne(float a, float b) {
+  if constexpr (DT == QUANTO_HIP_BF16) {
+    bf16x2 r;
+    r.x = (__bf16)a;
+    r.y = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, r);
+  } else {
+    f16x2 r;
+    r.x = (_Float16)a;
+    r.y = (_Float16)b;
+    return __builtin_bit_cast(uint32_t, r);
+  }
+}
+
+// Two weights of one feature -> one MFMA operand dword.  `spread`: the lane's nibble plane spread to bytes (plane 0: q, plane 1: 16 q -
+// the factor 16 is folded into s / zp below, exactly: powers of two).  `PAIR`: byte pair 0 / 1 of the dword.
+template <int DT, bool INT_SHIFT, int PAIR>
+__device__ __forceinline__ uint32_t convert_pair4(uint32_t spread, float s, float z) {
+  const f32x2 s2{s, s}, z2{z, z};  // one register each: the packed ops broadcast the low half (op_sel)
+  f32x2 q;
+  q.x = ubyte_to_f32<2 * PAIR>(spread);
+  q.y = ubyte_to_f32<2 * PAIR + 1>(spread);
+  if constexpr (INT_SHIFT) {
+    const f32x2 t = (q - z2) * s2;  // (q - zp) exact, one rounding (tensor/qbits.py:35-42)
+    return pack_rne<DT>(t.x, t.y);
+  } else {
+    const f32x2 t = q * s2;         // exact in fp32 (8 x 4 significant bits) ...
+    f32x2 r;
+    r.x = round_to_T<DT>(t.x);      // ... rounded to T as `scale * data` is (tensor/qbits.py:41)
+    r.y = round_to_T<DT>(t.y);
+    const f32x2 u = r - z2;         // `dqt -= shift` (:44): fp32 difference of two T values, rounded to T by the pack
+    return pack_rne<DT>(u.x, u.y);
+  }
+}
+
+template <int DT, bool INT_SHIFT>
+__global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args a) {
+  using E = Elem<DT>;
+  using T = typename E::T;
+  using V8 = typename Mma<DT>::V8;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* tab = reinterpret_cast<uint32_t*>(smem + STAGES * A_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = a.M, N = a.N, K = a.K, C = a.C, G = a.G;
+  const int P = N >> 1;
+  const int nk = K / BK;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (P + BP - 1) / BP;
+  int tm, tn;
+  lt::tile_coords(blockIdx.x, tiles_m, tiles_n, a.group_m, tm, tn);
+  const int m0 = tm * BM, p0 = tn * BP;
+
+  // ---- activation DMA (qmm_mfma_large.hip's image: 8 rows x 128 B per piece, chunk c of row R stored at position c ^ swz_a(R)) ----
+  uint32_t asrc[APIECES];
+#pragma unroll
+  for (int j = 0; j < APIECES; ++j) {
+    const int R = (j * NW + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz_a(R);
+    int m = m0 + R;
+    m = m < M ? m : M - 1;
+    asrc[j] = ((uint32_t)m * (uint32_t)K + (uint32_t)(c * 8)) * 2u;  // 32-bit arithmetic: M * K < 2^30 (launcher)
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+  const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.x);
+  uint32_t adst[STAGES][APIECES];
+#pragma unroll
+  for (int t = 0; t < STAGES; ++t)
+#pragma unroll
+    for (int j = 0; j < APIECES; ++j) adst[t][j] = __builtin_amdgcn_readfirstlane(lds_base + t * A_BYTES + (j * NW + wave) * 1024);
+
+  // ---- weights: lane (r, g) owns bytes 16g..16g+15 of packed row p0 + 16 wave + r of every K-tile --------------------------------
+  const int fr = lane & 15, fg = lane >> 4;
+  uint32_t wofs;
+  {
+    int p = p0 + wave * 16 + fr;
+    p = p < P ? p : P - 1;
+    wofs = (uint32_t)p * (uint32_t)K + (uint32_t)(fg * 16);      // N * K < 2^32 (launcher)
+  }
+  u32x4 raw[STAGES];  // raw[t % 3]: tile t's bytes (.x .y = k-half 0, .z .w = k-half 1)
+  auto load_w = [&](int kt, u32x4& dst) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(wofs), "s"(a.w + (size_t)kt * BK) : "memory");
+  };
+
+  // ---- fragment read offsets (activations): chunk 2 fg + kk of row fr (+ 16 i), see qmm_mfma_large.hip ------------------------------
+  int aoff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) aoff[kk] = fr * 128 + (((fg * 2 + kk) ^ swz_a(fr)) << 4);
+
+  // ---- scale / shift table: slot = group % TG; thread (f = tid & 255, q = tid >> 8) fetches TH groups of table q for feature f ------
+  const int tf_plane = (tid & 255) >> 7, tf_row = tid & 127, tq = tid >> 8;
+  uint32_t tf_index;  // first group of this feature in the scale / shift arrays (32-bit: the loads then take an SGPR base + one VGPR offset)
+  {
+    int p = p0 + tf_row;
+    p = p < P ? p : P - 1;
+    tf_index = (uint32_t)(tf_plane * P + p) * (uint32_t)G;
+  }
+  uint16_t pend[TH];
+  auto table_fetch = [&](int g0) {  // groups g0 .. g0 + TH - 1 (clamped) -> registers
+#pragma unroll
+    for (int i = 0; i < TH; ++i) {
+      const uint32_t e = tf_index + (uint32_t)(g0 + i < G ? g0 + i : G - 1);
+      if (tq == 0) {
+        pend[i] = reinterpret_cast<const uint16_t*>(a.scale)[e];
+      } else if constexpr (INT_SHIFT) {
+        const T z = E::from_f32((float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[e]);  // small integers: exact
+        pend[i] = __builtin_bit_cast(uint16_t, z);
+      } else {
+        pend[i] = reinterpret_cast<const uint16_t*>(a.shift)[e];
+      }
+    }
+  };
+  auto table_store = [&](int g0) {  // registers -> slots (g0 + i) % TG, half-dword tq of entry [slot][plane][row]
+    uint16_t* t16 = reinterpret_cast<uint16_t*>(tab);
+#pragma unroll
+    for (int i = 0; i < TH; ++i) t16[((((g0 + i) % TG) * 2 + tf_plane) * BP + tf_row) * 2 + tq] = pend[i];
+  };
+  // this lane's entries: plane j, row 16 wave + fr
+  auto table_read = [&](int g, float (&s2)[2], float (&z2)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t e = tab[((g % TG) * 2 + j) * BP + wave * 16 + fr];
+      T st, zt;
+      st = __builtin_bit_cast(T, (uint16_t)(e & 0xFFFFu));
+      zt = __builtin_bit_cast(T, (uint16_t)(e >> 16));
+      float s = E::to_f32(st), z = E::to_f32(zt);
+      if (j == 1) {  // plane 1 is converted from 16 q: fold the 16 into the scale (and into the zero-point), exactly
+        s *= 0.0625f;
+        if constexpr (INT_SHIFT) z *= 16.f;
+      }
+      s2[j] = s;
+      z2[j] = z;
+    }
+  };
+
+  f32x4 acc[2][MI];  // acc[j][i]: plane j (packed rows 16 wave + 4 fg + r), tokens 16 i + fr
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint32_t w0[2][4], w1[2][4];  // converted operands: [plane][dword], k-half 0 / 1
+  V8 xf[4];
+  auto as_v8 = [&](const uint32_t(&w)[4]) { return __builtin_bit_cast(V8, make_uint4(w[0], w[1], w[2], w[3])); };
+  // dword c (0..7) of a k-half: plane c >> 2, operand dword d = c & 3 = byte pair d & 1 of raw dword d >> 1 of that half
+  auto convert = [&](const u32x4& r, int kk, int c, const float (&s2)[2], const float (&z2)[2]) -> uint32_t {
+    const int j = c >> 2, d = c & 3;
+    const uint32_t word = kk == 0 ? (d < 2 ? r.x : r.y) : (d < 2 ? r.z : r.w);
+    const uint32_t spread = j == 0 ? (word & 0x0F0F0F0Fu) : (word & 0xF0F0F0F0u);
+    return (d & 1) ? convert_pair4<DT, INT_SHIFT, 1>(spread, s2[j], z2[j]) : convert_pair4<DT, INT_SHIFT, 0>(spread, s2[j], z2[j]);
+  };
+
+  // ---- prologue: table halves 0 and 1, tiles 0 and 1 in flight, tile 0's k-half-0 operands converted ---------------------------------
+#pragma unroll 1
+  for (int g0 = 0; g0 < TG; g0 += TH) {
+    table_fetch(g0);
+    table_store(g0);
+  }
+#pragma unroll
+  for (int p = 0; p < APIECES; ++p) glds16(xbase, asrc[p], adst[0][p]);
+  load_w(0, raw[0]);
+  if (nk > 1) {
+#pragma unroll
+    for (int p = 0; p < APIECES; ++p) glds16(xbase + (size_t)BK * 2, asrc[p], adst[1][p]);
+    load_w(1, raw[1]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1])::"memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // group bookkeeping (wave-uniform): group of the current tile, k offset of the current tile inside its group
+  int g_cur = 0, k_in_g = 0;
+  float sc[2], zc[2], sn[2], zn[2];  // scale / shift (per plane) of the current and of the next tile's group
+  table_read(0, sc, zc);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) w0[c >> 2][c & 3] = convert(raw[0], 0, c, sc, zc);
+  xf[0] = *reinterpret_cast<const V8*>(smem + aoff[0]);
+  xf[1] = *reinterpret_cast<const V8*>(smem + aoff[0] + 2048);
+  int refill_g0 = -1;  // first group of the unit fetched into `pend`, to be stored at the next tile boundary
+
+  auto tile = [&](auto p_tag, int kt, auto dma_tag, auto barrier_tag) {
+    constexpr int PS = decltype(p_tag)::value, PN = (PS + 1) % STAGES, PF = (PS + 2) % STAGES;
+    const bool dma = dma_tag, barrier = barrier_tag;  // integral_constants in the steady state (no branches), run-time flags in the tail
+    const uint8_t* st = smem + PS * A_BYTES;
+    const uint8_t* sx = smem + PN * A_BYTES;
+    // the next tile's group
+    int g_next = g_cur, k_next = k_in_g + BK;
+    if (k_next >= C) {
+      k_next = 0;
+      ++g_next;
+    }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const int kk = s / MI, i = s % MI;
+      if (s == MI) table_read(g_next, sn, zn);  // before the first conversion of the second phase
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (kk == 0)
+          acc[j][i] = Mma<DT>::run(as_v8(w0[j]), xf[s & 3], acc[j][i]);
+        else
+          acc[j][i] = Mma<DT>::run(as_v8(w1[j]), xf[s & 3], acc[j][i]);
+        if (j == 0) {
+          // one pair of weights per step: dword c = i / 2 in even steps ... split over both MFMA slots by the scheduler barrier below
+          if ((i & 1) == 0) {
+            const int c = i >> 1;
+            if (kk == 0)
+              w1[c >> 2][c & 3] = convert(raw[PS], 1, c, sc, zc);   // this tile's k-half 1
+            else
+              w0[c >> 2][c & 3] = convert(raw[PN], 0, c, sn, zn);   // next tile's k-half 0 (garbage, unused, behind the last tile)
+          }
+        } else {
+          // activation fragment of step s + 2 (the next tile's first two at the end)
+          xf[(s + 2) & 3] = s + 2 < STEPS ? *reinterpret_cast<const V8*>(st + aoff[(s + 2) / MI] + ((s + 2) % MI) * 2048)
+                                          : *reinterpret_cast<const V8*>(sx + aoff[0] + (s + 2 - STEPS) * 2048);
+          if (s < APIECES) {
+            if (dma) glds16(xbase + (size_t)(kt + 2) * (BK * 2), asrc[s], adst[PF][s]);
+          } else if (s == APIECES) {
+            if (dma) load_w(kt + 2, raw[PF]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // tile boundary: own DMA share + weight bytes of tile kt + 2 (and a pending table half) have landed -> barrier
+    if (barrier) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[PF])::"memory");
+      if (refill_g0 >= 0) {
+        table_store(refill_g0);
+        refill_g0 = -1;
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // the next tile opens a new unit of TH groups: every group of the unit before it is dead (its last reader was the table_read
+      // above) -> its slots take the groups one window further; stored at the next boundary, first read TG - TH groups later
+      if (g_next != g_cur && g_next % TH == 0 && g_next >= TH && g_next - TH + TG < G) {
+        table_fetch(g_next - TH + TG);
+        refill_g0 = g_next - TH + TG;
+      }
+    }
+    g_cur = g_next;
+    k_in_g = k_next;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      sc[j] = sn[j];
+      zc[j] = zn[j];
+    }
+  };
+  using yes = std::integral_constant<bool, true>;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  int kt = 0;
+  for (; kt + 4 < nk; kt += 3) {  // three tiles that all still have a tile kt + 2 to fetch
+    tile(S0{}, kt, yes{}, yes{});
+    tile(S1{}, kt + 1, yes{}, yes{});
+    tile(S2{}, kt + 2, yes{}, yes{});
+  }
+  const int rem = nk - kt;  // 2..4 tiles left, kt % 3 == 0
+  tile(S0{}, kt, rem > 2, true);
+  tile(S1{}, kt + 1, rem > 3, rem > 2);
+  if (rem > 2) tile(S2{}, kt + 2, false, rem > 3);
+  if (rem > 3) tile(S0{}, kt + 3, false, false);
+
+  // ---- epilogue: park the tile in LDS ([token][plane][128 packed rows] of T), store whole 256-byte rows per column block --------------
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  const bool has_bias = a.bias != nullptr;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int p = p0 + wave * 16 + fg * 4 + r;
+      p = p < P ? p : P - 1;
+      bv[r] = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[j * P + p]) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      T out[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[j][i][r];
+        if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[r];  // product rounded to T, then the bias, then rounded (tensor/function.py:45-46)
+        out[r] = E::from_f32(v);
+      }
+      const int row = i * 16 + fr;
+      *reinterpret_cast<uint2*>(smem + row * OUT_PITCH + (j * BP + wave * 16 + fg * 4) * 2) = *reinterpret_cast<const uint2*>(out);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  T* yg = reinterpret_cast<T*>(a.y);
+  const bool full = (m0 + BM <= M) && (p0 + BP <= P) && (P % 8 == 0);
+#pragma unroll 4
+  for (int t = 0; t < BM * 32 / (NW * 64); ++t) {  // 32 chunks of 16 bytes per parked row, 16 rows per pass
+    const int row = t * 16 + (tid >> 5), c16 = tid & 31;
+    const uint4 v = *reinterpret_cast<const uint4*>(smem + row * OUT_PITCH + c16 * 16);
+    const int m = m0 + row;
+    const int j = c16 >> 4, pl = (c16 & 15) * 8;  // plane, first packed row of the chunk inside the tile
+    const size_t n = (size_t)j * P + p0 + pl;
+    if (full) {
+      __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + (size_t)m * N + n));
+    } else if (m < M) {
+      const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (p0 + pl + r < P) yg[(size_t)m * N + n + r] = e[r];
+    }
+  }
+}
+
+template <int DT, bool INT_SHIFT>
+static int launch(const Args& a, hipStream_t stream) {
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N / 2 + BP - 1) / BP, tiles = tiles_m * tiles_n;
+  Args b = a;
+  {
+    // per-XCD band of B tiles as a (g x B/g) rectangle: fetched bytes per k ~ g * BM * 2 (activations) + (B / g) * BP (packed weights)
+    const int band = (tiles + 7) / 8;
+    int g = 1;
+    while ((g + 1) * (g + 1) * 2 * BM <= band * BP) ++g;
+    const int forced = env_int("QUANTO_HIP_GROUP_M", 0);  // experiments
+    if (forced > 0) g = forced;
+    b.group_m = g < tiles_m ? g : tiles_m;
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_mfma_large_kernel<DT, INT_SHIFT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipLaunchKernelGGL((qbits_mfma_large_kernel<DT, INT_SHIFT>), dim3(tiles), dim3(NW * 64), LDS_BYTES, stream, b);
+  return launch_status();
+}
+
+}  // namespace l4
+
+bool qbits_mfma_large_supported(int64_t M, const PackedGeom& g, int dtype) {
+  return g.bits == 4 && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N % 2 == 0 && g.K % l4::BK == 0 && g.K >= 2 * l4::BK &&
+         g.C % l4::BK == 0 && M >= 1 && M * g.K < (1ll << 30) && g.N * g.K < (1ll << 32) && g.N * g.G < (1ll << 31) && g.N < (1 << 30) && M < (1 << 30);
+}
+
+int qbits_mm_mfma_large(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t M,
+                        const PackedGeom& g, int dtype, bool int_shift, hipStream_t stream) {
+  if (!qbits_mfma_large_supported(M, g, dtype)) return QUANTO_HIP_ENOTSUP;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(y)) % 16) return QUANTO_HIP_EALIGN;
+  l4::Args a{x, packed, scale, shift, bias, y, (int)M, (int)g.N, (int)g.K, (int)g.C, (int)g.G, 1};
+  if (dtype == QUANTO_HIP_BF16)
+    return int_shift ? l4::launch<QUANTO_HIP_BF16, true>(a, stream) : l4::launch<QUANTO_HIP_BF16, false>(a, stream);
+  return int_shift ? l4::launch<QUANTO_HIP_F16, true>(a, stream) : l4::launch<QUANTO_HIP_F16, false>(a, stream);
+}
+
+}  // namespace qh

@@ -20,9 +20,9 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # quanto_hip_dtype (include/quanto_hip.h)
 F32, F16, BF16, I8, U8, F8_E4M3FN, F8_E5M2, F8_E4M3FNUZ = range(8)
 WS_COUNTER_BYTES = 4096  # QUANTO_HIP_WS_COUNTER_BYTES
-KERNEL_AUTO, KERNEL_NAIVE, KERNEL_GEMV, KERNEL_MFMA, KERNEL_MFMA_LARGE, KERNEL_SKINNY, KERNEL_NATIVE8, KERNEL_DEQUANT_MFMA, KERNEL_MFMA_FUSED4, KERNEL_MMV = range(10)
+KERNEL_AUTO, KERNEL_NAIVE, KERNEL_GEMV, KERNEL_MFMA, KERNEL_MFMA_LARGE, KERNEL_SKINNY, KERNEL_NATIVE8, KERNEL_DEQUANT_MFMA, KERNEL_MFMA_FUSED4, KERNEL_MMV, KERNEL_MFMA_LARGE4 = range(11)
 KERNELS = {"auto": KERNEL_AUTO, "naive": KERNEL_NAIVE, "gemv": KERNEL_GEMV, "mfma": KERNEL_MFMA, "mfma_large": KERNEL_MFMA_LARGE, "skinny": KERNEL_SKINNY,
-           "mfma_native8": KERNEL_NATIVE8, "dequant_mfma": KERNEL_DEQUANT_MFMA, "mfma_fused4": KERNEL_MFMA_FUSED4, "mmv": KERNEL_MMV}
+           "mfma_native8": KERNEL_NATIVE8, "dequant_mfma": KERNEL_DEQUANT_MFMA, "mfma_fused4": KERNEL_MFMA_FUSED4, "mmv": KERNEL_MMV, "mfma_large4": KERNEL_MFMA_LARGE4}
 
 _DTYPES = {
     torch.float32: F32,
@@ -428,7 +428,7 @@ class QuantoHipExtension(NativeLibrary):
             "quanto_hip",
             root_dir=csrc,
             lib_path=os.path.join(_PKG_DIR, "lib", "libquanto_hip.so"),
-            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qmm_mfma_large.hip", "qmm_mfma_large32.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbytes_skinny.hip", "qmm_native8.hip", "quantize.hip",
+            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qmm_mfma_large.hip", "qmm_mfma_large32.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbits_mfma_large.hip", "qbytes_skinny.hip", "qmm_native8.hip", "quantize.hip",
                      "qh_common.h", os.path.join("..", "..", "include", "quanto_hip.h")],
         )
         self._bindings = None

@@ -633,6 +633,53 @@ def test_fp8a8_4096_cubed():
     assert_close_to_exact(y, want * s.astype(np.float64).reshape(1, -1), "bf16", "fp8a8 4096^3 (all rows)")
 
 
+def _rounded_weight_product(p, bias=None):
+    """float64 product with the reference's DEQUANTIZED weight (two roundings to the dtype, tensor/qbits.py:27-49) - the oracle of the
+    kernels that put scale / shift into the operand (dequantize + dense GEMM, the large-tile int4 GEMM)."""
+    w = O.dequantize_qbits_ref(p["packed"], p["bits"], p["scale"], p["shift"], 0, p["group_size"], (p["N"], p["K"]), p["dt"]).astype(np.float64)
+    return np.matmul(p["x"].astype(np.float64), w.T)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K,gs,zp,bias", [
+    (256, 256, 128, 128, False, False),     # one tile, two K-tiles (the shortest loop: tail only)
+    (300, 512, 1024, 128, False, True),     # ragged M, two feature tiles, bias
+    (512, 320, 640, 64, False, False),      # group size 64, packed rows not a multiple of 128 (ragged feature tile), odd K-tile count
+    (257, 768, 576, None, True, False),     # per-channel scales + integer zero-point, 9 K-tiles
+    (640, 256, 5120, 128, False, False),    # 40 groups: the scale / shift window (32 groups) is refilled while the loop runs
+    (256, 512, 14336, 128, True, True),     # Llama-3 down_proj depth: 112 groups, zero-point, bias
+    (1024, 1024, 4096, 128, False, False),  # 4 x 4 tiles: the XCD-aware raster
+    (384, 512, 2304, 192, False, False),    # group size 192 (a multiple of 64 that is not a power of two)
+])
+def test_large_tile_int4_gemm(dt, M, N, K, gs, zp, bias):
+    """qbits_mfma_large.hip (forced): packed int4 -> registers -> MFMA operands with the reference's rounding sequence.  Whole output
+    against the float64 product with the reference's dequantized weight (same gate as dequantize + dense GEMM: the operands ARE that
+    weight, bit for bit); power-of-two linearity."""
+    p = make_qbits_problem(M, N, K, dt, group_size=gs or K, zeropoint=zp, seed=M + N + K)
+    p["group_size"] = gs or K
+    b = O.round_to(np.random.default_rng(N).standard_normal(N).astype(np.float32), dt) if bias else None
+    q = dict(p, group_size=gs)  # the op takes None for per-channel
+    y = _run_qbits(q, "mfma_large4", bias=b)
+    want = _rounded_weight_product(p)
+    if bias:
+        assert_close_with_bias(y, want, b.astype(np.float64)[None, :], dt, f"large int4 {M}x{K}x{N} g{gs}")
+    else:
+        assert_close_to_exact(y, want, dt, f"large int4 {M}x{K}x{N} g{gs}")
+        np.testing.assert_array_equal(_run_qbits(dict(q, x=p["x"] * 2), "mfma_large4"), y * 2)
+
+
+def test_large_tile_int4_gemm_operands_are_the_dequantized_weight():
+    """x = identity: the product IS the operand matrix - every dequantized weight bit-identical to quanto::dequantize_qbits (which is
+    bit-identical to the reference's dequantize(), test_dequantize_qbits_bit_exact), for float shifts and zero-points, both dtypes."""
+    for dt in ("bf16", "fp16"):
+        for zp in (False, True):
+            p = make_qbits_problem(512, 512, 512, dt, group_size=128, zeropoint=zp, seed=3)
+            p["x"] = np.eye(512, dtype=np.float32)
+            y = _run_qbits(p, "mfma_large4")  # [512 tokens = k, 512 features]: y[k, n] = W[n, k]
+            w = O.dequantize_qbits_ref(p["packed"], 4, p["scale"], p["shift"], 0, 128, (512, 512), dt)
+            np.testing.assert_array_equal(y, w.T.astype(np.float32))
+
+
 def test_int4_prefill_4096_cubed():
     """bench workload int4_prefill at full size, whole output.  AUTO picks either the fused int4 GEMM (exact products of the
     stored integers, scale / shift folded in fp32: gate = exact math) or dequantize + dense GEMM (multiplies the reference's
@@ -640,8 +687,8 @@ def test_int4_prefill_4096_cubed():
     p = make_qbits_problem(4096, 4096, 4096, "bf16", seed=10)
     y = _run_qbits(p, "auto")
     kernel = quanto_hip.lib.last_kernel()
-    assert kernel in ("dequant_mfma", "mfma_fused4")
-    if kernel == "dequant_mfma":
+    assert kernel in ("dequant_mfma", "mfma_fused4", "mfma_large4")
+    if kernel in ("dequant_mfma", "mfma_large4"):
         w = O.dequantize_qbits_ref(p["packed"], 4, p["scale"], p["shift"], 0, 128, (4096, 4096), "bf16").astype(np.float64)
         want = np.matmul(p["x"].astype(np.float64), w.T)
     else:
