@@ -124,11 +124,25 @@ static bool mmv_wins(int64_t M, const PackedGeom& g) {
   return M <= env_int("QUANTO_HIP_MMV_MAX_M", 16) && g.N <= env_int("QUANTO_HIP_MMV_MAX_N", 4096) && g.K <= 4096;
 }
 
+// Large-tile int4 GEMM (qbits_mfma_large.hip: reference-rounded operands built in registers, no workspace, 2 x less traffic) against
+// dequantize + dense GEMM, r4, us (bf16, group size 128): 4096^3 138.9 / 116.8, (2048,4096,4096) 107.8 / 83.7, (8192,4096,4096) 253 / 217,
+// (4096,4096,14336) 478 / 418, (4096,14336,4096) 420 / 412, (1024,4096,14336) 118.5 / 121.6, 8192^3 961 / 1346: its conversion costs
+// ~2.9 VALU per MFMA, the dense path's dequantize pass is paid once - the fused kernel wins where the dense weight (N*K*2 bytes written and
+// re-read) no longer sits in the caches, and it is what AUTO takes at prefill sizes when the caller has no workspace at all.
+static bool large4_wins(int64_t M, const PackedGeom& g, bool have_workspace) {
+  const int mode = env_int("QUANTO_HIP_LARGE4", 1);  // experiments: 0 never, 2 whenever supported
+  if (mode == 0) return false;
+  if (mode == 2) return M > 192;
+  if (!have_workspace) return M > 1024;  // otherwise: passes of the streaming kernel / the one-thread-per-output kernel
+  return M >= 4096 && g.N >= 8192 && g.K >= 8192;
+}
+
 static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {
   if (M <= env_int("QUANTO_HIP_GEMV_MAX_M", 4) && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
   if (mmv_wins(M, g) && qbits_mmv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MMV;
   if (fused4_wins(M, g) && qbits_mfma_fused_supported(M, g, dtype) && (have_workspace || !qbits_mfma_fused_needs_workspace(g)))
     return QUANTO_HIP_KERNEL_MFMA_FUSED4;
+  if (large4_wins(M, g, have_workspace) && qbits_mfma_large_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MFMA_LARGE4;
   // the streaming kernel's time grows with M (passes of 64 rows), dequantize + dense GEMM is flat in M up to 1024 rows:
   // (M, 4096, 4096) us streaming / dequantize + GEMM: M = 128 34 / 56, M = 256 66 / 54; (256, 14336, 4096) 116 / 79; but
   // (256, 4096, 14336) 127 / 167

@@ -13,12 +13,16 @@
 // Workgroup = 8 waves, 256 tokens x 128 PACKED rows (= 256 features: byte (p,k) = W[p,k] | W[p+N/2,k] << 4, so the output tile is two
 // 128-wide column blocks, at p0 and at N/2 + p0).  All waves side by side along the features (1 x 8): wave w owns packed rows
 // 16w..16w+15 (32 features, both nibble planes) and ALL 256 tokens - every weight is converted exactly once per workgroup, which is
-// what makes the conversion affordable (7 VALU per pair of weights: 2 cvt_f32_ubyte, pk_mul, 2 roundings, pk_add, cvt_pk; ~1.9 VALU
-// per MFMA; a 2 x 4 layout would convert everything twice).
-//   * activations: LDS-DMA ring of three 32 KiB stages (global_load_lds_dwordx4, swizzled as in qmm_mfma_large.hip), fragments two
+// what makes the conversion affordable (11 VALU per pair of weights: 2 cvt_f32_ubyte, 2 mul, 2 x (cvt_pk + shift) for the first rounding,
+// 2 sub, cvt_pk; ~2.9 VALU per MFMA; a 2 x 4 layout would convert everything twice).
+// SCALAR fp32 math on purpose (and -fno-slp-vectorize for this file): with v_pk_mul_f32 / v_pk_add_f32 - 4 VALU per pair fewer - one
+// operand element of the last 16 lanes came out wrong in one wave every few launches (always a v_pk_add_f32 whose low lane takes the HIGH
+// half of its source pair, op_sel:[0,1], issued in the shadow of an MFMA; never reproduced with scalar instructions: r4,
+// profiles/r04_packed_fp32_next_to_mfma.md).
+//   * activations: LDS-DMA ring of three stages (32 KiB each) (global_load_lds_dwordx4, swizzled as in qmm_mfma_large.hip), fragments two
 //     steps ahead through a ring of four;
-//   * weights never touch the LDS: a wave reads only its own 16 packed rows, so lane (r = lane & 15, g = lane >> 4) loads its 16 bytes
-//     (k = 16g..16g+15 of the K-tile, both planes) straight into a register ring, two K-tiles ahead;
+//   * packed weights ride the same ring (8 KiB per stage); a wave only ever reads back the 16 packed rows it fetched itself: lane
+//     (r = lane & 15, g = lane >> 4) takes its 16 bytes (k = 16g..16g+15 of the K-tile, both planes) with one ds_read_b128 per K-tile;
 //   * scale / shift: a 32-group window per workgroup in LDS ({s, z} pairs, 32 KiB; K = 4096 never refills), refilled 8 groups at a time while the loop runs (K = 14336
 //     has 112 groups); a lane re-reads its two entries once per K-tile;
 //   * step (kk, i), 32 per K-tile: 2 MFMAs (both planes) x token fragment i; phase kk = 0 converts this tile's k-half-1 operands,
@@ -37,6 +41,7 @@ using lt::glds16;
 using lt::lds_ptr_t;
 using lt::Mma;
 using lt::swz_a;
+using lt::swz_w;
 
 constexpr int BM = 256;           // tokens per workgroup
 constexpr int BP = 128;           // packed rows per workgroup (256 features)
@@ -44,13 +49,15 @@ constexpr int NW = 8;             // waves
 constexpr int MI = BM / 16;       // token fragments per wave (all of them)
 constexpr int STEPS = 2 * MI;     // (k-half, token fragment)
 constexpr int STAGES = 3;
-constexpr int A_BYTES = BM * BK * 2;          // 32 KiB per stage
+constexpr int A_BYTES = BM * BK * 2;          // 32 KiB of activations per stage
+constexpr int W_BYTES = BP * BK;              // + 8 KiB of packed weights
+constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
 constexpr int APIECES = BM / 8 / NW;          // 4 activation DMA pieces (8 rows x 128 B) per wave and K-tile
 constexpr int TG = 32, TH = 8;                // groups in the table window / per refill unit
 constexpr int TAB_BYTES = TG * 2 * BP * 4;    // [slot][plane][row] {scale, shift} as two T: 32 KiB
 constexpr int OUT_PITCH = 2 * BP * 2 + 16;    // parked output row: 256 features of T + padding
-constexpr int LOOP_BYTES = STAGES * A_BYTES + TAB_BYTES;                                 // 128 KiB while the K loop runs
-constexpr int LDS_BYTES = LOOP_BYTES > BM * OUT_PITCH ? LOOP_BYTES : BM * OUT_PITCH;     // 132 KiB: the epilogue parks the output tile over the ring + table
+constexpr int LOOP_BYTES = STAGES * STAGE_BYTES + TAB_BYTES;                             // 152 KiB while the K loop runs
+constexpr int LDS_BYTES = LOOP_BYTES > BM * OUT_PITCH ? LOOP_BYTES : BM * OUT_PITCH;     // the epilogue parks the output tile (132 KiB) over the ring + table
 
 struct Args {
   const void* x;
@@ -67,29 +74,15 @@ struct Args {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-// T(v) as an fp32 number: the first of the reference's two roundings, kept in fp32 for the subtraction that follows.
-// bf16: v_cvt_pk_bf16_f32 with a zero LOW half is the fp32 image of the rounded value - one instruction.  (Written as C++ - a bf16x2 with a
-// zero element, bit-cast to float - hipcc converts into the low half and moves it up with a v_perm: two instructions.)
+// T(v) as an fp32 number: the first of the reference's two roundings, kept in fp32 for the subtraction that follows (bf16: v_cvt_pk_bf16_f32
+// + a 16-bit shift.  v_cvt_pk_bf16_f32 with a zero LOW half would be the fp32 image in one instruction, but hipcc only emits that form
+// from inline asm, and with it this kernel spills: 138.9 -> 144.6 us at 4096^3).
 template <int DT>
 __device__ __forceinline__ float round_to_T(float v) {
-  if constexpr (DT == QUANTO_HIP_BF16) {
-    float r;
-    asm("v_cvt_pk_bf16_f32 %0, 0, %1" : "=v"(r) : "v"(v));
-    return r;
-  } else {
+  if constexpr (DT == QUANTO_HIP_BF16)
+    return (float)(__bf16)v;
+  else
     return (float)(_Float16)v;
-  }
-}
-
-// byte B of `v` as a float (v_cvt_f32_ubyteB: hipcc otherwise extracts the byte first - v_and_b32_sdwa + v_cvt_f32_ubyte0)
-template <int B>
-__device__ __forceinline__ float ubyte_to_f32(uint32_t v) {
-  float r;
-  if constexpr (B == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(v));
-  if constexpr (B == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(v));
-  if constexpr (B == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(v));
-  if constexpr (B == 3) asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(v));
-  return r;
 }
 
 // two fp32 -> one dword of T, round to nearest even (lt::Mma<F16>::pack rounds toward zero: exact only for the 8-bit formats it serves)
@@ -112,30 +105,28 @@ __device__ __forceinline__ uint32_t pack_rne(float a, float b) {
 // the factor 16 is folded into s / zp below, exactly: powers of two).  `PAIR`: byte pair 0 / 1 of the dword.
 template <int DT, bool INT_SHIFT, int PAIR>
 __device__ __forceinline__ uint32_t convert_pair4(uint32_t spread, float s, float z) {
-  const f32x2 s2{s, s}, z2{z, z};  // one register each: the packed ops broadcast the low half (op_sel)
-  f32x2 q;
-  q.x = ubyte_to_f32<2 * PAIR>(spread);
-  q.y = ubyte_to_f32<2 * PAIR + 1>(spread);
+  // `spread` is opaque to the optimizer (see convert): these two are v_cvt_f32_ubyte{0,1} / {2,3}, emitted by the compiler
+  const float q0 = (float)((spread >> (16 * PAIR)) & 0xFFu), q1 = (float)((spread >> (16 * PAIR + 8)) & 0xFFu);
   if constexpr (INT_SHIFT) {
-    const f32x2 t = (q - z2) * s2;  // (q - zp) exact, one rounding (tensor/qbits.py:35-42)
-    return pack_rne<DT>(t.x, t.y);
+    return pack_rne<DT>((q0 - z) * s, (q1 - z) * s);  // (q - zp) exact, one rounding (tensor/qbits.py:35-42)
   } else {
-    const f32x2 t = q * s2;         // exact in fp32 (8 x 4 significant bits) ...
-    f32x2 r;
-    r.x = round_to_T<DT>(t.x);      // ... rounded to T as `scale * data` is (tensor/qbits.py:41)
-    r.y = round_to_T<DT>(t.y);
-    const f32x2 u = r - z2;         // `dqt -= shift` (:44): fp32 difference of two T values, rounded to T by the pack
-    return pack_rne<DT>(u.x, u.y);
+    // q * s is exact in fp32 (8 x 4 significant bits), rounded to T as `scale * data` is (tensor/qbits.py:41); `dqt -= shift` (:44) is
+    // the fp32 difference of two T values, rounded to T by the pack
+    const float r0 = round_to_T<DT>(q0 * s), r1 = round_to_T<DT>(q1 * s);
+    return pack_rne<DT>(r0 - z, r1 - z);
   }
 }
 
-template <int DT, bool INT_SHIFT>
+// FULLM: M is a multiple of 256 - the activation rows of DMA piece j are the lane's piece-0 row + 64 j, a wave-uniform byte offset added to
+// the SGPR base (one VGPR for all four pieces).  Ragged M clamps every row to M - 1 and recomputes the lane's offset per piece
+// (3 VALU each): four live VGPRs more made hipcc spill INSIDE the loop - among others the registers of weight loads still in flight.
+template <int DT, bool INT_SHIFT, bool FULLM>
 __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args a) {
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint32_t* tab = reinterpret_cast<uint32_t*>(smem + STAGES * A_BYTES);
+  uint32_t* tab = reinterpret_cast<uint32_t*>(smem + STAGES * STAGE_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,35 +139,42 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
   const int m0 = tm * BM, p0 = tn * BP;
 
   // ---- activation DMA (qmm_mfma_large.hip's image: 8 rows x 128 B per piece, chunk c of row R stored at position c ^ swz_a(R)) ----
-  uint32_t asrc[APIECES];
-#pragma unroll
-  for (int j = 0; j < APIECES; ++j) {
-    const int R = (j * NW + wave) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ swz_a(R);
-    int m = m0 + R;
-    m = m < M ? m : M - 1;
-    asrc[j] = ((uint32_t)m * (uint32_t)K + (uint32_t)(c * 8)) * 2u;  // 32-bit arithmetic: M * K < 2^30 (launcher)
-  }
+  // piece j of wave w: rows (j * NW + w) * 8 + (lane >> 3); the swizzle only depends on the row modulo 16, i.e. not on j
+  const int arow = m0 + wave * 8 + (lane >> 3);
+  const uint32_t acol = (uint32_t)(((lane & 7) ^ swz_a(wave * 8 + (lane >> 3))) * 16);
+  const uint32_t asrc0 = (uint32_t)(arow < M ? arow : M - 1) * (uint32_t)K * 2u + acol;  // 32-bit arithmetic: M * K < 2^30 (launcher)
+  auto a_offset = [&](int j) -> uint32_t {  // the lane's byte offset of piece j (ragged M)
+    const int r = arow + j * (NW * 8);
+    return (uint32_t)(r < M ? r : M - 1) * (uint32_t)K * 2u + acol;
+  };
+  const size_t apiece_stride = (size_t)(NW * 8) * K * 2;  // FULLM: piece j = piece 0 + j * 64 rows
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
   const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.x);
   uint32_t adst[STAGES][APIECES];
 #pragma unroll
   for (int t = 0; t < STAGES; ++t)
 #pragma unroll
-    for (int j = 0; j < APIECES; ++j) adst[t][j] = __builtin_amdgcn_readfirstlane(lds_base + t * A_BYTES + (j * NW + wave) * 1024);
+    for (int j = 0; j < APIECES; ++j) adst[t][j] = __builtin_amdgcn_readfirstlane(lds_base + t * STAGE_BYTES + (j * NW + wave) * 1024);
 
-  // ---- weights: lane (r, g) owns bytes 16g..16g+15 of packed row p0 + 16 wave + r of every K-tile --------------------------------
+  // ---- weights: wave w DMAs its own 16 packed rows (one 1 KiB piece per K-tile: lane -> row lane >> 2, 16-byte chunk (lane & 3) ^ swz_w(row),
+  // qmm_mfma_large.hip's image) and reads them back as fragments: lane (fr, fg) = the 16 bytes k = 16 fg .. 16 fg + 15 of row 16 w + fr.
+  // Through the LDS, not straight into registers: an asm global_load hands its result to a C++ variable long before the data arrives,
+  // and hipcc is free to copy that variable (a v_mov at the loop back-edge, a spill) before the counted wait - r4, first version of this
+  // kernel: one wrong operand element per few launches.  LDS-DMA writes no register; the ds_read below is compiler-visible.
   const int fr = lane & 15, fg = lane >> 4;
-  uint32_t wofs;
+  uint32_t wsrc;
   {
-    int p = p0 + wave * 16 + fr;
+    const int R = wave * 16 + (lane >> 2);
+    int p = p0 + R;
     p = p < P ? p : P - 1;
-    wofs = (uint32_t)p * (uint32_t)K + (uint32_t)(fg * 16);      // N * K < 2^32 (launcher)
+    wsrc = (uint32_t)p * (uint32_t)K + (uint32_t)(((lane & 3) ^ swz_w(R)) * 16);  // N * K < 2^32 (launcher)
   }
-  u32x4 raw[STAGES];  // raw[t % 3]: tile t's bytes (.x .y = k-half 0, .z .w = k-half 1)
-  auto load_w = [&](int kt, u32x4& dst) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(wofs), "s"(a.w + (size_t)kt * BK) : "memory");
-  };
+  uint32_t wdst[STAGES];
+#pragma unroll
+  for (int t = 0; t < STAGES; ++t) wdst[t] = __builtin_amdgcn_readfirstlane(lds_base + t * STAGE_BYTES + A_BYTES + wave * 1024);
+  const int woff = A_BYTES + (wave * 16 + fr) * 64 + ((fg ^ swz_w(wave * 16 + fr)) << 4);
+  u32x4 raw;  // the bytes being converted: tile t's from the start of tile t - 1's second phase (.x .y = k-half 0) to the end of tile t's first (.z .w)
+  auto read_w = [&](int stage) { return *reinterpret_cast<const u32x4*>(smem + stage * STAGE_BYTES + woff); };
 
   // ---- fragment read offsets (activations): chunk 2 fg + kk of row fr (+ 16 i), see qmm_mfma_large.hip ------------------------------
   int aoff[2];
@@ -242,7 +240,8 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
   auto convert = [&](const u32x4& r, int kk, int c, const float (&s2)[2], const float (&z2)[2]) -> uint32_t {
     const int j = c >> 2, d = c & 3;
     const uint32_t word = kk == 0 ? (d < 2 ? r.x : r.y) : (d < 2 ? r.z : r.w);
-    const uint32_t spread = j == 0 ? (word & 0x0F0F0F0Fu) : (word & 0xF0F0F0F0u);
+    uint32_t spread = j == 0 ? (word & 0x0F0F0F0Fu) : (word & 0xF0F0F0F0u);
+    asm("" : "+v"(spread));  // keeps hipcc from folding the nibble mask into per-byte extractions (v_and_b32_sdwa + v_cvt_f32_ubyte0 per weight)
     return (d & 1) ? convert_pair4<DT, INT_SHIFT, 1>(spread, s2[j], z2[j]) : convert_pair4<DT, INT_SHIFT, 0>(spread, s2[j], z2[j]);
   };
 
@@ -252,15 +251,22 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
     table_fetch(g0);
     table_store(g0);
   }
+  auto issue_w = [&](int kt, int stage) { glds16(a.w + (size_t)kt * BK, wsrc, wdst[stage]); };
+  auto issue_a = [&](int kt, int piece, uint32_t dst) {
+    if constexpr (FULLM)
+      glds16(xbase + (size_t)kt * (BK * 2) + piece * apiece_stride, asrc0, dst);
+    else
+      glds16(xbase + (size_t)kt * (BK * 2), a_offset(piece), dst);
+  };
 #pragma unroll
-  for (int p = 0; p < APIECES; ++p) glds16(xbase, asrc[p], adst[0][p]);
-  load_w(0, raw[0]);
+  for (int p = 0; p < APIECES; ++p) issue_a(0, p, adst[0][p]);
+  issue_w(0, 0);
   if (nk > 1) {
 #pragma unroll
-    for (int p = 0; p < APIECES; ++p) glds16(xbase + (size_t)BK * 2, asrc[p], adst[1][p]);
-    load_w(1, raw[1]);
+    for (int p = 0; p < APIECES; ++p) issue_a(1, p, adst[1][p]);
+    issue_w(1, 1);
   }
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1])::"memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
@@ -268,17 +274,18 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
   int g_cur = 0, k_in_g = 0;
   float sc[2], zc[2], sn[2], zn[2];  // scale / shift (per plane) of the current and of the next tile's group
   table_read(0, sc, zc);
+  raw = read_w(0);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) w0[c >> 2][c & 3] = convert(raw[0], 0, c, sc, zc);
+  for (int c = 0; c < 8; ++c) w0[c >> 2][c & 3] = convert(raw, 0, c, sc, zc);
   xf[0] = *reinterpret_cast<const V8*>(smem + aoff[0]);
   xf[1] = *reinterpret_cast<const V8*>(smem + aoff[0] + 2048);
-  int refill_g0 = -1;  // first group of the unit fetched into `pend`, to be stored at the next tile boundary
+  xf[2] = *reinterpret_cast<const V8*>(smem + aoff[0] + 4096);
 
   auto tile = [&](auto p_tag, int kt, auto dma_tag, auto barrier_tag) {
     constexpr int PS = decltype(p_tag)::value, PN = (PS + 1) % STAGES, PF = (PS + 2) % STAGES;
     const bool dma = dma_tag, barrier = barrier_tag;  // integral_constants in the steady state (no branches), run-time flags in the tail
-    const uint8_t* st = smem + PS * A_BYTES;
-    const uint8_t* sx = smem + PN * A_BYTES;
+    const uint8_t* st = smem + PS * STAGE_BYTES;
+    const uint8_t* sx = smem + PN * STAGE_BYTES;
     // the next tile's group
     int g_next = g_cur, k_next = k_in_g + BK;
     if (k_next >= C) {
@@ -288,7 +295,10 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       const int kk = s / MI, i = s % MI;
-      if (s == MI) table_read(g_next, sn, zn);  // before the first conversion of the second phase
+      if (s == MI) {  // before the first conversion of the second phase: the next tile's scale / shift and packed bytes
+        table_read(g_next, sn, zn);
+        raw = read_w(PN);
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (kk == 0)
@@ -300,38 +310,37 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
           if ((i & 1) == 0) {
             const int c = i >> 1;
             if (kk == 0)
-              w1[c >> 2][c & 3] = convert(raw[PS], 1, c, sc, zc);   // this tile's k-half 1
+              w1[c >> 2][c & 3] = convert(raw, 1, c, sc, zc);   // this tile's k-half 1
             else
-              w0[c >> 2][c & 3] = convert(raw[PN], 0, c, sn, zn);   // next tile's k-half 0 (garbage, unused, behind the last tile)
+              w0[c >> 2][c & 3] = convert(raw, 0, c, sn, zn);   // next tile's k-half 0 (garbage, unused, behind the last tile)
           }
         } else {
-          // activation fragment of step s + 2 (the next tile's first two at the end)
-          xf[(s + 2) & 3] = s + 2 < STEPS ? *reinterpret_cast<const V8*>(st + aoff[(s + 2) / MI] + ((s + 2) % MI) * 2048)
-                                          : *reinterpret_cast<const V8*>(sx + aoff[0] + (s + 2 - STEPS) * 2048);
+          // activation fragment of step s + AHEAD (the next tile's first ones at the end): a step is only two MFMAs (~36 cycles of
+          // matrix pipe), so the ring of four is used to its full depth - three fragments in flight behind the one in use
+          constexpr int AHEAD = 3;
+          xf[(s + AHEAD) & 3] = s + AHEAD < STEPS ? *reinterpret_cast<const V8*>(st + aoff[(s + AHEAD) / MI] + ((s + AHEAD) % MI) * 2048)
+                                                  : *reinterpret_cast<const V8*>(sx + aoff[0] + (s + AHEAD - STEPS) * 2048);
           if (s < APIECES) {
-            if (dma) glds16(xbase + (size_t)(kt + 2) * (BK * 2), asrc[s], adst[PF][s]);
+            if (dma) issue_a(kt + 2, s, adst[PF][s]);
           } else if (s == APIECES) {
-            if (dma) load_w(kt + 2, raw[PF]);
+            if (dma) issue_w(kt + 2, PF);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // tile boundary: own DMA share + weight bytes of tile kt + 2 (and a pending table half) have landed -> barrier
+    // tile boundary: own DMA share + weight bytes of tile kt + 2 have landed -> barrier
     if (barrier) {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[PF])::"memory");
-      if (refill_g0 >= 0) {
-        table_store(refill_g0);
-        refill_g0 = -1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the next tile opens a new unit of TH groups: every group of the unit before it is dead (its last reader was the table_read of the
+      // PREVIOUS tile, behind that tile's barrier) -> its slots take the groups one window further, first read TG - TH groups from now.
+      // Fetched and stored right here, before the barrier (only K > 32 groups ever gets here: ~1.5 us every 8 groups)
+      if (g_next != g_cur && g_next % TH == 0 && g_next >= TH && g_next - TH + TG < G) {
+        table_fetch(g_next - TH + TG);
+        table_store(g_next - TH + TG);
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      // the next tile opens a new unit of TH groups: every group of the unit before it is dead (its last reader was the table_read
-      // above) -> its slots take the groups one window further; stored at the next boundary, first read TG - TH groups later
-      if (g_next != g_cur && g_next % TH == 0 && g_next >= TH && g_next - TH + TG < G) {
-        table_fetch(g_next - TH + TG);
-        refill_g0 = g_next - TH + TG;
-      }
     }
     g_cur = g_next;
     k_in_g = k_next;
@@ -407,8 +416,8 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
   }
 }
 
-template <int DT, bool INT_SHIFT>
-static int launch(const Args& a, hipStream_t stream) {
+template <int DT, bool INT_SHIFT, bool FULLM>
+static int launch_m(const Args& a, hipStream_t stream) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N / 2 + BP - 1) / BP, tiles = tiles_m * tiles_n;
   Args b = a;
   {
@@ -420,9 +429,14 @@ static int launch(const Args& a, hipStream_t stream) {
     if (forced > 0) g = forced;
     b.group_m = g < tiles_m ? g : tiles_m;
   }
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_mfma_large_kernel<DT, INT_SHIFT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  hipLaunchKernelGGL((qbits_mfma_large_kernel<DT, INT_SHIFT>), dim3(tiles), dim3(NW * 64), LDS_BYTES, stream, b);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_mfma_large_kernel<DT, INT_SHIFT, FULLM>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipLaunchKernelGGL((qbits_mfma_large_kernel<DT, INT_SHIFT, FULLM>), dim3(tiles), dim3(NW * 64), LDS_BYTES, stream, b);
   return launch_status();
+}
+template <int DT, bool INT_SHIFT>
+static int launch(const Args& a, hipStream_t stream) {
+  return a.M % BM == 0 ? launch_m<DT, INT_SHIFT, true>(a, stream) : launch_m<DT, INT_SHIFT, false>(a, stream);
 }
 
 }  // namespace l4
