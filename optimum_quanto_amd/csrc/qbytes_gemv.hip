@@ -30,6 +30,16 @@ __device__ __forceinline__ void decode_word<QUANTO_HIP_F8_E5M2>(uint32_t w, floa
   f[0] = lo.x; f[1] = lo.y; f[2] = hi.x; f[3] = hi.y;
 }
 
+template <>
+__device__ __forceinline__ void decode_word<QUANTO_HIP_F8_E4M3FNUZ>(uint32_t w, float (&f)[4]) {  // qh_common.h: fn value / 2 + three patched patterns
+  const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
+  const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+  f[0] = fnuz_fix_f32(lo.x * 0.5f, w & 0xFFu);
+  f[1] = fnuz_fix_f32(lo.y * 0.5f, (w >> 8) & 0xFFu);
+  f[2] = fnuz_fix_f32(hi.x * 0.5f, (w >> 16) & 0xFFu);
+  f[3] = fnuz_fix_f32(hi.y * 0.5f, w >> 24);
+}
+
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
@@ -227,16 +237,18 @@ static int gemv8_dispatch(const void* a, const GemvProblem8& pb, int M, int K, i
   if (out_dtype == QUANTO_HIP_BF16) {
     if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_BF16, QUANTO_HIP_I8);
     if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_BF16, QUANTO_HIP_F8_E4M3FN);
+    if (b_dtype == QUANTO_HIP_F8_E4M3FNUZ) QH_CASE(QUANTO_HIP_BF16, QUANTO_HIP_F8_E4M3FNUZ);
     QH_CASE(QUANTO_HIP_BF16, QUANTO_HIP_F8_E5M2);
   }
   if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_F16, QUANTO_HIP_I8);
   if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_F16, QUANTO_HIP_F8_E4M3FN);
+  if (b_dtype == QUANTO_HIP_F8_E4M3FNUZ) QH_CASE(QUANTO_HIP_F16, QUANTO_HIP_F8_E4M3FNUZ);
   QH_CASE(QUANTO_HIP_F16, QUANTO_HIP_F8_E5M2);
 #undef QH_CASE
 }
 
 bool qbytes_gemv_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
-  const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2;
+  const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2 || b_dtype == QUANTO_HIP_F8_E4M3FNUZ;
   return bd && a_dtype == out_dtype && (out_dtype == QUANTO_HIP_BF16 || out_dtype == QUANTO_HIP_F16) && M >= 1 &&
          M <= QUANTO_HIP_GEMV_MAX_M && K % 16 == 0 && K <= 16384 && N < (1 << 30);
 }

@@ -64,7 +64,7 @@ struct Mma<QUANTO_HIP_F16> {
   static __device__ __forceinline__ uint32_t pack(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 };
 
-enum { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2 };
+enum { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2, W_F8E4M3FNUZ = 3 };
 
 // bytes (2p, 2p+1) of `word` -> two 16-bit elements (exact: every int8 / fp8 value is representable in bf16 and fp16);
 // fp8 / bf8 in one op with gfx950's v_cvt_scalef32_pk_{bf16,f16}_{fp8,bf8} at scale 1.0 (see qmm_large_common.h)
@@ -74,6 +74,8 @@ __device__ __forceinline__ uint32_t convert_pair(uint32_t word, int p) {
     const float f0 = p == 0 ? (float)(int8_t)(word & 0xFFu) : (float)(int8_t)((word >> 16) & 0xFFu);
     const float f1 = p == 0 ? (float)(int8_t)((word >> 8) & 0xFFu) : (float)(int8_t)(word >> 24);
     return Mma<DT>::pack(f0, f1);
+  } else if constexpr (FMT == W_F8E4M3FNUZ) {
+    return DT == QUANTO_HIP_BF16 ? fnuz_pair_bf16(word, p) : fnuz_pair_f16(word, p);  // qh_common.h
   } else if constexpr (FMT == W_F8E4M3) {
     if constexpr (DT == QUANTO_HIP_BF16)
       return __builtin_bit_cast(uint32_t, p == 0 ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)word, 1.0f, false)
@@ -375,7 +377,7 @@ static int skinny8_split(int64_t N, int64_t K) {
 static size_t skinny8_counter_bytes(int64_t) { return QUANTO_HIP_WS_COUNTER_BYTES; }
 
 bool qbytes_skinny_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
-  const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2;
+  const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2 || b_dtype == QUANTO_HIP_F8_E4M3FNUZ;
   return bd && a_dtype == out_dtype && (out_dtype == QUANTO_HIP_BF16 || out_dtype == QUANTO_HIP_F16) && K % skinny8::BK == 0 && M >= 1 &&
          M <= QUANTO_HIP_SKINNY_MAX_M && N >= 1 && N < (1 << 30) && K < (1 << 30);
 }
@@ -404,6 +406,7 @@ int qbytes_mm_skinny(const void* x, const void* w, const void* s, const void* bi
 #define QH_FMT(DT)                                                                              \
   r = b_dtype == QUANTO_HIP_I8 ? skinny8::launch_tf<DT, skinny8::W_I8>(a, stream)               \
       : b_dtype == QUANTO_HIP_F8_E4M3FN ? skinny8::launch_tf<DT, skinny8::W_F8E4M3>(a, stream)  \
+      : b_dtype == QUANTO_HIP_F8_E4M3FNUZ ? skinny8::launch_tf<DT, skinny8::W_F8E4M3FNUZ>(a, stream) \
                                         : skinny8::launch_tf<DT, skinny8::W_F8E5M2>(a, stream)
     if (out_dtype == QUANTO_HIP_BF16) {
       QH_FMT(QUANTO_HIP_BF16);
@@ -463,6 +466,7 @@ int qbytes_mm_skinny_multi(const void* x, int nseg, const void* const* w, const 
 #define QH_FMT(DT)                                                                                        \
   r = b_dtype == QUANTO_HIP_I8 ? skinny8::launch_tf<DT, skinny8::W_I8>(a, stream, &segs, fb)              \
       : b_dtype == QUANTO_HIP_F8_E4M3FN ? skinny8::launch_tf<DT, skinny8::W_F8E4M3>(a, stream, &segs, fb) \
+      : b_dtype == QUANTO_HIP_F8_E4M3FNUZ ? skinny8::launch_tf<DT, skinny8::W_F8E4M3FNUZ>(a, stream, &segs, fb) \
                                         : skinny8::launch_tf<DT, skinny8::W_F8E5M2>(a, stream, &segs, fb)
   if (out_dtype == QUANTO_HIP_BF16) {
     QH_FMT(QUANTO_HIP_BF16);

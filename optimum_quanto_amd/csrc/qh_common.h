@@ -58,6 +58,38 @@ __device__ __forceinline__ float decode_e4m3fnuz(uint32_t b) {
   return (b & 0x80u) ? -v : v;
 }
 
+// e4m3fnuz on the OCP converters (r4): an fnuz byte is the e4m3fn value of the same bits times 1/2 (exponent bias 8 instead of 7; the
+// subnormals m * 2^-10 = fn's m * 2^-9 halved), except for the three patterns the two formats disagree on: 0x7F / 0xFF are +-240 in fnuz
+// (NaN in fn) and 0x80 is fnuz's only NaN (-0 in fn).  The hardware converts with scale 0.5 (a power of two: exact), the three patterns are
+// patched - they are rare but real: the absmax element of every row quantizes to +-240.
+__device__ __forceinline__ float fnuz_fix_f32(float half_of_fn, uint32_t byte) {
+  float v = half_of_fn;
+  if ((byte & 0x7Fu) == 0x7Fu) v = (byte & 0x80u) ? -240.f : 240.f;
+  if (byte == 0x80u) v = __builtin_nanf("");
+  return v;
+}
+// two T elements (bytes 2p, 2p + 1 of `word`); MAX_T / NAN_T: 240.0 and a quiet NaN in T
+template <uint32_t MAX_T, uint32_t NAN_T>
+__device__ __forceinline__ uint32_t fnuz_fix_pair(uint32_t converted, uint32_t word, int p) {
+  const uint32_t b0 = (word >> (16 * p)) & 0xFFu, b1 = (word >> (16 * p + 8)) & 0xFFu;
+  uint32_t lo = converted & 0xFFFFu, hi = converted >> 16;
+  if ((b0 & 0x7Fu) == 0x7Fu) lo = MAX_T | ((b0 & 0x80u) << 8);
+  if ((b1 & 0x7Fu) == 0x7Fu) hi = MAX_T | ((b1 & 0x80u) << 8);
+  if (b0 == 0x80u) lo = NAN_T;
+  if (b1 == 0x80u) hi = NAN_T;
+  return lo | (hi << 16);
+}
+__device__ __forceinline__ uint32_t fnuz_pair_bf16(uint32_t word, int p) {
+  const uint32_t c = __builtin_bit_cast(uint32_t, p == 0 ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)word, 0.5f, false)
+                                                         : __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)word, 0.5f, true));
+  return fnuz_fix_pair<0x4370u, 0x7FC0u>(c, word, p);
+}
+__device__ __forceinline__ uint32_t fnuz_pair_f16(uint32_t word, int p) {
+  const uint32_t c = __builtin_bit_cast(uint32_t, p == 0 ? __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)word, 0.5f, false)
+                                                         : __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)word, 0.5f, true));
+  return fnuz_fix_pair<0x5B80u, 0x7E00u>(c, word, p);
+}
+
 template <int DT>
 __device__ __forceinline__ float decode8(uint8_t b);
 template <>

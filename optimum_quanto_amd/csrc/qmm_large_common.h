@@ -46,7 +46,7 @@ struct Mma<QUANTO_HIP_F16> {
   }
 };
 
-enum { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2, W_DENSE = 3 };  // W_DENSE: weights already in the activation dtype (weights-direct loop only)
+enum { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2, W_DENSE = 3, W_F8E4M3FNUZ = 4 };  // W_DENSE: weights already in the activation dtype (weights-direct loop only)
 
 __device__ __forceinline__ int swz_a(int row) {
   const int q = (row + 4) & 15;
@@ -63,6 +63,8 @@ __device__ __forceinline__ uint32_t convert_pair(uint32_t word, int p) {
     const float f0 = p == 0 ? (float)(int8_t)(word & 0xFFu) : (float)(int8_t)((word >> 16) & 0xFFu);
     const float f1 = p == 0 ? (float)(int8_t)((word >> 8) & 0xFFu) : (float)(int8_t)(word >> 24);
     return Mma<DT>::pack(f0, f1);
+  } else if constexpr (FMT == W_F8E4M3FNUZ) {
+    return DT == QUANTO_HIP_BF16 ? fnuz_pair_bf16(word, p) : fnuz_pair_f16(word, p);  // qh_common.h: fn / 2 + three patched patterns
   } else if constexpr (FMT == W_F8E4M3) {
     if constexpr (DT == QUANTO_HIP_BF16)
       return __builtin_bit_cast(uint32_t, p == 0 ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)word, 1.0f, false)

@@ -557,7 +557,7 @@ static int launch(const Args& a, int cfg, hipStream_t stream) {
 int qbytes_mm_mfma_large32(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, hipStream_t);
 
 bool qbytes_mfma_large_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
-  const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2;
+  const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2 || b_dtype == QUANTO_HIP_F8_E4M3FNUZ;
   return bd && a_dtype == out_dtype && (out_dtype == QUANTO_HIP_BF16 || out_dtype == QUANTO_HIP_F16) && K % lt::BK == 0 &&
          K >= 2 * lt::BK && M >= 1 && M * K < (1ll << 30) && N * K < (1ll << 31) && M < (1 << 30) && N < (1 << 30);
 }
@@ -618,7 +618,7 @@ int qbytes_mm_mfma_large(const void* x, const void* w, const void* s, const void
   const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
   const int cfg = forced >= 0 ? forced : (tiles128 > 512 ? lt::CFG_256_8W : lt::CFG_128_4W);
   if (cfg != lt::CFG_128_4W) split = 1;  // the workspace is sized for 128-tiles
-  if (cfg == lt::CFG_256_MFMA32) return qbytes_mm_mfma_large32(x, w, s, bias, y, M, N, K, b_dtype, out_dtype, stream);
+  if (cfg == lt::CFG_256_MFMA32 && b_dtype != QUANTO_HIP_F8_E4M3FNUZ) return qbytes_mm_mfma_large32(x, w, s, bias, y, M, N, K, b_dtype, out_dtype, stream);
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
   lt::Args a{x, reinterpret_cast<const uint8_t*>(w), s, bias, y, (int)M, (int)N, (int)K, 1, split, reinterpret_cast<int*>(workspace),
              split > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + large_counter_bytes(M, N)) : nullptr};
@@ -626,10 +626,12 @@ int qbytes_mm_mfma_large(const void* x, const void* w, const void* s, const void
   if (out_dtype == QUANTO_HIP_BF16) {
     if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_BF16, lt::W_I8);
     if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_BF16, lt::W_F8E4M3);
+    if (b_dtype == QUANTO_HIP_F8_E4M3FNUZ) QH_CASE(QUANTO_HIP_BF16, lt::W_F8E4M3FNUZ);
     QH_CASE(QUANTO_HIP_BF16, lt::W_F8E5M2);
   }
   if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_F16, lt::W_I8);
   if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_F16, lt::W_F8E4M3);
+  if (b_dtype == QUANTO_HIP_F8_E4M3FNUZ) QH_CASE(QUANTO_HIP_F16, lt::W_F8E4M3FNUZ);
   QH_CASE(QUANTO_HIP_F16, lt::W_F8E5M2);
 #undef QH_CASE
 }

@@ -484,6 +484,51 @@ def test_qbytes_naive_any_shape(dt, kind, M, N, K):
     assert_close_to_exact(_run_qbytes(p, "auto"), want, dt, "qbytes auto")
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K,kernel", [(1, 256, 1024, "gemv"), (2, 512, 4096, "gemv"), (8, 256, 1024, "skinny"), (40, 512, 2048, "skinny"),
+                                          (64, 1024, 4096, "skinny"), (300, 512, 1024, "mfma_large"), (1024, 1024, 4096, "mfma_large")])
+def test_qbytes_e4m3fnuz_on_the_fast_kernels(dt, M, N, K, kernel):
+    """float8_e4m3fnuz weights (the reference's tests/library/test_mm.py:32; an MI300-era checkpoint) no longer fall to the
+    one-thread-per-output kernel: the OCP converter at scale 1/2 + the three byte patterns the two formats disagree on (0x7F / 0xFF =
+    +-240, which the absmax element of EVERY row quantizes to; 0x80 = NaN).  AUTO picks the same kernels as for e4m3fn; exact-math gate."""
+    p = make_qbytes_problem(M, N, K, dt, "e4m3fnuz", seed=M + N + K)
+    assert ((p["data"] & 0x7F) == 0x7F).any()  # the +-240 patterns are in play
+    want = O.qbytes_mm_exact(p["x"], p["data"], p["scale"], "e4m3fnuz")
+    assert_close_to_exact(_run_qbytes(p, kernel), want, dt, f"e4m3fnuz {kernel} {M}x{K}x{N}")
+    assert_close_to_exact(_run_qbytes(p, "auto"), want, dt, f"e4m3fnuz auto {M}x{K}x{N}")
+    assert quanto_hip.lib.last_kernel() == kernel
+
+
+def test_qbytes_e4m3fnuz_every_byte_value():
+    """All 256 byte patterns through every kernel's converter: x = identity, so row n of the weight comes back as the output column n
+    (times the scale 1): bit-identical to the software decode, NaN (0x80) included."""
+    K = N = 256
+    data = np.tile(np.arange(256, dtype=np.uint8), (N, 1))          # every row holds every byte value
+    want = O.fp8_decode(data, "e4m3fnuz").astype(np.float32)         # [N, K]
+    scale = np.ones((N, 1), np.float32)
+    for dt in ("bf16", "fp16"):
+        for M, kernel in ((1, "gemv"), (16, "skinny"), (256, "mfma_large")):
+            x = np.zeros((M, K), np.float32)
+            rows = np.arange(M) * (K // M)                           # token m reads weight column rows[m]
+            x[np.arange(M), rows] = 1.0
+            p = dict(x=x, data=data, scale=scale, kind="e4m3fnuz", N=N, K=K, dt=dt)
+            y = _run_qbytes(p, kernel)                               # y[m, n] = W[n, rows[m]] (+ 0 * everything else: NaN rows pollute)
+            expect = want[:, rows].T.copy()
+            expect[:, :] = np.where(np.isnan(want).any(axis=1)[None, :], np.nan, expect)  # a NaN anywhere in row n makes column n NaN
+            np.testing.assert_array_equal(y, expect)
+    # without the NaN pattern: exact values of all the other 255 bytes
+    data2 = data.copy()
+    data2[data2 == 0x80] = 0
+    want2 = O.fp8_decode(data2, "e4m3fnuz").astype(np.float32)
+    for dt in ("bf16", "fp16"):
+        for M, kernel in ((2, "gemv"), (64, "skinny"), (256, "mfma_large")):
+            x = np.zeros((M, K), np.float32)
+            rows = (np.arange(M) * 7) % K
+            x[np.arange(M), rows] = 1.0
+            p = dict(x=x, data=data2, scale=scale, kind="e4m3fnuz", N=N, K=K, dt=dt)
+            np.testing.assert_array_equal(_run_qbytes(p, kernel), want2[:, rows].T)
+
+
 @pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
 def test_qbytes_int8_activations_bit_exact(dt):
     """library/qbytes_mm.py:36-50: int32 accumulate, fp32 rescale, one rounding -> reproducible bit for bit."""
