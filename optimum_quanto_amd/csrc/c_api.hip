@@ -125,16 +125,19 @@ static bool mmv_wins(int64_t M, const PackedGeom& g) {
 }
 
 // Large-tile int4 GEMM (qbits_mfma_large.hip: reference-rounded operands built in registers, no workspace, 2 x less traffic) against
-// dequantize + dense GEMM, r4, us (bf16, group size 128): 4096^3 138.9 / 116.8, (2048,4096,4096) 107.8 / 83.7, (8192,4096,4096) 253 / 217,
-// (4096,4096,14336) 478 / 418, (4096,14336,4096) 420 / 412, (1024,4096,14336) 118.5 / 121.6, 8192^3 961 / 1346: its conversion costs
-// ~2.9 VALU per MFMA, the dense path's dequantize pass is paid once - the fused kernel wins where the dense weight (N*K*2 bytes written and
-// re-read) no longer sits in the caches, and it is what AUTO takes at prefill sizes when the caller has no workspace at all.
+// dequantize + dense GEMM, r4, us (bf16, group size 128; profiles/r04_large4_vs_dequant_dense.jsonl): 4096^3 138.9 / 116.8,
+// (4096,8192,8192) 503 / 471, (8192,4096,14336) 846 / 774, (8192,14336,4096) 804 / 799, (2048,8192,8192) 246 / 252, but 8192^3 932 / 1339,
+// (16384,8192,8192) 1872 / 2702, (4096,8192,28672) 1643 / 2167, (4096,28672,8192) 1607 / 1914.  Its conversion costs ~2.9 VALU per MFMA where
+// the dense path pays one dequantize pass; it wins once the dense weight (N*K*2 bytes, written and re-read) together with the activations no
+// longer sits in the 256 MiB Infinity Cache: N*K >= 8192^2 with M >= 8192, or N*K >= 3 x 8192^2 - and it is what AUTO takes at prefill sizes
+// when the caller has no workspace at all.
 static bool large4_wins(int64_t M, const PackedGeom& g, bool have_workspace) {
   const int mode = env_int("QUANTO_HIP_LARGE4", 1);  // experiments: 0 never, 2 whenever supported
   if (mode == 0) return false;
   if (mode == 2) return M > 192;
   if (!have_workspace) return M > 1024;  // otherwise: passes of the streaming kernel / the one-thread-per-output kernel
-  return M >= 4096 && g.N >= 8192 && g.K >= 8192;
+  const int64_t nk = g.N * g.K;
+  return nk >= (64ll << 20) && (M >= 8192 || nk >= (192ll << 20)) && M >= 2048;
 }
 
 static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {

@@ -86,8 +86,14 @@ class QuantizedTransformersModel:
         with open(qmap_path, "r", encoding="utf-8") as f:
             qmap = json.load(f)
         config = AutoConfig.from_pretrained(path)
+        # the skeleton in the dtype the checkpoint was saved in (config.dtype): quantized scales are then taken as they are (requantize
+        # only re-rounds them when the skeleton's dtype differs) and the reloaded model computes in the dtype it was quantized in
+        dtype = getattr(config, "dtype", None) or getattr(config, "torch_dtype", None)
         with init_empty_weights():
-            model = cls.auto_class().from_config(config)
+            try:
+                model = cls.auto_class().from_config(config, dtype=dtype) if isinstance(dtype, torch.dtype) else cls.auto_class().from_config(config)
+            except TypeError:  # older transformers: torch_dtype=
+                model = cls.auto_class().from_config(config, torch_dtype=dtype)
         # shards are read straight onto `device` (checkpoint.py): no CPU staging copy of the quantized weights
         requantize(model, state_dict=load_state_dict_to_device(path, device), quantization_map=qmap, device=device)
         if getattr(model.config, "tie_word_embeddings", True):

@@ -720,10 +720,10 @@ def test_large_tile_int4_gemm_operands_are_the_dequantized_weight():
 
 
 def test_auto_takes_the_large_tile_int4_gemm_where_it_wins():
-    """(4096, 8192, 8192): AUTO = the large-tile int4 GEMM (r4: 961 vs 1346 us at 8192^3).  It multiplies the same rounded weight as
+    """8192^3: AUTO = the large-tile int4 GEMM (r4: 932 vs 1339 us).  It multiplies the same rounded weight as
     dequantize + dense GEMM, so the two outputs may only differ by the fp32 accumulation order: compared element by element in bf16 ulps
     (a float64 product of this size is left to the smaller shapes above); 24 sampled rows against the float64 oracle."""
-    M, N, K = 4096, 8192, 8192
+    M, N, K = 8192, 8192, 8192
     g = torch.Generator(device=DEV).manual_seed(5)
     x = torch.randn((M, K), generator=g, device=DEV).to(torch.bfloat16)
     p = make_qbits_problem(8, N, K, "bf16", seed=11)
@@ -738,7 +738,7 @@ def test_auto_takes_the_large_tile_int4_gemm_where_it_wins():
     rows = np.random.default_rng(0).choice(M, 24, replace=False)
     w = O.dequantize_qbits_ref(p["packed"], 4, p["scale"], p["shift"], 0, 128, (N, K), "bf16").astype(np.float64)
     want = np.matmul(to_numpy(x[torch.from_numpy(rows).to(DEV)]).astype(np.float64), w.T)
-    assert_close_to_exact(to_numpy(y)[rows], want, "bf16", "large int4 (4096,8192,8192), sampled rows")
+    assert_close_to_exact(to_numpy(y)[rows], want, "bf16", "large int4 8192^3, sampled rows")
 
 
 def test_int4_prefill_4096_cubed():
