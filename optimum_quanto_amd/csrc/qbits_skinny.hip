@@ -99,6 +99,7 @@ struct Args {
   float* partials;  // [blocks][TF][WAVES*64 lanes] float4 (fragment-major: every store / load instruction covers whole lines)
   // groups per 128-k tile: 1 (group size 128), 2 (64), 4 (32); per_channel: ONE scale / shift per feature (G = 1), the tables repeat it
   int gpt, per_channel;
+  int planes;       // values per packed byte: 2 (int4), 4 (int2)
   int nt;           // non-temporal weight DMA (single-pass calls: M <= 64)
   // QUANTO_HIP_SKINNY_ABLATE (timing experiments, WRONG results): 1 no split-K reduction, 2 no MFMA/LDS-read work,
   // 4 no activation DMA, 8 no weight DMA, 16 no scale/shift table
@@ -131,14 +132,19 @@ struct Segs {
 // per wave.
 // GPT: quantization groups per 128-k tile - 1 (group size 128 and per-channel scales), 2 (64), 4 (32); the small group sizes are
 // instantiated for 64-feature blocks and the 4-stage ring only.
-template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI = false, int SETS = 1, int GPT = 1>
+// PLANES: values per packed byte - 2 (int4) or 4 (int2, r4).  A wave's 16 features are then 4 packed rows x 4 planes (lane i of 16: row
+// i & 3, plane i >> 2, two bits at 2 * plane) instead of 8 rows x 2 planes; its weight piece of a tile is 512 bytes (the lower 32 lanes of the
+// DMA instruction).  Instantiated for 64-feature blocks, the 4-stage ring and group size 128.
+template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI = false, int SETS = 1, int GPT = 1, int PLANES = 2>
 __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a, const Segs segs) {
   static_assert(SETS == 1 || WAVES == 4, "two wave sets: 64-feature blocks only");
+  static_assert(PLANES == 2 || (PLANES == 4 && WAVES == 4 && !MULTI && GPT == 1), "int2: 64-feature blocks, one Linear, group size 128");
+  constexpr int RPW = 16 / PLANES;    // packed rows per wave
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
-  constexpr int ROWS = 8 * WAVES;     // packed rows per block (2*ROWS output features)
-  constexpr int W_BYTES = ROWS * BK;  // 1 KiB per wave
+  constexpr int ROWS = RPW * WAVES;   // packed rows per block (PLANES * ROWS output features)
+  constexpr int W_BYTES = ROWS * BK;  // 1 KiB per wave (int2: 512 B)
   constexpr int XP = TF * 4 / WAVES;  // 1 KiB activation DMA pieces per wave and tile
   constexpr int X_BYTES = TF * 16 * BK * 2;
   constexpr int STAGE_BYTES = W_BYTES + X_BYTES;
@@ -170,7 +176,7 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
     a.N = segs.N[seg];
   }
   const int M = a.M, N = a.N, K = a.K;
-  const int P = N >> 1;
+  const int P = N / PLANES;
   const int p0 = fb * ROWS;
   const int nk = K / BK / S;   // tiles (= groups) of this block's K-range
   const int kt0 = sp * nk;     // first global tile / group index
@@ -180,8 +186,8 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   // weights: this wave's 8 rows x 128 B = 1 KiB per tile; lane -> row lane>>3, position lane&7 holds chunk pos ^ (row & 7)
   const uint8_t* wsrc;
   {
-    const int r = lane >> 3, c = (lane & 7) ^ (r & 7);
-    wsrc = a.w + (size_t)(p0 + wave * 8 + r) * K + c * 16 + (size_t)kt0 * BK;
+    const int r = (lane >> 3) & (RPW - 1), c = (lane & 7) ^ (r & 7);  // int2: lanes 32..63 repeat rows 0..3 and stay idle (w_lane)
+    wsrc = a.w + (size_t)(p0 + wave * RPW + r) * K + c * 16 + (size_t)kt0 * BK;
   }
   // activations: XP KiB-instructions per wave; instruction u covers tile rows 4*(wave*XP+u) .. +3
   const uint8_t* xsrc[XP];
@@ -193,14 +199,17 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
     xsrc[u] = reinterpret_cast<const uint8_t*>(reinterpret_cast<const T*>(a.x) + (size_t)m * K + c * 8 + (size_t)kt0 * BK);
   }
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+  const bool w_lane = PLANES == 2 || lane < 32;  // lanes that carry a weight DMA piece (RPW rows x 128 B = RPW * 8 lanes)
   auto issue = [&](int kt, int stage) {
     const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
     // ablations keep the instruction count per tile (vmcnt arithmetic) and re-read tile 0 instead: L2 hits
     const int ktw = (a.ablate & 8) ? 0 : kt, ktx = (a.ablate & 4) ? 0 : kt;
-    if (a.nt)
-      glds16_nt(wsrc + (size_t)ktw * BK, st + wave * 1024);
-    else
-      glds16(wsrc + (size_t)ktw * BK, st + wave * 1024);
+    if (w_lane) {
+      if (a.nt)
+        glds16_nt(wsrc + (size_t)ktw * BK, st + wave * (RPW * BK));
+      else
+        glds16(wsrc + (size_t)ktw * BK, st + wave * (RPW * BK));
+    }
 #pragma unroll
     for (int u = 0; u < XP; ++u) glds16(xsrc[u] + (size_t)ktx * (BK * 2), st + W_BYTES + (wave * XP + u) * 1024);
   };
@@ -222,12 +231,12 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   auto issue_pair = [&](int kt, int sa, int sb) {  // kt even; the odd tile exists when kt + 1 < nk
     const uint32_t sta = __builtin_amdgcn_readfirstlane(lds_base + sa * STAGE_BYTES), stb = __builtin_amdgcn_readfirstlane(lds_base + sb * STAGE_BYTES);
     const bool has_odd = kt + 1 < nk;
-    if (set == 0 || has_odd) {
+    if ((set == 0 || has_odd) && w_lane) {
       const uint32_t st = set == 0 ? sta : stb;
       if (a.nt)
-        glds16_nt(wsrc + (size_t)(kt + set) * BK, st + wave * 1024);
+        glds16_nt(wsrc + (size_t)(kt + set) * BK, st + wave * (RPW * BK));
       else
-        glds16(wsrc + (size_t)(kt + set) * BK, st + wave * 1024);
+        glds16(wsrc + (size_t)(kt + set) * BK, st + wave * (RPW * BK));
     }
 #pragma unroll
     for (int j = 0; j < (SETS == 2 ? TF : 0); ++j) {
@@ -248,7 +257,7 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   // ---- park scale / (shift + OFFSET*scale) of the block's 64 features and the XS rows in LDS ---------------------
   // sz[g][0][f] = scale, sz[g][1][f] = shift (zero-points converted to T: small integers are exact),
   // f = plane*ROWS + local packed row; kept in the 16-bit storage type so that K = 14336 (112 groups) fits
-  constexpr int NF = 2 * ROWS;  // features per block
+  constexpr int NF = PLANES * ROWS;  // features per block
   // Row pitch of the table: NF + 4 entries.  With a pitch of NF (a multiple of 256 bytes for 64 features) the fill below - lanes
   // run over the groups of one feature - put all 64 lanes of a ds_write_b16 on ONE bank (SQ_LDS_BANK_CONFLICT = 3970 cycles per
   // block on the gate+up launch, 0.9 us of the (32,4096,4096) call); 8 bytes of padding spread them and keep the 8-byte reads aligned
@@ -265,7 +274,7 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
 
   // ---- fragment read offsets ----------------------------------------------------------------------------------------
   const int fi = lane & 15, fg = lane >> 4;
-  const int wrow = wave * 8 + (fi & 7);
+  const int wrow = wave * RPW + (fi & (RPW - 1));
   int woff[2];  // 16-byte chunks fg and 4+fg of the lane's row
 #pragma unroll
   for (int h = 0; h < 2; ++h) woff[h] = wrow * 128 + (((4 * h + fg) ^ (wrow & 7)) << 4);
@@ -274,7 +283,7 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   int woff4[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) woff4[t] = wrow * 128 + (((2 * t + (fg >> 1)) ^ (wrow & 7)) << 4) + 8 * (fg & 1);
-  const uint32_t nib_shift = (fi >> 3) * 4;  // high-nibble plane for lanes 8..15 of each 16
+  const uint32_t nib_shift = PLANES == 2 ? (fi >> 3) * 4 : (fi >> 2) * 2;  // the lane's plane: nibble 0 / 1, or bit pair 0..3
   int xoff[TF][4];
 #pragma unroll
   for (int tf = 0; tf < TF; ++tf) {
@@ -283,13 +292,13 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
     for (int t = 0; t < 4; ++t)
       xoff[tf][t] = W_BYTES + row * 256 + (((GPT == 4 ? 4 * t + fg : 8 * (t >> 1) + 2 * fg + (t & 1)) ^ (row & 15)) << 4);
   }
-  // this lane's 4 consecutive features inside the block: plane (fg>>1), local packed rows wave*8 + 4*(fg&1) + r
-  const int floc = (fg >> 1) * ROWS + wave * 8 + 4 * (fg & 1);
+  // this lane's 4 consecutive features inside the block: int4 plane (fg>>1), local packed rows wave*8 + 4*(fg&1) + r; int2 plane fg, rows wave*4 + r
+  const int floc = PLANES == 2 ? (fg >> 1) * ROWS + wave * 8 + 4 * (fg & 1) : fg * ROWS + wave * 4;
 
   f32x4 acc[TF];
 #pragma unroll
   for (int tf = 0; tf < TF; ++tf) acc[tf] = f32x4{0.f, 0.f, 0.f, 0.f};
-  uint32_t kmask = 0x0F0F0F0Fu, kmagic = Mma<DT>::MAGIC;
+  uint32_t kmask = PLANES == 2 ? 0x0F0F0F0Fu : 0x03030303u, kmagic = Mma<DT>::MAGIC;
   asm volatile("" : "+s"(kmask));
   asm volatile("" : "+v"(kmagic));
 
@@ -469,7 +478,7 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------------
   T* yg = reinterpret_cast<T*>(a.y);
-  const int n0 = p0 + wave * 8 + 4 * (fg & 1) + (fg >> 1) * P;  // 4 consecutive output features n0..n0+3
+  const int n0 = PLANES == 2 ? p0 + wave * 8 + 4 * (fg & 1) + (fg >> 1) * P : p0 + wave * 4 + fg * P;  // 4 consecutive output features n0..n0+3
   float bv[4] = {0.f, 0.f, 0.f, 0.f};
   const bool has_bias = a.bias != nullptr;
   if (has_bias) {
@@ -494,14 +503,16 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   if (a.tl && tid == 0) a.tl[blockIdx.x * 32 + 31] = wall_clock64();
 }
 
-constexpr int lds_bytes(int tf, int stages, int G, int waves) { return stages * (waves * 8 * BK + tf * 16 * BK * 2) + G * 2 * (16 * waves + 4) * 2; }
+constexpr int lds_bytes(int tf, int stages, int G, int waves, int planes = 2) {
+  return stages * (waves * (16 / planes) * BK + tf * 16 * BK * 2) + G * 2 * (16 * waves + 4) * 2;
+}
 
 // `segs` (with the total number of feature blocks) selects the multi-Linear launch; 64-feature blocks only, like the two-set form
-template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI, int SETS, int GPT = 1>
+template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI, int SETS, int GPT = 1, int PLANES = 2>
 static int launch_k(const Args& a, hipStream_t stream, const Segs& segs, int grid, int lds) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS, GPT>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS, GPT, PLANES>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS, GPT>), dim3(grid), dim3(WAVES * SETS * 64), lds, stream, a, segs);
+  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS, GPT, PLANES>), dim3(grid), dim3(WAVES * SETS * 64), lds, stream, a, segs);
   return launch_status();
 }
 
@@ -571,8 +582,20 @@ static int launch_small_groups_tf(const Args& a, hipStream_t stream) {
   return launch_small_groups<DT, INT_SHIFT, 4, GPT>(a, stream);
 }
 
+// qint2 (four planes per byte): 64-feature blocks, 4-stage ring, two wave sets from two token fragments on
+template <int DT, bool INT_SHIFT, int TF>
+static int launch_int2(const Args& a, hipStream_t stream) {
+  const int lds = lds_bytes(TF, 4, a.K / BK / a.S, 4, 4);
+  return launch_k<DT, TF, 4, INT_SHIFT, 4, false, (TF >= 2 ? 2 : 1), 1, 4>(a, stream, Segs{}, a.N / 64 * a.S, lds);
+}
+
 template <int DT, bool INT_SHIFT>
 static int launch_tf(const Args& a, hipStream_t stream, const Segs* segs = nullptr, int total_fb = 0) {
+  if (a.planes == 4) {
+    if (a.M <= 16) return launch_int2<DT, INT_SHIFT, 1>(a, stream);
+    if (a.M <= 32) return launch_int2<DT, INT_SHIFT, 2>(a, stream);
+    return launch_int2<DT, INT_SHIFT, 4>(a, stream);
+  }
   if (a.gpt == 2) return launch_small_groups_tf<DT, INT_SHIFT, 2>(a, stream);
   if (a.gpt == 4) return launch_small_groups_tf<DT, INT_SHIFT, 4>(a, stream);
   if (a.M <= 16) return launch_waves<DT, INT_SHIFT, 1>(a, stream, segs, total_fb);
@@ -590,7 +613,7 @@ static int skinny_split(const PackedGeom& g, int64_t M) {
   const int forced = env_int("QUANTO_HIP_SKINNY_SPLIT", 0);  // experiments
   const int tf = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
   // group sizes 64 / 32 always launch 64-feature blocks (launch_small_groups), whatever the wave knob says
-  const int blocks = (g.C == 64 || g.C == 32) ? (int)(g.N / 64) : (int)(g.N / (16 * skinny::pick_waves((int)g.N, tf)));
+  const int blocks = (g.C == 64 || g.C == 32 || g.bits == 2) ? (int)(g.N / 64) : (int)(g.N / (16 * skinny::pick_waves((int)g.N, tf)));
   int s = 1;
   const int tiles = (int)(g.K / 128);  // 128-k tiles (= groups of 128)
   while (s < 8 && blocks * s * 2 <= 512 && tiles % (s * 2) == 0 && tiles / (s * 2) >= 8) s *= 2;
@@ -611,6 +634,10 @@ bool qbits_skinny_supported(int64_t M, const PackedGeom& g, int dtype) {
   const bool per_channel = g.C == g.K && g.C != 128;
   const bool grouped = g.C == 128 || ((g.C == 64 || g.C == 32) && g.N % 64 == 0);
   const int groups = per_channel ? (int)(g.K / 128) : (int)g.G;
+  if (g.bits == 2)  // qint2 (r4): group size 128, 64-feature blocks (16 packed rows x 4 planes)
+    return g.C == 128 && g.N % 64 == 0 && g.K % 128 == 0 && M >= 1 && M <= QUANTO_HIP_SKINNY_MAX_M &&
+           (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30) && g.K < (1 << 30) &&
+           skinny::lds_bytes(tf, 4, (int)g.G, 4, 4) <= 160 * 1024;
   return g.bits == 4 && (grouped || per_channel) && (g.N % 16 == 0) && (g.K % 128 == 0) && M >= 1 && M <= QUANTO_HIP_SKINNY_MAX_M &&
          (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30) && g.K < (1 << 30) &&
          skinny::lds_bytes(tf, 4, groups, skinny::pick_waves((int)g.N)) <= 160 * 1024;
@@ -639,7 +666,7 @@ int qbits_mm_skinny(const void* x, const uint8_t* packed, const void* scale, con
                    reinterpret_cast<uint8_t*>(y) + (size_t)m0 * g.N * esize, (int)rows, (int)g.N, (int)g.K, (int)g.G, S,
                    reinterpret_cast<int*>(workspace),
                    S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr,
-                   per_channel ? 1 : (int)(128 / g.C), per_channel ? 1 : 0,
+                   per_channel ? 1 : (int)(128 / g.C), per_channel ? 1 : 0, g.bits == 2 ? 4 : 2,
                    // later passes of a multi-pass call re-read the weights from the Infinity Cache: keep them cacheable there
                    env_int("QUANTO_HIP_SKINNY_NT", M <= 64 ? 1 : 0), env_int("QUANTO_HIP_SKINNY_ABLATE", 0),
                    reinterpret_cast<unsigned long long*>(env_ptr("QUANTO_HIP_SKINNY_TIMELINE"))};
@@ -699,7 +726,7 @@ int qbits_mm_skinny_multi(const void* x, int nseg, const uint8_t* const* packed,
   if (S > 1 && (!workspace || workspace_bytes < qbits_skinny_workspace(M, g) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
   skinny::Args a{x, packed[0], scale[0], shift[0], bias ? bias[0] : nullptr, y[0], (int)M, (int)N[0], (int)K, (int)g.G, S,
                  reinterpret_cast<int*>(workspace),
-                 S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr, 1, 0,
+                 S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr, 1, 0, 2,
                  env_int("QUANTO_HIP_SKINNY_NT", 1), 0, nullptr};
   if (dtype == QUANTO_HIP_BF16)
     return int_shift ? skinny::launch_tf<QUANTO_HIP_BF16, true>(a, stream, &segs, fb) : skinny::launch_tf<QUANTO_HIP_BF16, false>(a, stream, &segs, fb);

@@ -335,10 +335,30 @@ def test_qbits_gemv_int2(dt, zp, M, N, K, gs):
     """qint2 weights (four planes per byte) on the same decode kernel: exact-math gate."""
     p = make_qbits_problem(M, N, K, dt, bits=2, group_size=gs, zeropoint=zp, seed=N + K + 2)
     y = _run_qbits(p, "auto")
-    assert quanto_hip.lib.last_kernel() == "gemv"
+    # beyond 4 rows the streaming MFMA kernel takes group size 128 on 64-feature blocks (r4, test_qbits_skinny_int2); the GEMV keeps the rest
+    assert quanto_hip.lib.last_kernel() == ("skinny" if M > 4 and gs == 128 and N % 64 == 0 else "gemv")
+    if quanto_hip.lib.last_kernel() != "gemv":
+        y = _run_qbits(p, "gemv")
     assert_close_to_exact(y, _exact_qbits(p), dt, f"gemv int2 group_size={gs} {M}x{K}x{N}")
     bias = O.round_to(np.random.default_rng(6).standard_normal(N).astype(np.float32), dt)
     np.testing.assert_array_equal(_run_qbits(p, "gemv", bias), O.round_to((y + bias).astype(np.float32), dt))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("zp", [False, True])
+@pytest.mark.parametrize("M,N,K", [(5, 256, 1024), (16, 64, 512), (24, 512, 4096), (32, 4096, 4096), (40, 128, 2048), (64, 1024, 1024), (100, 256, 1152),
+                                   (192, 512, 14336)])
+def test_qbits_skinny_int2(dt, zp, M, N, K):
+    """qint2 weights (four planes per byte) on the streaming MFMA kernel (r4: batched decode with 2-bit weights no longer goes through
+    dequantize + dense GEMM beyond 24 rows): a wave's 16 features are 4 packed rows x 4 planes; one / two / four token fragments, split and
+    unsplit grids, passes of 64 rows, zero-points, bias; exact-math gate; AUTO picks it."""
+    p = make_qbits_problem(M, N, K, dt, bits=2, group_size=128, zeropoint=zp, seed=M + N + K)
+    want = _exact_qbits(p)
+    assert_close_to_exact(_run_qbits(p, "skinny"), want, dt, f"skinny int2 {M}x{K}x{N}")
+    assert_close_to_exact(_run_qbits(p, "auto"), want, dt, f"auto int2 {M}x{K}x{N}")
+    assert quanto_hip.lib.last_kernel() == "skinny"
+    bias = O.round_to(np.random.default_rng(M).standard_normal(N).astype(np.float32), dt)
+    assert_close_with_bias(_run_qbits(p, "skinny", bias), want, bias, dt, "skinny int2 + bias")
 
 
 def test_qbits_auto_picks_fast_kernels():
