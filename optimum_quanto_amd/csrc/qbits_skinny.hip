@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   static_assert(SETS == 1 || WAVES == 4, "two wave sets: 64-feature blocks only");
   static_assert(PLANES == 2 || (PLANES == 4 && WAVES == 4 && !MULTI && GPT == 1), "int2: 64-feature blocks, one Linear, group size 128");
   constexpr int RPW = 16 / PLANES;    // packed rows per wave
+  constexpr int QSHIFT = DT == QUANTO_HIP_BF16 ? 5 : 6;  // int2 only: position of the two bits inside the mantissa byte
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
@@ -186,7 +187,8 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   // weights: this wave's 8 rows x 128 B = 1 KiB per tile; lane -> row lane>>3, position lane&7 holds chunk pos ^ (row & 7)
   const uint8_t* wsrc;
   {
-    const int r = (lane >> 3) & (RPW - 1), c = (lane & 7) ^ (r & 7);  // int2: lanes 32..63 repeat rows 0..3 and stay idle (w_lane)
+    // the swizzle is a function of the row INSIDE THE BLOCK (what the fragment reads undo); int2: lanes 32..63 repeat rows 0..3 and stay idle (w_lane)
+    const int r = (lane >> 3) & (RPW - 1), c = (lane & 7) ^ ((wave * RPW + r) & 7);
     wsrc = a.w + (size_t)(p0 + wave * RPW + r) * K + c * 16 + (size_t)kt0 * BK;
   }
   // activations: XP KiB-instructions per wave; instruction u covers tile rows 4*(wave*XP+u) .. +3
@@ -334,7 +336,14 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
         const uint32_t d0 = (t & 1) ? wr[t >> 1].z : wr[t >> 1].x, d1 = (t & 1) ? wr[t >> 1].w : wr[t >> 1].y;
         // 8 VALU per 8 weights (r3, as qbits_mfma_fused.hip): the lane's nibble plane shifted down and masked once per raw dword, then ONE
         // v_perm per pair of weights interleaves their bytes with the exponent byte of 128 (bf16 0x43) / 1024 (fp16 0x64)
-        const uint32_t s0 = (d0 >> nib_shift) & kmask, s1 = (d1 >> nib_shift) & kmask;
+        uint32_t s0 = (d0 >> nib_shift) & kmask, s1 = (d1 >> nib_shift) & kmask;
+        if constexpr (PLANES == 4) {
+          // int2: the two useful bits go to the TOP of the mantissa byte - operand = OFFSET + QS q with QS = 32 (bf16: 128 + 32 q < 256) or
+          // 64 (fp16: 1024 + 64 q < 2048).  With OFFSET + q they ride on a constant 85 / 680 times their own size and the fp32 cancellation
+          // error of the fold reaches an fp16 ulp; the fold divides by QS (exact)
+          s0 <<= QSHIFT;
+          s1 <<= QSHIFT;
+        }
         uint32_t op[4];
         op[0] = __builtin_amdgcn_perm(kmagic, s0, 0x07010500u);  // bytes 0,1 -> (q0, exp, q1, exp)
         op[1] = __builtin_amdgcn_perm(kmagic, s0, 0x07030502u);  // bytes 2,3
@@ -356,9 +365,10 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
       float s4[4], z4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s4[r] = E::to_f32(s4t[r]);
+        constexpr float QS = PLANES == 4 ? (float)(1 << QSHIFT) : 1.f;  // operand = OFFSET + QS * q
+        s4[r] = E::to_f32(s4t[r]) * (1.f / QS);       // exact: a power of two
         const float z = E::to_f32(z4t[r]);
-        z4[r] = INT_SHIFT ? s4[r] * (z + Mma<DT>::OFFSET) : z + Mma<DT>::OFFSET * s4[r];
+        z4[r] = INT_SHIFT ? s4[r] * (QS * z + Mma<DT>::OFFSET) : z + Mma<DT>::OFFSET * s4[r];
       }
 #pragma unroll
       for (int tf = 0; tf < TF; ++tf) {
