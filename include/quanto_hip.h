@@ -129,10 +129,13 @@ int quanto_hip_dequantize_qbits(const uint8_t* packed, const void* scale, const 
  *   The reference has no such op; its CUDA analogs are gemm_f16i4_awq / gemm_f16i4_marlin
  *   (library/extensions/cuda/__init__.py:82-121,170-202).
  * x: dtype[M, K]; packed/scale/shift as in quanto_hip_dequantize_qbits; bias: dtype[N] or NULL;
- * y: dtype[M, N].  dtype in {F32, F16, BF16}.  Accumulation is fp32.  Every kernel except DEQUANT_MFMA multiplies the stored
- * integers exactly and applies scale / shift to the fp32 accumulator (the dequantized weight exists nowhere); DEQUANT_MFMA - what
- * AUTO takes for large M, where one dequantize pass is amortised over thousands of rows - writes the reference's dequantized weight
- * (bit-identical to QBitsDequantizer) into the caller's workspace and multiplies that, exactly as the reference does per call.
+ * y: dtype[M, N].  dtype in {F32, F16, BF16}.  Accumulation is fp32.  Every kernel except DEQUANT_MFMA and MFMA_LARGE4 multiplies
+ * the stored integers exactly and applies scale / shift to the fp32 accumulator (the dequantized weight exists nowhere).  The two
+ * prefill kernels multiply the reference's DEQUANTIZED weight (its two roundings to dtype, bit-identical to QBitsDequantizer), as the
+ * reference does per call: DEQUANT_MFMA - AUTO's choice for large M while weight and activations sit in the caches - writes it into the
+ * caller's workspace (one pass, amortised over thousands of rows) and runs a dense GEMM; MFMA_LARGE4 builds the same values as MFMA
+ * operands in registers (no workspace; AUTO beyond the Infinity Cache: N*K >= 8192^2 with M >= 8192, or N*K >= 3 * 8192^2, and whenever
+ * workspace == NULL at prefill sizes).
  */
 int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale, const void* shift,
                         const void* bias, void* y, int64_t M, int64_t N, int64_t K, int bits, int group_size,
