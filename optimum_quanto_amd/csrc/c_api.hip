@@ -165,8 +165,11 @@ static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool hav
 // ... or M fills most of a 128-row tile: with the weights-direct loop a lone 128-tile workgroup streams a K-tile in 0.42 us,
 // which beats the streaming kernel's passes of 64 rows (bf16 x int8, us, streaming -> tile: (128,4096,4096) 32 -> 27,
 // (256,4096,4096) 64 -> 27, (128,14336,4096) 45 -> 28, (128,1024,4096) 29 -> 27; but (96,4096,4096) 26 -> 32)
+// r4 (profiles/r04_auto_vs_best.jsonl, off the fitted grid): at M = 96 the tile kernel already wins from 40 tiles on while K is short enough
+// for its K split to cover the chip - (96,5120,5120) 30.3 vs 34.1 us streaming, but (96,11008,5120) 69.4 vs 56.4 and (96,2048,2048) 21.0 vs 18.1
 static bool prefer_large_tile(int64_t M, int64_t N, int64_t K) {
-  return ((M + 127) / 128) * ((N + 127) / 128) >= 64 || (M > 96 && K >= 512);
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  return tiles >= 64 || (tiles >= 40 && K <= 8192 && M >= 96) || (M > 96 && K >= 512);
 }
 
 }  // namespace qh
