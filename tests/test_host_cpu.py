@@ -83,7 +83,15 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 4, 0, 2) for m in (8, 128)] == [SKINNY, SKINNY]       # per-channel
     assert lib.quanto_hip_qbits_mm_pick(40, 200, 512, 4, 64, 2) == MFMA128                                      # N not in 64-feature blocks
     assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 1152, 4, 96, 2) for m in (8, 24, 25)] == [GEMV, GEMV, DEQUANT]  # group size 96
-    assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 2, 128, 2) for m in (8, 25)] == [GEMV, DEQUANT]           # qint2
+    assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 2, 128, 2) for m in (4, 8, 25, 192, 193)] == [GEMV, SKINNY, SKINNY, SKINNY, DEQUANT]  # qint2 (r4)
+    assert lib.quanto_hip_qbits_mm_pick(8, 4096, 4096, 2, 64, 2) == GEMV                                          # qint2, group size 64: GEMV passes
+    # r4: the large-tile int4 GEMM where the dense weight leaves the Infinity Cache; dequantize + dense below
+    LARGE4 = 10
+    assert [lib.quanto_hip_qbits_mm_pick(m, 8192, 8192, 4, 128, 2) for m in (2048, 4096, 8192)] == [DEQUANT, DEQUANT, LARGE4]
+    assert lib.quanto_hip_qbits_mm_pick(4096, 28672, 8192, 4, 128, 2) == LARGE4 and lib.quanto_hip_qbits_mm_pick(8192, 14336, 4096, 4, 128, 2) == DEQUANT
+    assert lib.quanto_hip_qbits_mm_workspace_size(8192, 8192, 8192, 4, 128, 2, 0) == 0                               # ... and it needs no workspace
+    # int8, M = 96 off the fitted grid (r4): the tile kernel from 40 tiles on while K is short
+    assert [lib.quanto_hip_qbytes_mm_pick(96, n, k, 2, 3, 2) for n, k in ((5120, 5120), (2048, 2048), (5120, 11008), (8192, 8192))] == [4, 5, 5, 4]
     assert lib.quanto_hip_qbits_mm_pick(64, 192, 14336, 4, 32, 2) == DEQUANT  # 448 groups' tables do not fit next to the ring
     assert lib.quanto_hip_qbits_mm_workspace_size(4, 4096, 4096, 4, 128, 2, 0) == 0
     assert lib.quanto_hip_qbits_mm_workspace_size(1, 4096, 4096, 4, 128, 2, 0) == 0  # GEMV needs none
