@@ -62,6 +62,14 @@ class QuantizedTransformersModel:
         if getattr(model.config, "tie_word_embeddings", True):
             if isinstance(model.get_input_embeddings(), QModuleMixin) or isinstance(model.get_output_embeddings(), QModuleMixin):
                 model.config.tie_word_embeddings = False  # a quantized embedding / head is no longer tied
+        # record the dtype the model computes in (transformers' own save_pretrained does; config.save_pretrained alone does not): from_pretrained
+        # builds its skeleton in it, so the quantized scales come back as saved
+        first = next((p for p in model.parameters() if type(p.data) is torch.Tensor and p.is_floating_point()), None)
+        if first is not None and getattr(model.config, "dtype", None) is None:
+            try:
+                model.config.dtype = first.dtype
+            except Exception:  # a config class without that attribute: the loader falls back to from_config's default
+                pass
         model.config.save_pretrained(save_directory)
         state = {k: v.contiguous().cpu() for k, v in model.state_dict().items()}
         if getattr(model.config, "tie_word_embeddings", False) and model.get_output_embeddings() is not None:
