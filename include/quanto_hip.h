@@ -272,6 +272,19 @@ int quanto_hip_quantize_affine_packed(const void* base, const void* scale, const
  */
 int quanto_hip_pack(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int64_t cols, int bits, void* stream);
 
+/*
+ * F.conv2d with an int8 / fp8 weight - what QConv2d.forward (nn/qconv2d.py:54-55) reaches through WeightQBytesTensor's dispatch, where the
+ * reference dequantizes the whole weight per call (qfallback) and runs a float convolution.  Dense convolution (groups = 1) as an IMPLICIT
+ * GEMM: y[b, n, oh, ow] = scale[n] * sum_{c,i,j} x[b, c, oh*sh - ph + i*dh, ow*sw - pw + j*dw] * w[n, c, i, j] (+ bias[n]); the im2col operand
+ * is gathered inside the kernel's staging loads, nothing is materialised.
+ *   x: dtype[B, cin, H, W] (NCHW, contiguous); w: 8-bit [OC, cin, KH, KW] (I8 / F8_E4M3FN / F8_E5M2); scales: dtype[OC]; bias: dtype[OC] or NULL;
+ *   y: dtype[B, OC, OH, OW] with OH = (H + 2 ph - dh (KH - 1) - 1) / sh + 1 (OW alike), passed by the caller.  dtype in {F16, BF16}.
+ *   Requires cin * KH * KW to be a multiple of 64; QUANTO_HIP_ENOTSUP otherwise (the caller then lowers the convolution to im2col + qbytes_mm).
+ */
+int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, const void* bias, void* y, int64_t B, int64_t cin, int64_t H,
+                             int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,
+                             int pad_w, int dil_h, int dil_w, int a_dtype, int b_dtype, int out_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,10 @@
 //     exact-math product of the reference's integers and scales up to fp32 accumulation order.
 // Weight tiles are read from HBM exactly once per (m-tile, n-tile); the dense dequantized weight the reference
 // materialises on every call (library/qbytes_mm.py:25-33, tensor/qbits.py:27-49) never exists.
+//
+// CONV (r4): the same kernel as an IMPLICIT GEMM for a dense convolution with an 8-bit weight [OC, C, kh, kw] (nn/qconv2d.py:54-55): the
+// activation operand A[m][k], m = (image, oh, ow), k = (c, i, j) - the order the weight is flattened in - is gathered from the NCHW input
+// inside the staging loads (zero where the window hangs over the padding), no im2col tensor is ever written; the epilogue stores NCHW.
 #include "qh_common.h"
 
 namespace qh {
@@ -106,12 +110,15 @@ struct MmaArgs {
   const void* shift;    // W4 only: [N*G] (activation dtype, or uint8/int8 zero-point)
   const float* xs;      // W4 only: workspace [G][Mpad] group sums of x
   const void* bias;     // [N] or null
-  void* y;              // [M, N]
+  void* y;              // [M, N]; CONV: [B, N, OH, OW]
   int M, N, K, C, G, Mpad;
+  // CONV only: x is [B, cin, H, W]; M = B * OH * OW, K = cin * KH * KW
+  int cin, H, W, KH, KW, OH, OW, sh, sw, ph, pw, dh, dw;
 };
 
-template <int DT, int FMT, bool INT_SHIFT>
+template <int DT, int FMT, bool INT_SHIFT, bool CONV = false>
 __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
+  static_assert(!CONV || FMT != W_I4, "implicit-GEMM convolution: 8-bit weights");
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
@@ -131,14 +138,50 @@ __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
   // W8: 2 chunks/thread of 16 bytes: c = tid + 256*j -> row c>>2, part c&3 (16 weights -> kc 2*part, 2*part+1)
   // W4: 1 chunk/thread: packed row tid>>2, part tid&3 -> tile rows (tid>>2) [low plane] and 64+(tid>>2) [high plane]
   uint4 ra[4], rw[2];
+  // CONV: the four rows this thread stages, decomposed once: element offset of the image, top-left input coordinate of the window
+  int cv_base[4], cv_ih[4], cv_iw[4];
+  if constexpr (CONV) {
+    const int L = a.OH * a.OW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int m = m0 + ((tid + 256 * j) >> 3);
+      m = m < M ? m : M - 1;
+      const int b = m / L, l = m - b * L, oh = l / a.OW, ow = l - oh * a.OW;
+      cv_base[j] = b * a.cin * a.H * a.W;
+      cv_ih[j] = oh * a.sh - a.ph;
+      cv_iw[j] = ow * a.sw - a.pw;
+    }
+  }
   auto issue_loads = [&](int kt) {
     const int k0 = kt * BK;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = tid + 256 * j, row = c >> 3, kc = c & 7;
-      int m = m0 + row;
-      m = m < M ? m : M - 1;
-      ra[j] = *reinterpret_cast<const uint4*>(xg + (size_t)m * K + k0 + kc * 8);
+      if constexpr (CONV) {
+        // eight consecutive k = (ci, i, jj) of one row: one division pair for the first, then counted up
+        const int khw = a.KH * a.KW;
+        int k = k0 + kc * 8;
+        int ci = k / khw, rem = k - ci * khw, ki = rem / a.KW, kj = rem - ki * a.KW;
+        uint16_t e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int ih = cv_ih[j] + ki * a.dh, iw = cv_iw[j] + kj * a.dw;
+          const bool in = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+          e[q] = in ? reinterpret_cast<const uint16_t*>(xg)[cv_base[j] + (ci * a.H + ih) * a.W + iw] : (uint16_t)0;
+          if (++kj == a.KW) {
+            kj = 0;
+            if (++ki == a.KH) {
+              ki = 0;
+              ++ci;
+            }
+          }
+        }
+        ra[j] = make_uint4(e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16), e[4] | ((uint32_t)e[5] << 16), e[6] | ((uint32_t)e[7] << 16));
+      } else {
+        int m = m0 + row;
+        m = m < M ? m : M - 1;
+        ra[j] = *reinterpret_cast<const uint4*>(xg + (size_t)m * K + k0 + kc * 8);
+      }
     }
     if constexpr (FMT == W_I4) {
       int p = nt * 64 + (tid >> 2);
@@ -287,7 +330,12 @@ __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
           float v = acc[i][j][r] * sc;
           asm volatile("" : "+v"(v));  // product rounded to fp32 first, with and without bias (no single-rounding v_fma_mixlo_f16)
           if (has_bias) v = E::to_f32(E::from_f32(v)) + bv;
-          yg[(size_t)m * N + n] = E::from_f32(v);
+          if constexpr (CONV) {
+            const int L = a.OH * a.OW, b = m / L;
+            yg[((size_t)b * N + n) * L + (m - b * L)] = E::from_f32(v);  // NCHW: the lane's four rows are four neighbouring pixels
+          } else {
+            yg[(size_t)m * N + n] = E::from_f32(v);
+          }
         }
       }
     }
@@ -330,18 +378,18 @@ int qbits_group_sums(const void* x, float* xs, int M, int K, int C, int Mpad, in
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int DT, int FMT, bool INT_SHIFT>
+template <int DT, int FMT, bool INT_SHIFT, bool CONV = false>
 static int mma_launch(const MmaArgs& a, hipStream_t stream) {
   static bool attr_done = false;
   constexpr int lds = 2 * 2 * TILE_BYTES;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmm_mfma_kernel<DT, FMT, INT_SHIFT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmm_mfma_kernel<DT, FMT, INT_SHIFT, CONV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   const int ntiles = FMT == W_I4 ? (a.N / 2 + 63) / 64 : (a.N + BN - 1) / BN;
   dim3 grid(ntiles, (a.M + BM - 1) / BM);
-  hipLaunchKernelGGL((qmm_mfma_kernel<DT, FMT, INT_SHIFT>), grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((qmm_mfma_kernel<DT, FMT, INT_SHIFT, CONV>), grid, dim3(256), lds, stream, a);
   return launch_status();
 }
 
@@ -357,6 +405,35 @@ int qbytes_mm_mfma(const void* x, const void* w, const void* s, const void* bias
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
   MmaArgs a{x, reinterpret_cast<const uint8_t*>(w), s, nullptr, nullptr, bias, y, (int)M, (int)N, (int)K, 0, 0, 0};
 #define QH_CASE(DT, FMT) return mma_launch<DT, FMT, false>(a, stream)
+  if (out_dtype == QUANTO_HIP_BF16) {
+    if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_BF16, W_I8);
+    if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_BF16, W_F8E4M3);
+    QH_CASE(QUANTO_HIP_BF16, W_F8E5M2);
+  }
+  if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_F16, W_I8);
+  if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_F16, W_F8E4M3);
+  QH_CASE(QUANTO_HIP_F16, W_F8E5M2);
+#undef QH_CASE
+}
+
+// Dense convolution with an 8-bit weight as an implicit GEMM (CONV above).  K = cin * KH * KW must be a multiple of 64 (the K-tile); every
+// element offset must fit 31 bits.
+bool qbytes_conv2d_supported(int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int a_dtype,
+                             int b_dtype, int out_dtype) {
+  const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2;
+  const int64_t K = cin * KH * KW;
+  return bd && a_dtype == out_dtype && (out_dtype == QUANTO_HIP_BF16 || out_dtype == QUANTO_HIP_F16) && B >= 1 && OH >= 1 && OW >= 1 && K % BK == 0 &&
+         B * cin * H * W < (1ll << 31) && B * OC * OH * OW < (1ll << 31) && OC * K < (1ll << 31) && B * OH * OW < (1ll << 30);
+}
+
+int qbytes_conv2d_mfma(const void* x, const void* w, const void* s, const void* bias, void* y, int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC,
+                       int64_t KH, int64_t KW, int64_t OH, int64_t OW, int sh, int sw, int ph, int pw, int dh, int dw, int a_dtype, int b_dtype,
+                       int out_dtype, hipStream_t stream) {
+  if (!qbytes_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
+  if (reinterpret_cast<uintptr_t>(w) % 16) return QUANTO_HIP_EALIGN;
+  MmaArgs a{x, reinterpret_cast<const uint8_t*>(w), s, nullptr, nullptr, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), 0, 0, 0,
+            (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw};
+#define QH_CASE(DT, FMT) return mma_launch<DT, FMT, false, true>(a, stream)
   if (out_dtype == QUANTO_HIP_BF16) {
     if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_BF16, W_I8);
     if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_BF16, W_F8E4M3);

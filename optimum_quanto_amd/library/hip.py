@@ -106,6 +106,8 @@ class _Bindings:
         c.quanto_hip_quantize_affine_packed.argtypes = [vp, vp, vp, vp, i64, i64, ci, ci, ci, ci, vp]
         c.quanto_hip_pack.restype = ci
         c.quanto_hip_pack.argtypes = [vp, vp, i64, i64, ci, vp]
+        c.quanto_hip_qbytes_conv2d.restype = ci
+        c.quanto_hip_qbytes_conv2d.argtypes = [vp, vp, vp, vp, vp] + [i64] * 9 + [ci] * 9 + [vp]
         self._c = c
         if c.quanto_hip_abi_version() != 1:
             raise QuantoHipError("libquanto_hip.so ABI version mismatch: rebuild with __graft_entry__.build()")
@@ -238,6 +240,36 @@ class _Bindings:
         with torch.cuda.device(t.device):
             self._check(self._c.quanto_hip_pack(_ptr(t), _ptr(out), rows, cols, bits, self._stream(t)), "pack")
         return out
+
+    # -- quanto::qbytes_conv2d (implicit GEMM) -----------------------------------------------------------
+    @staticmethod
+    def conv2d_out_size(size, k, stride, pad, dil):
+        return (size + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+    def qbytes_conv2d_supported(self, x, w) -> bool:
+        """What the kernel takes: NCHW 16-bit activations, an 8-bit OCP weight, cin * KH * KW a multiple of the K-tile (64)."""
+        return (x.is_cuda and x.dim() == 4 and w.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and
+                w.dtype in (torch.int8, torch.float8_e4m3fn, torch.float8_e5m2) and (w.shape[1] * w.shape[2] * w.shape[3]) % 64 == 0)
+
+    def qbytes_conv2d(self, x, w, scales, bias, stride, padding, dilation):
+        """Dense convolution with an 8-bit weight [OC, C, KH, KW] and per-channel scales: im2col happens inside the kernel's staging loads."""
+        self._require_cuda(x, w, scales, bias)
+        B, C, H, W = x.shape
+        OC, _, KH, KW = w.shape
+        OH = self.conv2d_out_size(H, KH, stride[0], padding[0], dilation[0])
+        OW = self.conv2d_out_size(W, KW, stride[1], padding[1], dilation[1])
+        x, w = x.contiguous(), w.contiguous()
+        s = scales.reshape(-1).to(x.dtype).contiguous()
+        if s.numel() == 1:
+            s = s.expand(OC).contiguous()
+        if bias is not None:
+            bias = bias.to(x.dtype).contiguous()
+        y = torch.empty((B, OC, max(OH, 0), max(OW, 0)), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            st = self._c.quanto_hip_qbytes_conv2d(_ptr(x), _ptr(w), _ptr(s), _ptr(bias), _ptr(y), B, C, H, W, OC, KH, KW, OH, OW, stride[0], stride[1],
+                                                  padding[0], padding[1], dilation[0], dilation[1], _dt(x), _dt(w), _dt(y), self._stream(x))
+        self._check(st, "qbytes_conv2d")
+        return y
 
     # -- quanto::unpack ---------------------------------------------------------------------------
     def unpack(self, t: torch.Tensor, bits: int) -> torch.Tensor:

@@ -152,6 +152,22 @@ if _define("qbytes_mm_bias", "(Tensor A, Tensor B, Tensor scales, Tensor? bias) 
     _impl("qbytes_mm_bias", "CUDA", qbytes_mm_bias_hip, True)
 
 
+def qbytes_conv2d_default(input, weight, scales, bias, stride, padding, dilation):
+    """What the reference computes for F.conv2d on a WeightQBytesTensor (nn/qconv2d.py:54-55 -> qfallback): dequantize, float convolution."""
+    w = scales.reshape(-1, 1, 1, 1).to(input.dtype) * weight.to(input.dtype)
+    return torch.nn.functional.conv2d(input, w, bias, tuple(stride), tuple(padding), tuple(dilation), 1)
+
+
+def qbytes_conv2d_hip(input, weight, scales, bias, stride, padding, dilation):
+    return quanto_hip.lib.qbytes_conv2d(input, weight, scales, bias, tuple(stride), tuple(padding), tuple(dilation))
+
+
+# new op: dense convolution with an int8 / fp8 weight as an implicit GEMM on the device (csrc/qmm_mfma.hip, CONV): no im2col tensor
+if _define("qbytes_conv2d", "(Tensor input, Tensor weight, Tensor scales, Tensor? bias, int[] stride, int[] padding, int[] dilation) -> Tensor"):
+    _impl("qbytes_conv2d", "CompositeExplicitAutograd", qbytes_conv2d_default, True)
+    _impl("qbytes_conv2d", "CUDA", qbytes_conv2d_hip, True)
+
+
 # ------------------------------------------------------------------------------------------------
 # quanto::quantize_symmetric / quantize_affine (quantize-time, plain torch on every device)
 # ------------------------------------------------------------------------------------------------

@@ -43,6 +43,22 @@ def conv2d_patches(input, kernel_size, stride, padding, dilation):
     return a.contiguous(), oh, ow
 
 
+def _implicit_conv2d(input, weight, scale, bias, stride, padding, dilation, groups):
+    """``quanto::qbytes_conv2d`` - the convolution as an implicit GEMM, im2col inside the kernel's staging loads (r4) - when the call is
+    eligible: dense (groups = 1), batched NCHW 16-bit input on a ROCm device, int8 / OCP fp8 weight, C*kh*kw a multiple of 64, no gradient
+    wanted.  None otherwise: the caller then lowers to a materialised im2col + GEMM (conv2d_as_gemm) or keeps the reference behaviour."""
+    from ..library.hip import quanto_hip
+
+    if groups != 1 or isinstance(padding, str) or type(input) is not torch.Tensor or input.dim() != 4 or input.device.type != "cuda":
+        return None
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (input, weight, bias)):
+        return None
+    if weight.dim() != 4 or input.shape[1] != weight.shape[1] or not quanto_hip.lib.qbytes_conv2d_supported(input, weight._data):
+        return None
+    pair = lambda v: [v, v] if isinstance(v, int) else list(v)  # noqa: E731
+    return torch.ops.quanto.qbytes_conv2d(input, weight._data, scale, bias, pair(stride), pair(padding), pair(dilation))
+
+
 def conv2d_as_gemm(input, weight, bias, stride, padding, dilation, groups, gemm):
     """``F.conv2d`` with a quantized [N, C, kh, kw] weight as im2col + one fused GEMM on the device.
 
@@ -177,6 +193,9 @@ class WeightQBytesTensor(QBytesTensor):
                     return None
                 n = weight.shape[0]
                 scale = weight._scale.reshape(-1, 1).expand(n, 1).contiguous()  # per-channel [N,1,1,1] or per-tensor
+                implicit = _implicit_conv2d(input, weight, scale, bias, stride, padding, dilation, groups)
+                if implicit is not None:
+                    return implicit
                 data = weight._data.reshape(n, -1)
                 return conv2d_as_gemm(input, weight, bias, stride, padding, dilation, groups,
                                       lambda a: torch.ops.quanto.qbytes_mm_bias(a, data, scale, bias))

@@ -108,7 +108,7 @@ def test_qconv2d_fused_gemm_gpu(golden, tag, cname, dt):
     with torch.no_grad():
         y = q(x)
     kernel = quanto_hip.lib.last_kernel()
-    assert kernel in ("gemv", "skinny", "mfma", "mfma_large", "dequant_mfma", "naive"), kernel
+    assert kernel in ("gemv", "skinny", "mfma", "mfma_large", "dequant_mfma", "naive", "conv2d_mfma"), kernel
     assert y.is_cuda and y.dtype == TORCH_DT[dt] and tuple(y.shape) == golden[key + "/y"].shape
     # exact math on the reference's integers: float64 convolution, product rounded, bias added, rounded again
     cin, cout, ksz, stride, pad = CONVS[cname]
@@ -135,6 +135,37 @@ def test_qconv2d_fused_gemm_gpu(golden, tag, cname, dt):
     else:
         assert_close_with_bias(yn, prod, bias, dt, f"qconv2d {key} ({kernel})")
     assert_similar(torch.from_numpy(golden[key + "/y"]), y.float().cpu(), atol=1e-2 if dt == "bf16" else 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("wq", ["qint8", "qfloat8_e4m3fn", "qfloat8_e5m2"])
+@pytest.mark.parametrize("cin,cout,k,s,p,d", [(64, 96, 3, 1, 1, 1), (64, 40, 3, 2, 0, 1), (128, 64, (3, 5), (2, 1), (1, 2), (1, 2)), (64, 32, 1, 1, 0, 1),
+                                              (192, 130, 3, 1, 2, 2)])
+def test_qconv2d_implicit_gemm_gpu(dt, wq, cin, cout, k, s, p, d):
+    """quanto::qbytes_conv2d (r4): the convolution as an IMPLICIT GEMM - the im2col operand is gathered inside the kernel's staging loads,
+    the output is written NCHW.  Strides, paddings, dilations, rectangular windows, ragged M (3 x 13 x 11 pixels) and ragged output channels;
+    gate: float64 convolution on the stored integers / fp8 values, per-channel scale on the accumulator, the reference's bias order."""
+    torch.manual_seed(cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, dilation=d).to(TORCH_DT[dt])
+    q = Q.QConv2d.from_module(conv, weights=getattr(Q, wq))
+    Q.freeze(q)
+    q = q.cuda()
+    x = torch.randn(3, cin, 13, 11).to(TORCH_DT[dt])
+    with torch.no_grad():
+        y = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == "conv2d_mfma"
+        w64 = q.weight._data.cpu().double() if wq == "qint8" else q.weight._data.cpu().float().double()
+        prod = torch.nn.functional.conv2d(x.double(), w64, None, conv.stride, conv.padding, conv.dilation)
+        prod = prod * q.weight._scale.cpu().double().reshape(1, -1, 1, 1)
+    assert y.shape == prod.shape and y.dtype == TORCH_DT[dt]
+    bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
+    assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), dt, f"implicit conv {cin}->{cout} k{k}")
+    # and without a bias: the plain exact-math gate
+    q.bias = None
+    with torch.no_grad():
+        y0 = q(x.cuda())
+    assert_close_to_exact(to_numpy(y0), prod.numpy(), dt, f"implicit conv {cin}->{cout} k{k}, no bias")
 
 
 @pytest.mark.gpu
