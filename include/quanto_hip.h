@@ -82,7 +82,7 @@ typedef enum {
 #define QUANTO_HIP_GEMV_MAX_M 8         /* qbytes_mm: rows of x the GEMV kernel accepts                    */
 #define QUANTO_HIP_SKINNY_MAX_M 256      /* qbits_mm: rows of x the streaming MFMA kernel accepts (passes of 64) */
 #define QUANTO_HIP_GEMV_MAX_M_QBITS 64  /* qbits_mm: ditto (passes of up to 8 rows; weights re-read from MALL) */
-#define QUANTO_HIP_GEMV_MAX_M_OTHER 24  /* qbits_mm, group size 96, qint2 (and 64 / 32 / per-channel where the streaming kernel's block shape does not fit): passes of 4 rows */
+#define QUANTO_HIP_GEMV_MAX_M_OTHER 24  /* qbits_mm, formats / shapes the streaming kernel's 64-feature blocks do not fit (group sizes 96 / 64 / 32, per-channel, qint2): passes of 4 rows */
 
 int quanto_hip_abi_version(void);
 const char* quanto_hip_status_string(int status);

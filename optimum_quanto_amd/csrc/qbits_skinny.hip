@@ -100,6 +100,7 @@ struct Args {
   // groups per 128-k tile: 1 (group size 128), 2 (64), 4 (32); per_channel: ONE scale / shift per feature (G = 1), the tables repeat it
   int gpt, per_channel;
   int planes;       // values per packed byte: 2 (int4), 4 (int2)
+  int tk;           // k per tile: 128, or 96 (group size 96)
   int nt;           // non-temporal weight DMA (single-pass calls: M <= 64)
   // QUANTO_HIP_SKINNY_ABLATE (timing experiments, WRONG results): 1 no split-K reduction, 2 no MFMA/LDS-read work,
   // 4 no activation DMA, 8 no weight DMA, 16 no scale/shift table
@@ -135,10 +136,16 @@ struct Segs {
 // PLANES: values per packed byte - 2 (int4) or 4 (int2, r4).  A wave's 16 features are then 4 packed rows x 4 planes (lane i of 16: row
 // i & 3, plane i >> 2, two bits at 2 * plane) instead of 8 rows x 2 planes; its weight piece of a tile is 512 bytes (the lower 32 lanes of the
 // DMA instruction).  Instantiated for 64-feature blocks, the 4-stage ring and group size 128.
-template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI = false, int SETS = 1, int GPT = 1, int PLANES = 2>
+// TK: k per tile - 128, or 96 (r4: group size 96, what nn/qmodule.py:121-129 picks for in_features = 96 (2j + 1), e.g. 1152, 2880, 4800).  A
+// tile is then ONE group of 96 = three k-steps; the LDS image keeps its 128-byte (weights) / 256-byte (activations) row pitch and its
+// swizzles, the DMA lanes whose chunk lies beyond k = 96 stay idle (6 of 8 / 12 of 16 chunks per row) and nothing reads those holes.
+// 64-feature blocks, the 4-stage ring, one Linear.
+template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI = false, int SETS = 1, int GPT = 1, int PLANES = 2, int TK = 128>
 __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a, const Segs segs) {
   static_assert(SETS == 1 || WAVES == 4, "two wave sets: 64-feature blocks only");
   static_assert(PLANES == 2 || (PLANES == 4 && WAVES == 4 && !MULTI && GPT == 1), "int2: 64-feature blocks, one Linear, group size 128");
+  static_assert(TK == 128 || (TK == 96 && WAVES == 4 && !MULTI && GPT == 1 && PLANES == 2), "group size 96: 64-feature blocks, one Linear, int4");
+  constexpr bool K32MAP = GPT == 4 || TK == 96;  // k-step t covers k = 32 t .. 32 t + 31 (a k-step must stay inside one group / the 96 valid k)
   constexpr int RPW = 16 / PLANES;    // packed rows per wave
   constexpr int QSHIFT = DT == QUANTO_HIP_BF16 ? 5 : 6;  // int2 only: position of the two bits inside the mantissa byte
   using E = Elem<DT>;
@@ -179,46 +186,52 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   const int M = a.M, N = a.N, K = a.K;
   const int P = N / PLANES;
   const int p0 = fb * ROWS;
-  const int nk = K / BK / S;   // tiles (= groups) of this block's K-range
+  const int nk = K / TK / S;   // tiles (= groups) of this block's K-range
   const int kt0 = sp * nk;     // first global tile / group index
   const int G = nk * GPT;      // groups held in the LDS tables
 
   // ---- per-lane DMA sources ---------------------------------------------------------------------------
   // weights: this wave's 8 rows x 128 B = 1 KiB per tile; lane -> row lane>>3, position lane&7 holds chunk pos ^ (row & 7)
   const uint8_t* wsrc;
+  bool w_valid;  // TK = 96: the lane's chunk lies inside the tile
   {
     // the swizzle is a function of the row INSIDE THE BLOCK (what the fragment reads undo); int2: lanes 32..63 repeat rows 0..3 and stay idle (w_lane)
     const int r = (lane >> 3) & (RPW - 1), c = (lane & 7) ^ ((wave * RPW + r) & 7);
-    wsrc = a.w + (size_t)(p0 + wave * RPW + r) * K + c * 16 + (size_t)kt0 * BK;
+    wsrc = a.w + (size_t)(p0 + wave * RPW + r) * K + c * 16 + (size_t)kt0 * TK;
+    w_valid = c * 16 < TK;
   }
   // activations: XP KiB-instructions per wave; instruction u covers tile rows 4*(wave*XP+u) .. +3
   const uint8_t* xsrc[XP];
+  bool x_valid[XP];
 #pragma unroll
   for (int u = 0; u < XP; ++u) {
     const int row = 4 * (wave * XP + u) + (lane >> 4);
     const int c = (lane & 15) ^ (row & 15);
     const int m = row < M ? row : M - 1;
-    xsrc[u] = reinterpret_cast<const uint8_t*>(reinterpret_cast<const T*>(a.x) + (size_t)m * K + c * 8 + (size_t)kt0 * BK);
+    xsrc[u] = reinterpret_cast<const uint8_t*>(reinterpret_cast<const T*>(a.x) + (size_t)m * K + c * 8 + (size_t)kt0 * TK);
+    x_valid[u] = c * 8 < TK;
   }
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
-  const bool w_lane = PLANES == 2 || lane < 32;  // lanes that carry a weight DMA piece (RPW rows x 128 B = RPW * 8 lanes)
+  const bool w_lane = (PLANES == 2 || lane < 32) && (TK == 128 || w_valid);  // lanes that carry a weight DMA piece (RPW rows x 128 B = RPW * 8 lanes)
   auto issue = [&](int kt, int stage) {
     const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
     // ablations keep the instruction count per tile (vmcnt arithmetic) and re-read tile 0 instead: L2 hits
     const int ktw = (a.ablate & 8) ? 0 : kt, ktx = (a.ablate & 4) ? 0 : kt;
     if (w_lane) {
       if (a.nt)
-        glds16_nt(wsrc + (size_t)ktw * BK, st + wave * (RPW * BK));
+        glds16_nt(wsrc + (size_t)ktw * TK, st + wave * (RPW * BK));
       else
-        glds16(wsrc + (size_t)ktw * BK, st + wave * (RPW * BK));
+        glds16(wsrc + (size_t)ktw * TK, st + wave * (RPW * BK));
     }
 #pragma unroll
-    for (int u = 0; u < XP; ++u) glds16(xsrc[u] + (size_t)ktx * (BK * 2), st + W_BYTES + (wave * XP + u) * 1024);
+    for (int u = 0; u < XP; ++u)
+      if (TK == 128 || x_valid[u]) glds16(xsrc[u] + (size_t)ktx * (TK * 2), st + W_BYTES + (wave * XP + u) * 1024);
   };
   // SETS = 2: the pieces of a PAIR of tiles (even tile -> stage sa, odd tile -> stage sb) dealt over the eight waves: wave (set,
   // f) carries weight piece f of the tile of its set and the activation pieces q = wave_id * TF + j of the 8 TF of the pair
   const uint8_t* xsrc2[SETS == 2 ? TF : 1];
   uint32_t xdst2[SETS == 2 ? TF : 1];
+  bool x_valid2[SETS == 2 ? TF : 1];
   if constexpr (SETS == 2) {
 #pragma unroll
     for (int j = 0; j < TF; ++j) {
@@ -226,8 +239,9 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
       const int row = 4 * piece + (lane >> 4);
       const int c = (lane & 15) ^ (row & 15);
       const int m = row < M ? row : M - 1;
-      xsrc2[j] = reinterpret_cast<const uint8_t*>(reinterpret_cast<const T*>(a.x) + (size_t)m * K + c * 8 + (size_t)(kt0 + odd) * BK);
+      xsrc2[j] = reinterpret_cast<const uint8_t*>(reinterpret_cast<const T*>(a.x) + (size_t)m * K + c * 8 + (size_t)(kt0 + odd) * TK);
       xdst2[j] = ((uint32_t)odd << 31) | (uint32_t)(W_BYTES + piece * 1024);  // bit 31: the odd tile's stage
+      x_valid2[j] = c * 8 < TK;
     }
   }
   auto issue_pair = [&](int kt, int sa, int sb) {  // kt even; the odd tile exists when kt + 1 < nk
@@ -236,14 +250,14 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
     if ((set == 0 || has_odd) && w_lane) {
       const uint32_t st = set == 0 ? sta : stb;
       if (a.nt)
-        glds16_nt(wsrc + (size_t)(kt + set) * BK, st + wave * (RPW * BK));
+        glds16_nt(wsrc + (size_t)(kt + set) * TK, st + wave * (RPW * BK));
       else
-        glds16(wsrc + (size_t)(kt + set) * BK, st + wave * (RPW * BK));
+        glds16(wsrc + (size_t)(kt + set) * TK, st + wave * (RPW * BK));
     }
 #pragma unroll
     for (int j = 0; j < (SETS == 2 ? TF : 0); ++j) {
       const bool odd = xdst2[j] >> 31;
-      if (!odd || has_odd) glds16(xsrc2[j] + (size_t)kt * (BK * 2), (odd ? stb : sta) + (xdst2[j] & 0x7FFFFFFFu));
+      if ((!odd || has_odd) && (TK == 128 || x_valid2[j])) glds16(xsrc2[j] + (size_t)kt * (TK * 2), (odd ? stb : sta) + (xdst2[j] & 0x7FFFFFFFu));
     }
   };
   if constexpr (SETS == 2) {
@@ -292,7 +306,7 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
     const int row = tf * 16 + fi;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      xoff[tf][t] = W_BYTES + row * 256 + (((GPT == 4 ? 4 * t + fg : 8 * (t >> 1) + 2 * fg + (t & 1)) ^ (row & 15)) << 4);
+      xoff[tf][t] = W_BYTES + row * 256 + (((K32MAP ? 4 * t + fg : 8 * (t >> 1) + 2 * fg + (t & 1)) ^ (row & 15)) << 4);
   }
   // this lane's 4 consecutive features inside the block: int4 plane (fg>>1), local packed rows wave*8 + 4*(fg&1) + r; int2 plane fg, rows wave*4 + r
   const int floc = PLANES == 2 ? (fg >> 1) * ROWS + wave * 8 + 4 * (fg & 1) : fg * ROWS + wave * 4;
@@ -311,11 +325,12 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   // One tile = 128 k = GPT groups: read the wave's weight bytes, 4 k-steps x (TF + TF) MFMAs, one fold into acc per group (after
   // 4 / GPT k-steps: group sizes 128, 64, 32)
   auto compute_tile = [&](const uint8_t* st, int kt) {
-    constexpr int KS = 4 / GPT;
+    constexpr int KS = TK == 96 ? 3 : 4 / GPT;
     uint4 wr[2];
-    if constexpr (GPT == 4) {
+    if constexpr (K32MAP) {
       const uint2 q0 = *reinterpret_cast<const uint2*>(st + woff4[0]), q1 = *reinterpret_cast<const uint2*>(st + woff4[1]);
-      const uint2 q2 = *reinterpret_cast<const uint2*>(st + woff4[2]), q3 = *reinterpret_cast<const uint2*>(st + woff4[3]);
+      const uint2 q2 = *reinterpret_cast<const uint2*>(st + woff4[2]);
+      const uint2 q3 = TK == 96 ? q2 : *reinterpret_cast<const uint2*>(st + woff4[3]);  // group size 96: chunks 6, 7 of a row were never written
       wr[0] = make_uint4(q0.x, q0.y, q1.x, q1.y);  // same register picture as below: k-step t = dwords 2 (t & 1), 2 (t & 1) + 1 of wr[t >> 1]
       wr[1] = make_uint4(q2.x, q2.y, q3.x, q3.y);
     } else {
@@ -518,11 +533,11 @@ constexpr int lds_bytes(int tf, int stages, int G, int waves, int planes = 2) {
 }
 
 // `segs` (with the total number of feature blocks) selects the multi-Linear launch; 64-feature blocks only, like the two-set form
-template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI, int SETS, int GPT = 1, int PLANES = 2>
+template <int DT, int TF, int STAGES, bool INT_SHIFT, int WAVES, bool MULTI, int SETS, int GPT = 1, int PLANES = 2, int TK = 128>
 static int launch_k(const Args& a, hipStream_t stream, const Segs& segs, int grid, int lds) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS, GPT, PLANES>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS, GPT, PLANES, TK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS, GPT, PLANES>), dim3(grid), dim3(WAVES * SETS * 64), lds, stream, a, segs);
+  hipLaunchKernelGGL((qbits_skinny_kernel<DT, TF, STAGES, INT_SHIFT, WAVES, MULTI, SETS, GPT, PLANES, TK>), dim3(grid), dim3(WAVES * SETS * 64), lds, stream, a, segs);
   return launch_status();
 }
 
@@ -599,8 +614,20 @@ static int launch_int2(const Args& a, hipStream_t stream) {
   return launch_k<DT, TF, 4, INT_SHIFT, 4, false, (TF >= 2 ? 2 : 1), 1, 4>(a, stream, Segs{}, a.N / 64 * a.S, lds);
 }
 
+// group size 96 (r4): tiles of 96 k, 64-feature blocks, 4-stage ring, two wave sets from two token fragments on
+template <int DT, bool INT_SHIFT, int TF>
+static int launch_g96(const Args& a, hipStream_t stream) {
+  const int lds = lds_bytes(TF, 4, a.K / 96 / a.S, 4);
+  return launch_k<DT, TF, 4, INT_SHIFT, 4, false, (TF >= 2 ? 2 : 1), 1, 2, 96>(a, stream, Segs{}, a.N / 64 * a.S, lds);
+}
+
 template <int DT, bool INT_SHIFT>
 static int launch_tf(const Args& a, hipStream_t stream, const Segs* segs = nullptr, int total_fb = 0) {
+  if (a.tk == 96) {
+    if (a.M <= 16) return launch_g96<DT, INT_SHIFT, 1>(a, stream);
+    if (a.M <= 32) return launch_g96<DT, INT_SHIFT, 2>(a, stream);
+    return launch_g96<DT, INT_SHIFT, 4>(a, stream);
+  }
   if (a.planes == 4) {
     if (a.M <= 16) return launch_int2<DT, INT_SHIFT, 1>(a, stream);
     if (a.M <= 32) return launch_int2<DT, INT_SHIFT, 2>(a, stream);
@@ -623,10 +650,19 @@ static int skinny_split(const PackedGeom& g, int64_t M) {
   const int forced = env_int("QUANTO_HIP_SKINNY_SPLIT", 0);  // experiments
   const int tf = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
   // group sizes 64 / 32 always launch 64-feature blocks (launch_small_groups), whatever the wave knob says
-  const int blocks = (g.C == 64 || g.C == 32 || g.bits == 2) ? (int)(g.N / 64) : (int)(g.N / (16 * skinny::pick_waves((int)g.N, tf)));
+  const bool g96 = g.C == 96 && g.K != 96;
+  const int blocks = (g.C == 64 || g.C == 32 || g96 || g.bits == 2) ? (int)(g.N / 64) : (int)(g.N / (16 * skinny::pick_waves((int)g.N, tf)));
   int s = 1;
-  const int tiles = (int)(g.K / 128);  // 128-k tiles (= groups of 128)
+  const int tiles = (int)(g.K / (g96 ? 96 : 128));  // 128-k tiles (= groups of 128), or groups of 96
   while (s < 8 && blocks * s * 2 <= 512 && tiles % (s * 2) == 0 && tiles / (s * 2) >= 8) s *= 2;
+  // K = 96 j with j not a multiple of 4: the largest divisor of the tile count under the same bounds, not only powers of two, while the partial
+  // sums are small (us, bf16, N = 4096, K = 4800 = 50 tiles, split 2 -> 5: M = 32 17.0 -> 13.5, but M = 64 20.3 -> 22.1, M = 128 39.3 -> 41.8)
+  if (g96 && tf <= 2)
+    for (int d = 8; d > s; --d)
+      if (tiles % d == 0 && blocks * d <= 512 && tiles / d >= 8) {
+        s = d;
+        break;
+      }
   if (forced > 0 && tiles % forced == 0) s = forced;
   if ((size_t)blocks * 4 > QUANTO_HIP_WS_COUNTER_BYTES) s = 1;  // one counter per feature block
   return s;
@@ -644,6 +680,10 @@ bool qbits_skinny_supported(int64_t M, const PackedGeom& g, int dtype) {
   const bool per_channel = g.C == g.K && g.C != 128;
   const bool grouped = g.C == 128 || ((g.C == 64 || g.C == 32) && g.N % 64 == 0);
   const int groups = per_channel ? (int)(g.K / 128) : (int)g.G;
+  if (g.bits == 4 && g.C == 96 && !per_channel)  // group size 96 (r4): tiles of 96 k, 64-feature blocks
+    return g.N % 64 == 0 && g.K % 96 == 0 && g.K >= 192 && M >= 1 && M <= QUANTO_HIP_SKINNY_MAX_M &&
+           (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30) && g.K < (1 << 30) &&
+           skinny::lds_bytes(tf, 4, (int)g.G, 4) <= 160 * 1024;
   if (g.bits == 2)  // qint2 (r4): group size 128, 64-feature blocks (16 packed rows x 4 planes)
     return g.C == 128 && g.N % 64 == 0 && g.K % 128 == 0 && M >= 1 && M <= QUANTO_HIP_SKINNY_MAX_M &&
            (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N < (1 << 30) && g.K < (1 << 30) &&
@@ -676,7 +716,7 @@ int qbits_mm_skinny(const void* x, const uint8_t* packed, const void* scale, con
                    reinterpret_cast<uint8_t*>(y) + (size_t)m0 * g.N * esize, (int)rows, (int)g.N, (int)g.K, (int)g.G, S,
                    reinterpret_cast<int*>(workspace),
                    S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr,
-                   per_channel ? 1 : (int)(128 / g.C), per_channel ? 1 : 0, g.bits == 2 ? 4 : 2,
+                   per_channel ? 1 : (int)(128 / g.C), per_channel ? 1 : 0, g.bits == 2 ? 4 : 2, (g.C == 96 && !per_channel) ? 96 : 128,
                    // later passes of a multi-pass call re-read the weights from the Infinity Cache: keep them cacheable there
                    env_int("QUANTO_HIP_SKINNY_NT", M <= 64 ? 1 : 0), env_int("QUANTO_HIP_SKINNY_ABLATE", 0),
                    reinterpret_cast<unsigned long long*>(env_ptr("QUANTO_HIP_SKINNY_TIMELINE"))};
@@ -736,7 +776,7 @@ int qbits_mm_skinny_multi(const void* x, int nseg, const uint8_t* const* packed,
   if (S > 1 && (!workspace || workspace_bytes < qbits_skinny_workspace(M, g) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
   skinny::Args a{x, packed[0], scale[0], shift[0], bias ? bias[0] : nullptr, y[0], (int)M, (int)N[0], (int)K, (int)g.G, S,
                  reinterpret_cast<int*>(workspace),
-                 S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr, 1, 0, 2,
+                 S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + skinny_counter_bytes(g)) : nullptr, 1, 0, 2, 128,
                  env_int("QUANTO_HIP_SKINNY_NT", 1), 0, nullptr};
   if (dtype == QUANTO_HIP_BF16)
     return int_shift ? skinny::launch_tf<QUANTO_HIP_BF16, true>(a, stream, &segs, fb) : skinny::launch_tf<QUANTO_HIP_BF16, false>(a, stream, &segs, fb);

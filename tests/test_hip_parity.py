@@ -300,6 +300,7 @@ def test_qbits_gemv_other_group_sizes(dt, zp, M, N, K, gs):
     ya = _run_qbits(p, "auto")
     # r3: from 5 rows on the streaming MFMA kernel serves group sizes 64 / 32 (64-feature blocks) and per-channel scales too
     streaming = M > 4 and K % 128 == 0 and ((gs in (64, 32) and N % 64 == 0) or (gs is None and N % 16 == 0))
+    streaming = streaming or (M > 4 and gs == 96 and N % 64 == 0 and K % 96 == 0)  # r4: tiles of 96 k
     assert quanto_hip.lib.last_kernel() == ("skinny" if streaming else "gemv")
     assert_close_to_exact(ya, _exact_qbits(p), dt, f"auto group_size={gs} {M}x{K}x{N}")
     y = _run_qbits(p, "gemv")
@@ -313,11 +314,12 @@ def test_qbits_gemv_other_group_sizes(dt, zp, M, N, K, gs):
 @pytest.mark.parametrize("zp", [False, True])
 @pytest.mark.parametrize("M", [5, 16, 17, 33, 64, 130])
 @pytest.mark.parametrize("N,K,gs", [(256, 1024, 64), (512, 4096, 32), (64, 128, 32), (192, 14336, 64), (128, 384, None), (1024, 1024, None),
-                                    (4096, 4096, 64)])
+                                    (4096, 4096, 64), (256, 1152, 96), (64, 192, 96), (128, 288, 96), (512, 2880, 96), (4096, 4800, 96)])
 def test_qbits_skinny_small_groups_and_per_channel(dt, zp, M, N, K, gs):
     """Streaming MFMA kernel with 2 / 4 quantization groups per 128-k tile (group sizes 64 / 32: one fold per group) and with per-channel
     scales (one table entry per feature, repeated): 1 / 2 / 4 token fragments, passes of 64 rows, K split over workgroups (N = 512,
-    K = 4096), long K (448 table rows of 64 features), integer zero-points; exact-math gate and the bias-add sequence."""
+    K = 4096), long K (448 table rows of 64 features), integer zero-points; exact-math gate and the bias-add sequence.
+    r4: group size 96 (in_features = 96 (2j + 1): tiles of 96 k with idle DMA lanes; 2 / 3 tiles, an odd tile count, K split 2 ways)."""
     p = make_qbits_problem(M, N, K, dt, group_size=gs, zeropoint=zp, seed=M + N + K)
     y = _run_qbits(p, "skinny")
     assert quanto_hip.lib.last_kernel() == "skinny"

@@ -75,14 +75,15 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 4, 128, 2) for m in (4, 5, 16, 17)] == [2, 9, 9, 5]
     assert [lib.quanto_hip_qbits_mm_pick(8, n, k, 4, 128, 2) for n, k in ((1024, 4096), (14336, 4096), (4096, 14336), (5120, 5120))] == [9, 5, 5, 5]
     assert lib.quanto_hip_qbits_mm_workspace_size(2048, 4096, 4096, 4, 128, 2, 0) == 4096 * 4096 * 2
-    # r3: group sizes 64 / 32 (64-feature blocks) and per-channel scales run the streaming kernel from 5 rows up to 192; group size 96 and
-    # qint2 keep the GEMV passes (<= 24 rows), everything beyond goes through dequantize + dense GEMM
+    # r3: group sizes 64 / 32 (64-feature blocks) and per-channel scales run the streaming kernel from 5 rows up to 192 (r4: group size 96 and
+    # qint2 with group size 128 as well); what it does not take keeps the GEMV passes (<= 24 rows), everything beyond goes through dequantize + dense GEMM
     SKINNY, GEMV, DEQUANT, MFMA128 = 5, 2, 7, 3
     assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 4, 64, 2) for m in (4, 5, 64, 192, 193)] == [GEMV, SKINNY, SKINNY, SKINNY, DEQUANT]
     assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 4, 32, 2) for m in (8, 128)] == [SKINNY, SKINNY]
     assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 4, 0, 2) for m in (8, 128)] == [SKINNY, SKINNY]       # per-channel
     assert lib.quanto_hip_qbits_mm_pick(40, 200, 512, 4, 64, 2) == MFMA128                                      # N not in 64-feature blocks
-    assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 1152, 4, 96, 2) for m in (8, 24, 25)] == [GEMV, GEMV, DEQUANT]  # group size 96
+    assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 1152, 4, 96, 2) for m in (4, 8, 25, 192, 193)] == [GEMV, SKINNY, SKINNY, SKINNY, DEQUANT]  # group size 96 (r4)
+    assert [lib.quanto_hip_qbits_mm_pick(8, n, k, 4, 96, 2) for n, k in ((4000, 1152), (4096, 96))] == [GEMV, GEMV]  # N not in 64-feature blocks; one group = per-channel
     assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 2, 128, 2) for m in (4, 8, 25, 192, 193)] == [GEMV, SKINNY, SKINNY, SKINNY, DEQUANT]  # qint2 (r4)
     assert lib.quanto_hip_qbits_mm_pick(8, 4096, 4096, 2, 64, 2) == GEMV                                          # qint2, group size 64: GEMV passes
     # r4: the large-tile int4 GEMM where the dense weight leaves the Infinity Cache; dequantize + dense below
