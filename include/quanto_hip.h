@@ -285,6 +285,21 @@ int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, c
                              int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,
                              int pad_w, int dil_h, int dil_w, int a_dtype, int b_dtype, int out_dtype, void* stream);
 
+/*
+ * F.conv2d with an int4 weight - what QConv2d.forward (nn/qconv2d.py:54-55) reaches through WeightQBitsTensor's dispatch (qfallback: dequantize
+ * the whole weight, float convolution).  The same implicit GEMM as quanto_hip_qbytes_conv2d; the packed bytes are dequantized while they are
+ * staged, with the reference's own roundings (tensor/qbits.py:27-49: T(T(scale q) - shift) for float shifts, T(scale (q - zero_point)) for
+ * integer zero-points), so the matrix cores multiply by exactly the dense weight the reference would have materialised.  No workspace.
+ *   x: dtype[B, cin, H, W]; packed: the generic PackedTensor bytes of the axis-0 quantized weight [OC, cin, KH, KW] viewed as [OC, K = cin KH KW]
+ *   (byte (p, k) = q[p, k] | q[p + OC/2, k] << 4); scale / shift: [OC * K / group_size] as for quanto_hip_qbits_mm (group_size 0 = per-channel);
+ *   bias: dtype[OC] or NULL; y: dtype[B, OC, OH, OW].  dtype in {F16, BF16}; shift_dtype = dtype or U8 / I8.
+ *   Requires bits = 4, OC even, K a multiple of 64 and group_size a multiple of 16; QUANTO_HIP_ENOTSUP otherwise (the caller then lowers the
+ *   convolution to im2col + qbits_mm).
+ */
+int quanto_hip_qbits_conv2d(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t B, int64_t cin,
+                            int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,
+                            int pad_w, int dil_h, int dil_w, int bits, int group_size, int dtype, int shift_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,10 @@
 
 namespace qh {
 
-enum WFmt { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2, W_I4 = 3 };
+// W_I4: generic packed int4, operand OFFSET + q, per-group fold in fp32 (exact math).  W_I4R (r4, convolution): the same bytes dequantized at
+// staging time with the reference's roundings (tensor/qbits.py:27-49: T(T(s q) - z) for float shifts, T(s (q - zp)) for zero-points) - the LDS
+// operand IS the reference's dense weight, no fold, no workspace
+enum WFmt { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2, W_I4 = 3, W_I4R = 4 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // one operand tile in LDS (16 KiB)
@@ -103,6 +106,35 @@ __device__ __forceinline__ void convert16_i4(const uint4& w, uint4 (&lo)[2], uin
   hi[1] = make_uint4(h[4], h[5], h[6], h[7]);
 }
 
+// 16 packed bytes -> 16 low-nibble and 16 high-nibble weights dequantized as the reference does (two roundings for float shifts, one for
+// zero-points), round-to-nearest-even into the activation dtype
+template <int DT, bool INT_SHIFT>
+__device__ __forceinline__ void convert16_i4r(const uint4& w, float s_lo, float z_lo, float s_hi, float z_hi, uint4 (&lo)[2], uint4 (&hi)[2]) {
+  using E = Elem<DT>;
+  auto deq = [](uint32_t q, float sc, float z) -> uint32_t {
+    float v;
+    if constexpr (INT_SHIFT)
+      v = sc * ((float)q - z);
+    else
+      v = E::to_f32(E::from_f32(sc * (float)q)) - z;
+    return (uint32_t)__builtin_bit_cast(uint16_t, E::from_f32(v));
+  };
+  const uint32_t in[4] = {w.x, w.y, w.z, w.w};
+  uint32_t l[8], h[8];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const uint32_t two = in[d] >> (16 * b);  // bytes 2b, 2b + 1
+      l[2 * d + b] = deq(two & 0xFu, s_lo, z_lo) | (deq((two >> 8) & 0xFu, s_lo, z_lo) << 16);
+      h[2 * d + b] = deq((two >> 4) & 0xFu, s_hi, z_hi) | (deq((two >> 12) & 0xFu, s_hi, z_hi) << 16);
+    }
+  lo[0] = make_uint4(l[0], l[1], l[2], l[3]);
+  lo[1] = make_uint4(l[4], l[5], l[6], l[7]);
+  hi[0] = make_uint4(h[0], h[1], h[2], h[3]);
+  hi[1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
 struct MmaArgs {
   const void* x;        // [M, K] activation dtype
   const uint8_t* w;     // W8: [N, K] bytes; W4: packed [N/2, K] bytes
@@ -118,7 +150,8 @@ struct MmaArgs {
 
 template <int DT, int FMT, bool INT_SHIFT, bool CONV = false>
 __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
-  static_assert(!CONV || FMT != W_I4, "implicit-GEMM convolution: 8-bit weights");
+  static_assert(!CONV || FMT != W_I4, "implicit-GEMM convolution: 8-bit weights, or int4 dequantized at staging (W_I4R)");
+  constexpr bool PACKED4 = FMT == W_I4 || FMT == W_I4R;  // generic packed int4 rows: a tile's 128 columns are 64 packed rows x both nibble planes
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
@@ -138,6 +171,7 @@ __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
   // W8: 2 chunks/thread of 16 bytes: c = tid + 256*j -> row c>>2, part c&3 (16 weights -> kc 2*part, 2*part+1)
   // W4: 1 chunk/thread: packed row tid>>2, part tid&3 -> tile rows (tid>>2) [low plane] and 64+(tid>>2) [high plane]
   uint4 ra[4], rw[2];
+  float rs[2] = {0.f, 0.f}, rz[2] = {0.f, 0.f};  // W_I4R: scale / shift of the thread's packed row, low and high plane, group of the K-tile chunk
   // CONV: the four rows this thread stages, decomposed once: element offset of the image, top-left input coordinate of the window
   int cv_base[4], cv_ih[4], cv_iw[4];
   if constexpr (CONV) {
@@ -183,10 +217,22 @@ __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
         ra[j] = *reinterpret_cast<const uint4*>(xg + (size_t)m * K + k0 + kc * 8);
       }
     }
-    if constexpr (FMT == W_I4) {
+    if constexpr (PACKED4) {
       int p = nt * 64 + (tid >> 2);
       p = p < P ? p : P - 1;
       rw[0] = *reinterpret_cast<const uint4*>(a.w + (size_t)p * K + k0 + (tid & 3) * 16);
+      if constexpr (FMT == W_I4R) {
+        const int g = (k0 + (tid & 3) * 16) / a.C;  // the 16 k of a chunk lie in one group (C % 16 == 0)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const size_t idx = (size_t)(pl * P + p) * a.G + g;
+          rs[pl] = E::to_f32(reinterpret_cast<const T*>(a.scale)[idx]);
+          if constexpr (INT_SHIFT)
+            rz[pl] = (float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[idx];
+          else
+            rz[pl] = E::to_f32(reinterpret_cast<const T*>(a.shift)[idx]);
+        }
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -205,9 +251,12 @@ __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
       const int c = tid + 256 * j, row = c >> 3, kc = c & 7;
       *reinterpret_cast<uint4*>(sa + lds_off(row, kc)) = ra[j];
     }
-    if constexpr (FMT == W_I4) {
+    if constexpr (PACKED4) {
       uint4 lo[2], hi[2];
-      convert16_i4<DT>(rw[0], lo, hi);
+      if constexpr (FMT == W_I4R)
+        convert16_i4r<DT, INT_SHIFT>(rw[0], rs[0], rz[0], rs[1], rz[1], lo, hi);
+      else
+        convert16_i4<DT>(rw[0], lo, hi);
       const int row = tid >> 2, part = tid & 3;
       *reinterpret_cast<uint4*>(sb + lds_off(row, 2 * part)) = lo[0];
       *reinterpret_cast<uint4*>(sb + lds_off(row, 2 * part + 1)) = lo[1];
@@ -239,7 +288,7 @@ __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int tc = wn * 64 + j * 16 + (lane & 15);
-    if constexpr (FMT == W_I4) {
+    if constexpr (PACKED4) {
       const int p = nt * 64 + (tc & 63);
       ncol[j] = (p < P) ? p + (tc >> 6) * P : -1;
     } else {
@@ -318,7 +367,7 @@ __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
     const int n = ncol[j];
     if (n < 0) continue;
     float sc = 1.f;
-    if constexpr (FMT != W_I4) sc = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
+    if constexpr (!PACKED4) sc = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
     const bool has_bias = a.bias != nullptr;
     const float bv = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
 #pragma unroll
@@ -387,7 +436,7 @@ static int mma_launch(const MmaArgs& a, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  const int ntiles = FMT == W_I4 ? (a.N / 2 + 63) / 64 : (a.N + BN - 1) / BN;
+  const int ntiles = (FMT == W_I4 || FMT == W_I4R) ? (a.N / 2 + 63) / 64 : (a.N + BN - 1) / BN;
   dim3 grid(ntiles, (a.M + BM - 1) / BM);
   hipLaunchKernelGGL((qmm_mfma_kernel<DT, FMT, INT_SHIFT, CONV>), grid, dim3(256), lds, stream, a);
   return launch_status();
@@ -443,6 +492,29 @@ int qbytes_conv2d_mfma(const void* x, const void* w, const void* s, const void* 
   if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_F16, W_F8E4M3);
   QH_CASE(QUANTO_HIP_F16, W_F8E5M2);
 #undef QH_CASE
+}
+
+// Dense convolution with a generic packed int4 weight (r4): the CONV gather above + W_I4R staging.  The weight [OC, cin, KH, KW] quantized along
+// axis 0 is the [OC, K = cin * KH * KW] operand of qbits_mm (groups run along the flattened K); group sizes that are multiples of 16 (a
+// staging chunk must not straddle groups) and per-channel scales.
+bool qbits_conv2d_supported(int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, const PackedGeom& g,
+                            int dtype) {
+  const int64_t K = cin * KH * KW;
+  return g.bits == 4 && g.N == OC && g.K == K && OC % 2 == 0 && g.C % 16 == 0 && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && B >= 1 &&
+         OH >= 1 && OW >= 1 && K % BK == 0 && B * cin * H * W < (1ll << 31) && B * OC * OH * OW < (1ll << 31) && OC * K < (1ll << 31) &&
+         OC * g.G < (1ll << 31) && B * OH * OW < (1ll << 30);
+}
+
+int qbits_conv2d_mfma(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t B, int64_t cin,
+                      int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int sh, int sw, int ph, int pw, int dh, int dw,
+                      const PackedGeom& g, int dtype, bool int_shift, hipStream_t stream) {
+  if (!qbits_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, g, dtype)) return QUANTO_HIP_ENOTSUP;
+  if (reinterpret_cast<uintptr_t>(packed) % 16) return QUANTO_HIP_EALIGN;
+  MmaArgs a{x, packed, scale, shift, nullptr, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), (int)g.C, (int)g.G, 0,
+            (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw};
+  if (dtype == QUANTO_HIP_BF16)
+    return int_shift ? mma_launch<QUANTO_HIP_BF16, W_I4R, true, true>(a, stream) : mma_launch<QUANTO_HIP_BF16, W_I4R, false, true>(a, stream);
+  return int_shift ? mma_launch<QUANTO_HIP_F16, W_I4R, true, true>(a, stream) : mma_launch<QUANTO_HIP_F16, W_I4R, false, true>(a, stream);
 }
 
 bool qbits_mfma_supported(int64_t M, const PackedGeom& g, int dtype) {

@@ -108,6 +108,8 @@ class _Bindings:
         c.quanto_hip_pack.argtypes = [vp, vp, i64, i64, ci, vp]
         c.quanto_hip_qbytes_conv2d.restype = ci
         c.quanto_hip_qbytes_conv2d.argtypes = [vp, vp, vp, vp, vp] + [i64] * 9 + [ci] * 9 + [vp]
+        c.quanto_hip_qbits_conv2d.restype = ci
+        c.quanto_hip_qbits_conv2d.argtypes = [vp] * 6 + [i64] * 9 + [ci] * 10 + [vp]
         self._c = c
         if c.quanto_hip_abi_version() != 1:
             raise QuantoHipError("libquanto_hip.so ABI version mismatch: rebuild with __graft_entry__.build()")
@@ -269,6 +271,36 @@ class _Bindings:
             st = self._c.quanto_hip_qbytes_conv2d(_ptr(x), _ptr(w), _ptr(s), _ptr(bias), _ptr(y), B, C, H, W, OC, KH, KW, OH, OW, stride[0], stride[1],
                                                   padding[0], padding[1], dilation[0], dilation[1], _dt(x), _dt(w), _dt(y), self._stream(x))
         self._check(st, "qbytes_conv2d")
+        return y
+
+    # -- quanto::qbits_conv2d (implicit GEMM, int4 dequantized while staged) -----------------------------------
+    def qbits_conv2d_supported(self, x, weight_size, bits: int, group_size) -> bool:
+        """NCHW 16-bit activations, generic packed int4 weight [OC, C, KH, KW] with OC even, C * KH * KW a multiple of 64 and groups of a
+        multiple of 16 (or per-channel scales)."""
+        oc, c, kh, kw = weight_size
+        k = c * kh * kw
+        return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and bits == 4 and oc % 2 == 0 and k % 64 == 0 and
+                (not group_size or (group_size % 16 == 0 and k % group_size == 0)))
+
+    def qbits_conv2d(self, x, packed, scale, shift, bias, bits: int, group_size, weight_size, stride, padding, dilation):
+        """Dense convolution with a generic packed int4 weight (its [OC, C, KH, KW] shape in ``weight_size``): im2col inside the staging loads,
+        the weight dequantized there with the reference's roundings."""
+        self._require_cuda(x, packed, scale, shift, bias)
+        if x.dtype != scale.dtype:
+            x = x.to(scale.dtype)
+        B, C, H, W = x.shape
+        OC, _, KH, KW = weight_size
+        OH = self.conv2d_out_size(H, KH, stride[0], padding[0], dilation[0])
+        OW = self.conv2d_out_size(W, KW, stride[1], padding[1], dilation[1])
+        x, packed, scale, shift = x.contiguous(), packed.contiguous(), scale.contiguous(), shift.contiguous()
+        if bias is not None:
+            bias = bias.to(x.dtype).contiguous()
+        y = torch.empty((B, OC, max(OH, 0), max(OW, 0)), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            st = self._c.quanto_hip_qbits_conv2d(_ptr(x), _ptr(packed), _ptr(scale), _ptr(shift), _ptr(bias), _ptr(y), B, C, H, W, OC, KH, KW, OH, OW,
+                                                 stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], bits, group_size or 0, _dt(x),
+                                                 _dt(shift), self._stream(x))
+        self._check(st, "qbits_conv2d")
         return y
 
     # -- quanto::unpack ---------------------------------------------------------------------------

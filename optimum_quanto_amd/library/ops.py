@@ -295,6 +295,27 @@ if _define("qbits_mm",
     _impl("qbits_mm", "CUDA", qbits_mm_hip, True)
 
 
+def qbits_conv2d_default(input, packed, scale, shift, bias, bits: int, group_size: Optional[int], weight_size, stride, padding, dilation):
+    """What the reference computes for F.conv2d on a WeightQBitsTensor (nn/qconv2d.py:54-55 -> qfallback): dequantize, float convolution."""
+    oc, c, kh, kw = weight_size
+    w = torch.ops.quanto.dequantize_qbits(packed, scale, shift, bits, group_size, oc, c * kh * kw).reshape(oc, c, kh, kw)
+    return torch.nn.functional.conv2d(input, w.to(input.dtype), bias, tuple(stride), tuple(padding), tuple(dilation), 1)
+
+
+def qbits_conv2d_hip(input, packed, scale, shift, bias, bits: int, group_size: Optional[int], weight_size, stride, padding, dilation):
+    return quanto_hip.lib.qbits_conv2d(input, packed, scale, shift, bias, bits, group_size, tuple(weight_size), tuple(stride), tuple(padding),
+                                       tuple(dilation))
+
+
+# new op: dense convolution with a packed int4 weight as an implicit GEMM on the device (csrc/qmm_mfma.hip, CONV + W_I4R): no im2col tensor,
+# no dequantized weight in memory
+if _define("qbits_conv2d",
+           "(Tensor input, Tensor packed, Tensor scale, Tensor shift, Tensor? bias, int bits, int? group_size, int[] weight_size, "
+           "int[] stride, int[] padding, int[] dilation) -> Tensor"):
+    _impl("qbits_conv2d", "CompositeExplicitAutograd", qbits_conv2d_default, True)
+    _impl("qbits_conv2d", "CUDA", qbits_conv2d_hip, True)
+
+
 # several Linears applied to the same input in one launch (q/k/v, gate/up of a decoder layer at decode time)
 def qbits_mm_multi_default(input, packed, scale, shift, bias, bits: int, group_size: Optional[int], out_features, in_features: int):
     return [torch.ops.quanto.qbits_mm(input, packed[i], scale[i], shift[i], bias[i], bits, group_size, out_features[i], in_features)

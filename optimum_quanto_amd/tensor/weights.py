@@ -61,6 +61,27 @@ def _implicit_conv2d(input, weight, scale, bias, stride, padding, dilation, grou
     return torch.ops.quanto.qbytes_conv2d(input, weight._data, scale, bias, pair(stride), pair(padding), pair(dilation))
 
 
+def _implicit_conv2d_qbits(input, weight, bias, stride, padding, dilation, groups):
+    """``quanto::qbits_conv2d`` - the same implicit GEMM for a packed int4 weight, dequantized with the reference's roundings while it is staged
+    (r4) - under the conditions of _implicit_conv2d; None otherwise (im2col + qbits_mm, or the reference behaviour)."""
+    from ..library.hip import quanto_hip
+
+    if groups != 1 or isinstance(padding, str) or type(input) is not torch.Tensor or input.dim() != 4 or input.device.type != "cuda":
+        return None
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (input, weight, bias)):
+        return None
+    packed = weight._data
+    if weight.dim() != 4 or input.shape[1] != weight.shape[1] or input.dtype != weight._scale.dtype:
+        return None
+    if not quanto_hip.lib.qbits_conv2d_supported(input, tuple(weight.shape), packed.bits, weight._group_size):
+        return None
+    pair = lambda v: [v, v] if isinstance(v, int) else list(v)  # noqa: E731
+    if tuple(weight.shape[2:]) == (1, 1) and pair(stride) == [1, 1] and pair(padding) == [0, 0]:
+        return None  # pointwise: a permuted view of the input + the tuned GEMM kernels
+    return torch.ops.quanto.qbits_conv2d(input, packed._data, weight._scale, weight._shift, bias, packed.bits, weight._group_size,
+                                         list(weight.shape), pair(stride), pair(padding), pair(dilation))
+
+
 def conv2d_as_gemm(input, weight, bias, stride, padding, dilation, groups, gemm):
     """``F.conv2d`` with a quantized [N, C, kh, kw] weight as im2col + one fused GEMM on the device.
 
@@ -388,6 +409,9 @@ class WeightQBitsTensor(QBitsTensor):
                         and not weight.qtype.is_floating_point):
                     return None
                 n, k = weight.shape[0], weight.numel() // weight.shape[0]
+                implicit = _implicit_conv2d_qbits(input, weight, bias, stride, padding, dilation, groups)
+                if implicit is not None:
+                    return implicit
                 return conv2d_as_gemm(input, weight, bias, stride, padding, dilation, groups,
                                       lambda a: torch.ops.quanto.qbits_mm(a, weight._data._data, weight._scale, weight._shift, bias,
                                                                           weight._data.bits, weight._group_size, n, k))

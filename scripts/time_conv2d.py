@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""QConv2d on the device: the implicit-GEMM kernel (quanto::qbytes_conv2d) against the materialised im2col + quanto::qbytes_mm lowering and the
-reference's behaviour (dequantize + float convolution).  One JSON line per shape; hipGraph-timed, best of five replays."""
+"""QConv2d on the device: the implicit-GEMM kernel (quanto::qbytes_conv2d; `qint4` as first argument: quanto::qbits_conv2d) against the materialised
+im2col + quanto::qbytes_mm / qbits_mm lowering and the reference's behaviour (dequantize + float convolution).  One JSON line per shape;
+hipGraph-timed, best of five replays."""
 import json
 import os
 import sys
@@ -14,23 +15,28 @@ import optimum_quanto_amd as Q  # noqa: E402
 from auto_vs_best import _time_graph  # noqa: E402
 from optimum_quanto_amd.tensor.weights import conv2d_as_gemm  # noqa: E402
 
+WEIGHTS = sys.argv[1] if len(sys.argv) > 1 else "qint8"
 for (B, C, H, OC, k, s, p) in [(8, 256, 56, 256, 3, 1, 1), (8, 128, 56, 128, 3, 1, 1), (32, 512, 14, 512, 3, 1, 1), (8, 64, 112, 128, 3, 2, 1), (8, 512, 28, 128, 1, 1, 0)]:
     torch.manual_seed(0)
     conv = torch.nn.Conv2d(C, OC, k, stride=s, padding=p).to(torch.bfloat16)
-    q = Q.QConv2d.from_module(conv, weights=Q.qint8)
+    q = Q.QConv2d.from_module(conv, weights=getattr(Q, WEIGHTS))
     Q.freeze(q)
     q = q.cuda()
     x = torch.randn(B, C, H, H, device="cuda").to(torch.bfloat16)
     w = q.weight
-    scale = w._scale.reshape(-1, 1).expand(OC, 1).contiguous()
-    data2d = w._data.reshape(OC, -1)
+    if WEIGHTS == "qint8":
+        scale = w._scale.reshape(-1, 1).expand(OC, 1).contiguous()
+        data2d = w._data.reshape(OC, -1)
+        gemm = lambda a: torch.ops.quanto.qbytes_mm_bias(a, data2d, scale, q.bias)  # noqa: E731
+    else:
+        gemm = lambda a: torch.ops.quanto.qbits_mm(a, w._data._data, w._scale, w._shift, q.bias, 4, w._group_size, OC, C * k * k)  # noqa: E731
     wdq = w.dequantize()
     with torch.no_grad():
         t_imp = _time_graph(lambda: q(x), 5)
-        t_unf = _time_graph(lambda: conv2d_as_gemm(x, w, q.bias, (s, s), (p, p), (1, 1), 1, lambda a: torch.ops.quanto.qbytes_mm_bias(a, data2d, scale, q.bias)), 5)
+        t_unf = _time_graph(lambda: conv2d_as_gemm(x, w, q.bias, (s, s), (p, p), (1, 1), 1, gemm), 5)
         t_ref = _time_graph(lambda: torch.nn.functional.conv2d(x, w.dequantize(), q.bias, s, p), 5)
         t_dense = _time_graph(lambda: torch.nn.functional.conv2d(x, wdq, q.bias, s, p), 5)
     OHW = (H + 2 * p - k) // s + 1
-    print(json.dumps({"B": B, "C": C, "H": H, "OC": OC, "k": k, "stride": s, "M": B * OHW * OHW, "K": C * k * k, "implicit_gemm_us": round(t_imp, 1),
+    print(json.dumps({"weights": WEIGHTS, "group_size": getattr(w, "_group_size", None), "B": B, "C": C, "H": H, "OC": OC, "k": k, "stride": s, "M": B * OHW * OHW, "K": C * k * k, "implicit_gemm_us": round(t_imp, 1),
                       "unfold_plus_gemm_us": round(t_unf, 1), "reference_dequantize_plus_conv_us": round(t_ref, 1), "float_conv_only_us": round(t_dense, 1),
                       "im2col_bytes_not_written": B * OHW * OHW * C * k * k * 2}), flush=True)

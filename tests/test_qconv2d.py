@@ -108,14 +108,14 @@ def test_qconv2d_fused_gemm_gpu(golden, tag, cname, dt):
     with torch.no_grad():
         y = q(x)
     kernel = quanto_hip.lib.last_kernel()
-    assert kernel in ("gemv", "skinny", "mfma", "mfma_large", "dequant_mfma", "naive", "conv2d_mfma"), kernel
+    assert kernel in ("gemv", "skinny", "mfma", "mfma_large", "dequant_mfma", "naive", "conv2d_mfma", "conv2d_mfma_int4"), kernel
     assert y.is_cuda and y.dtype == TORCH_DT[dt] and tuple(y.shape) == golden[key + "/y"].shape
     # exact math on the reference's integers: float64 convolution, product rounded, bias added, rounded again
     cin, cout, ksz, stride, pad = CONVS[cname]
     x64 = torch.from_numpy(golden[key + "/x"]).double()
     a64, _, _ = conv2d_patches(x64, (ksz, ksz), stride, pad, 1)
     a64 = a64.numpy()
-    if tag == "int4" and kernel != "dequant_mfma":
+    if tag == "int4" and kernel not in ("dequant_mfma", "conv2d_mfma_int4"):
         # the fused int4 kernels use q * scale - shift unrounded (exact math on the reference's integers and scales)
         gs = int(golden[key + "/group_size"])
         w64 = O.dequantize_qbits_exact(golden[key + "/wpacked"], 4, golden[key + "/wscale"], golden[key + "/wshift"], 0,
@@ -166,6 +166,44 @@ def test_qconv2d_implicit_gemm_gpu(dt, wq, cin, cout, k, s, p, d):
     with torch.no_grad():
         y0 = q(x.cuda())
     assert_close_to_exact(to_numpy(y0), prod.numpy(), dt, f"implicit conv {cin}->{cout} k{k}, no bias")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("zp", [False, True])
+@pytest.mark.parametrize("cin,cout,k,s,p,d,gs", [(128, 96, 3, 1, 1, 1, 128), (64, 40, 3, 2, 0, 1, 64), (128, 64, (3, 5), (2, 1), (1, 2), (1, 2), 128),
+                                                 (192, 130, 3, 1, 2, 2, 32), (64, 256, 3, 1, 1, 1, None), (32, 34, (2, 3), 1, 0, 1, 96),
+                                                 (64, 96, 3, 1, 1, 1, 96)])
+def test_qconv2d_int4_implicit_gemm_gpu(dt, zp, cin, cout, k, s, p, d, gs):
+    """quanto::qbits_conv2d (r4): the implicit GEMM with a packed int4 weight, dequantized while it is staged with the reference's roundings.
+    Gate: float64 convolution with the weight the reference dequantizes (bit for bit `q.weight.dequantize()`), the reference's bias order;
+    group sizes 128 / 96 / 64 / 32 and per-channel, float shifts and integer zero-points, ragged M and ragged output channels."""
+    from optimum_quanto_amd.tensor.weights import WeightQBitsTensor
+
+    torch.manual_seed(cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, dilation=d).to(TORCH_DT[dt])
+    q = Q.QConv2d.from_module(conv, weights=Q.qint4)
+    Q.freeze(q)
+    # the module picks its own group size (nn/qmodule.py:121-129); the weight under test is rebuilt with the requested one / with zero-points
+    scale, shift = Q.MaxOptimizer()(conv.weight.detach(), Q.qint4, 0, gs, zeropoint=zp)
+    w = Q.quantize_weight(conv.weight.detach(), Q.qint4, 0, scale, shift, group_size=gs, optimized=False)
+    assert isinstance(w, WeightQBitsTensor) and w._group_size == gs and (w._shift.dtype == torch.uint8) == zp
+    q.weight = torch.nn.Parameter(w, requires_grad=False)
+    q = q.cuda()
+    x = torch.randn(3, cin, 13, 11).to(TORCH_DT[dt])
+    with torch.no_grad():
+        y = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == "conv2d_mfma_int4"
+        wdq = q.weight.dequantize()
+        assert wdq.dtype == TORCH_DT[dt]
+        prod = torch.nn.functional.conv2d(x.double(), wdq.cpu().double(), None, conv.stride, conv.padding, conv.dilation)
+    assert y.shape == prod.shape and y.dtype == TORCH_DT[dt]
+    bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
+    assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), dt, f"int4 implicit conv {cin}->{cout} k{k} g{gs}")
+    q.bias = None
+    with torch.no_grad():
+        y0 = q(x.cuda())
+    assert_close_to_exact(to_numpy(y0), prod.numpy(), dt, f"int4 implicit conv {cin}->{cout} k{k} g{gs}, no bias")
 
 
 @pytest.mark.gpu
