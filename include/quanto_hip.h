@@ -87,8 +87,9 @@ typedef enum {
 int quanto_hip_abi_version(void);
 const char* quanto_hip_status_string(int status);
 
-/* Name of the kernel the last successful *_mm call on this thread dispatched to
- * ("naive", "gemv", "mfma", ...).  Used by tests to assert that the intended path ran. */
+/* Name of the kernel the last successful *_mm / *_conv2d call on this thread dispatched to ("naive", "gemv", "mmv", "skinny", "skinny_multi",
+ * "mfma", "mfma_large", "mfma_native8", "mfma_fused4", "mfma_large4", "dequant_mfma", "conv2d_mfma", "conv2d_mfma_int4", ...).  Used by tests to
+ * assert that the intended path ran. */
 const char* quanto_hip_last_kernel(void);
 
 /* 0 when `stream` is not being captured into a hipGraph, otherwise the (positive) id of the capture sequence; negative

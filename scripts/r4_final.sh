@@ -18,4 +18,8 @@ for w in int4_prefill; do
   f=$(find $D -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/r04_${w}_kernel_stats.csv; grep "^{" $D.log | tail -1 > $OUT/r04_${w}_bench_under_rocprof.json
   head -6 $OUT/r04_${w}_kernel_stats.csv | cut -c1-200
 done
+echo "== kernel stats: group-size-96 streaming kernel and the int4 implicit-GEMM convolution"
+D=$OUT/prof_r04_new; rm -rf $D
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o new -- python $REPO/scripts/profile_new_kernels.py > $D.log 2>&1)
+f=$(find $D -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "^\"Name|qbits_skinny_kernel|qmm_mfma_kernel" "$f" | cut -c1-300 > $OUT/r04_group96_and_int4_conv_kernel_stats.csv; cut -c1-200 $OUT/r04_group96_and_int4_conv_kernel_stats.csv
 rm -rf $OUT/prof_r04_* $OUT/g4
