@@ -172,19 +172,35 @@ __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
   // W4: 1 chunk/thread: packed row tid>>2, part tid&3 -> tile rows (tid>>2) [low plane] and 64+(tid>>2) [high plane]
   uint4 ra[4], rw[2];
   float rs[2] = {0.f, 0.f}, rz[2] = {0.f, 0.f};  // W_I4R: scale / shift of the thread's packed row, low and high plane, group of the K-tile chunk
-  // CONV: the four rows this thread stages, decomposed once: element offset of the image, top-left input coordinate of the window
-  int cv_base[4], cv_ih[4], cv_iw[4];
+  // CONV (r4, table-driven gather): a thread stages ONE output pixel - tile row tid & 127, chunks kc = (tid >> 7) + 2 j - so the 64 lanes of a
+  // load are 64 neighbouring pixels and k is uniform across a wave.  What depends on k only - the byte offset of tap (ci, ki, kj) relative to the
+  // window's top-left tap, and the tap's number ki KW + kj - is computed ONCE per K-tile by 64 threads into a 64-entry LDS table (two buffers);
+  // what depends on the pixel only - its base offset and one validity bit per tap - lives in three registers.  An element then costs
+  // add + bit-extract + two selects instead of a division-free but ~30-instruction walk per lane (a lone wave per SIMD issues a VALU op every
+  // ~8 cycles: the first form spent 3.7 us per K-tile whatever M was, profiles/r04_qconv2d_paths_grid_before_table_gather.jsonl).
+  uint32_t cv_voff = 0;  // byte offset of input element (b, 0, oh sh, ow sw): the window's top-left tap shifted right/down by the padding
+  uint64_t cv_mask = 0;  // bit ki KW + kj: tap (ki, kj) of this pixel's window lies inside the image (KH KW <= 64)
+  uint32_t cv_raw[CONV ? 4 : 1][8], cv_keep = 0;  // the gathered elements of the K-tile in flight (invalid taps hold x[0]) and their validity bits
+  int2* ktab = reinterpret_cast<int2*>(smem + 2 * 2 * TILE_BYTES);  // [2][64] {byte offset (signed), tap number}
+  auto fill_ktab = [&](int kt) {
+    if (tid < 64) {
+      const int khw = a.KH * a.KW, k = kt * BK + tid;
+      const int ci = k / khw, rem = k - ci * khw, ki = rem / a.KW, kj = rem - ki * a.KW;
+      ktab[(kt & 1) * 64 + tid] = make_int2(2 * ((ci * a.H + ki * a.dh) * a.W + kj * a.dw - (a.ph * a.W + a.pw)), rem);
+    }
+  };
   if constexpr (CONV) {
     const int L = a.OH * a.OW;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int m = m0 + ((tid + 256 * j) >> 3);
-      m = m < M ? m : M - 1;
-      const int b = m / L, l = m - b * L, oh = l / a.OW, ow = l - oh * a.OW;
-      cv_base[j] = b * a.cin * a.H * a.W;
-      cv_ih[j] = oh * a.sh - a.ph;
-      cv_iw[j] = ow * a.sw - a.pw;
-    }
+    int m = m0 + (tid & 127);
+    m = m < M ? m : M - 1;
+    const int b = m / L, l = m - b * L, oh = l / a.OW, ow = l - oh * a.OW;
+    const int ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
+    cv_voff = 2u * (uint32_t)(b * a.cin * a.H * a.W + oh * a.sh * a.W + ow * a.sw);
+    for (int ki = 0; ki < a.KH; ++ki)
+      for (int kj = 0; kj < a.KW; ++kj) {
+        const int ih = ih0 + ki * a.dh, iw = iw0 + kj * a.dw;
+        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) cv_mask |= 1ull << (ki * a.KW + kj);
+      }
   }
   auto issue_loads = [&](int kt) {
     const int k0 = kt * BK;
@@ -192,25 +208,19 @@ __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
     for (int j = 0; j < 4; ++j) {
       const int c = tid + 256 * j, row = c >> 3, kc = c & 7;
       if constexpr (CONV) {
-        // eight consecutive k = (ci, i, jj) of one row: one division pair for the first, then counted up
-        const int khw = a.KH * a.KW;
-        int k = k0 + kc * 8;
-        int ci = k / khw, rem = k - ci * khw, ki = rem / a.KW, kj = rem - ki * a.KW;
-        uint16_t e[8];
+        // eight consecutive k of the thread's pixel: table entries by broadcast LDS reads, invalid taps read element 0 and are zeroed
+        const int kcw = __builtin_amdgcn_readfirstlane(tid >> 7) + 2 * j;
+        const int4* tp = reinterpret_cast<const int4*>(ktab + (kt & 1) * 64 + kcw * 8);
+        const int4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+        const int off[8] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z}, tap[8] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w};
+        // the 32 loads of a K-tile are issued back to back and stay in flight during the MFMAs; masking and packing happen in write_lds
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const int ih = cv_ih[j] + ki * a.dh, iw = cv_iw[j] + kj * a.dw;
-          const bool in = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-          e[q] = in ? reinterpret_cast<const uint16_t*>(xg)[cv_base[j] + (ci * a.H + ih) * a.W + iw] : (uint16_t)0;
-          if (++kj == a.KW) {
-            kj = 0;
-            if (++ki == a.KH) {
-              ki = 0;
-              ++ci;
-            }
-          }
+          const uint32_t ok = (uint32_t)((cv_mask >> tap[q]) & 1ull);
+          cv_keep = j == 0 && q == 0 ? ok : cv_keep | (ok << (8 * j + q));
+          const uint32_t voff = (cv_voff + (uint32_t)off[q]) & (0u - ok);
+          cv_raw[j][q] = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(xg) + voff);
         }
-        ra[j] = make_uint4(e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16), e[4] | ((uint32_t)e[5] << 16), e[6] | ((uint32_t)e[7] << 16));
       } else {
         int m = m0 + row;
         m = m < M ? m : M - 1;
@@ -248,7 +258,14 @@ __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
     uint8_t* sb = sa + TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = tid + 256 * j, row = c >> 3, kc = c & 7;
+      const int c = tid + 256 * j;
+      const int row = CONV ? (tid & 127) : c >> 3, kc = CONV ? (tid >> 7) + 2 * j : c & 7;
+      if constexpr (CONV) {
+        uint32_t e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) e[q] = cv_raw[j][q] & (uint32_t)__builtin_amdgcn_sbfe(cv_keep, 8 * j + q, 1);  // zero where the tap hangs over the padding
+        ra[j] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+      }
       *reinterpret_cast<uint4*>(sa + lds_off(row, kc)) = ra[j];
     }
     if constexpr (PACKED4) {
@@ -298,12 +315,20 @@ __global__ void __launch_bounds__(256, 2) qmm_mfma_kernel(const MmaArgs a) {
   }
   const int steps_per_group = (FMT == W_I4) ? a.C / BK : 1;
 
+  if constexpr (CONV) {
+    fill_ktab(0);
+    if (nk > 1) fill_ktab(1);
+    __syncthreads();
+  }
   issue_loads(0);
   write_lds(0);
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) issue_loads(kt + 1);
+    if constexpr (CONV) {  // table of tile kt + 2 into the buffer tile kt's gather (an iteration ago) was the last to read; visible after this iteration's barrier
+      if (kt + 2 < nk) fill_ktab(kt + 2);
+    }
     const uint8_t* sa = smem + cur * 2 * TILE_BYTES;
     const uint8_t* sb = sa + TILE_BYTES;
 #pragma unroll
@@ -430,7 +455,7 @@ int qbits_group_sums(const void* x, float* xs, int M, int K, int C, int Mpad, in
 template <int DT, int FMT, bool INT_SHIFT, bool CONV = false>
 static int mma_launch(const MmaArgs& a, hipStream_t stream) {
   static bool attr_done = false;
-  constexpr int lds = 2 * 2 * TILE_BYTES;
+  constexpr int lds = 2 * 2 * TILE_BYTES + (CONV ? 2 * 64 * 8 : 0);  // + the convolution's two k-tables
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qmm_mfma_kernel<DT, FMT, INT_SHIFT, CONV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -466,13 +491,13 @@ int qbytes_mm_mfma(const void* x, const void* w, const void* s, const void* bias
 }
 
 // Dense convolution with an 8-bit weight as an implicit GEMM (CONV above).  K = cin * KH * KW must be a multiple of 64 (the K-tile); every
-// element offset must fit 31 bits.
+// element offset must fit 31 bits (input: byte offsets), windows of up to 64 taps (one validity bit per tap and pixel).
 bool qbytes_conv2d_supported(int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int a_dtype,
                              int b_dtype, int out_dtype) {
   const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2;
   const int64_t K = cin * KH * KW;
   return bd && a_dtype == out_dtype && (out_dtype == QUANTO_HIP_BF16 || out_dtype == QUANTO_HIP_F16) && B >= 1 && OH >= 1 && OW >= 1 && K % BK == 0 &&
-         B * cin * H * W < (1ll << 31) && B * OC * OH * OW < (1ll << 31) && OC * K < (1ll << 31) && B * OH * OW < (1ll << 30);
+         KH * KW <= 64 && B * cin * H * W < (1ll << 30) && B * OC * OH * OW < (1ll << 31) && OC * K < (1ll << 31) && B * OH * OW < (1ll << 30);
 }
 
 int qbytes_conv2d_mfma(const void* x, const void* w, const void* s, const void* bias, void* y, int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC,
@@ -501,7 +526,7 @@ bool qbits_conv2d_supported(int64_t B, int64_t cin, int64_t H, int64_t W, int64_
                             int dtype) {
   const int64_t K = cin * KH * KW;
   return g.bits == 4 && g.N == OC && g.K == K && OC % 2 == 0 && g.C % 16 == 0 && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && B >= 1 &&
-         OH >= 1 && OW >= 1 && K % BK == 0 && B * cin * H * W < (1ll << 31) && B * OC * OH * OW < (1ll << 31) && OC * K < (1ll << 31) &&
+         OH >= 1 && OW >= 1 && K % BK == 0 && KH * KW <= 64 && B * cin * H * W < (1ll << 30) && B * OC * OH * OW < (1ll << 31) && OC * K < (1ll << 31) &&
          OC * g.G < (1ll << 31) && B * OH * OW < (1ll << 30);
 }
 

@@ -16,7 +16,13 @@ from auto_vs_best import _time_graph  # noqa: E402
 from optimum_quanto_amd.tensor.weights import conv2d_as_gemm  # noqa: E402
 
 WEIGHTS = sys.argv[1] if len(sys.argv) > 1 else "qint8"
-for (B, C, H, OC, k, s, p) in [(8, 256, 56, 256, 3, 1, 1), (8, 128, 56, 128, 3, 1, 1), (32, 512, 14, 512, 3, 1, 1), (8, 64, 112, 128, 3, 2, 1), (8, 512, 28, 128, 1, 1, 0)]:
+SHAPES = [(8, 256, 56, 256, 3, 1, 1), (8, 128, 56, 128, 3, 1, 1), (32, 512, 14, 512, 3, 1, 1), (8, 64, 112, 128, 3, 2, 1), (8, 512, 28, 128, 1, 1, 0)]
+if len(sys.argv) > 2 and sys.argv[2] == "grid":  # the sweep behind the dispatch rule of tensor/weights.py (_implicit_conv2d_wins)
+    SHAPES = [(8, 64, 56, 64, 3, 1, 1), (32, 64, 56, 64, 3, 1, 1), (8, 128, 28, 128, 3, 1, 1), (32, 128, 28, 128, 3, 1, 1), (8, 192, 28, 192, 3, 1, 1),
+              (8, 256, 14, 256, 3, 1, 1), (32, 256, 14, 256, 3, 1, 1), (8, 256, 28, 256, 3, 1, 1), (8, 320, 32, 320, 3, 1, 1), (8, 512, 7, 512, 3, 1, 1),
+              (32, 512, 7, 512, 3, 1, 1), (1, 128, 56, 128, 3, 1, 1), (1, 256, 28, 256, 3, 1, 1), (8, 64, 56, 256, 1, 1, 0), (8, 256, 56, 64, 1, 1, 0),
+              (8, 128, 28, 128, 5, 1, 2), (8, 64, 64, 64, 7, 1, 3), (8, 128, 56, 256, 3, 2, 1)]
+for (B, C, H, OC, k, s, p) in SHAPES:
     torch.manual_seed(0)
     conv = torch.nn.Conv2d(C, OC, k, stride=s, padding=p).to(torch.bfloat16)
     q = Q.QConv2d.from_module(conv, weights=getattr(Q, WEIGHTS))
