@@ -280,7 +280,8 @@ int quanto_hip_pack(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int6
  * is gathered inside the kernel's staging loads, nothing is materialised.
  *   x: dtype[B, cin, H, W] (NCHW, contiguous); w: 8-bit [OC, cin, KH, KW] (I8 / F8_E4M3FN / F8_E5M2); scales: dtype[OC]; bias: dtype[OC] or NULL;
  *   y: dtype[B, OC, OH, OW] with OH = (H + 2 ph - dh (KH - 1) - 1) / sh + 1 (OW alike), passed by the caller.  dtype in {F16, BF16}.
- *   Requires cin * KH * KW to be a multiple of 64; QUANTO_HIP_ENOTSUP otherwise (the caller then lowers the convolution to im2col + qbytes_mm).
+ *   Requires cin * KH * KW to be a multiple of 64 and KH * KW <= 64; QUANTO_HIP_ENOTSUP otherwise (the caller then lowers the convolution to
+ *   im2col + qbytes_mm or keeps the reference's dequantize + float convolution).  Kernel: csrc/qconv_mfma.hip.
  */
 int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, const void* bias, void* y, int64_t B, int64_t cin, int64_t H,
                              int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,
@@ -294,8 +295,8 @@ int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, c
  *   x: dtype[B, cin, H, W]; packed: the generic PackedTensor bytes of the axis-0 quantized weight [OC, cin, KH, KW] viewed as [OC, K = cin KH KW]
  *   (byte (p, k) = q[p, k] | q[p + OC/2, k] << 4); scale / shift: [OC * K / group_size] as for quanto_hip_qbits_mm (group_size 0 = per-channel);
  *   bias: dtype[OC] or NULL; y: dtype[B, OC, OH, OW].  dtype in {F16, BF16}; shift_dtype = dtype or U8 / I8.
- *   Requires bits = 4, OC even, K a multiple of 64 and group_size a multiple of 16; QUANTO_HIP_ENOTSUP otherwise (the caller then lowers the
- *   convolution to im2col + qbits_mm).
+ *   Requires bits = 4, OC even, K a multiple of 64, KH * KW <= 64 and group_size a multiple of 8; QUANTO_HIP_ENOTSUP otherwise (the caller then
+ *   lowers the convolution to im2col + qbits_mm or keeps the reference's dequantize + float convolution).
  */
 int quanto_hip_qbits_conv2d(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t B, int64_t cin,
                             int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,

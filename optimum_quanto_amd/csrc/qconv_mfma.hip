@@ -1,0 +1,365 @@
+// F.conv2d with a quantized weight as an IMPLICIT GEMM (r4): QConv2d.forward (nn/qconv2d.py:54-55) -> F.conv2d on a WeightQBytesTensor /
+// WeightQBitsTensor, where the reference dequantizes the whole weight per call (qfallback) and runs a float convolution.
+//
+//   y[b, n, oh, ow] = scale[n] * sum_{c,i,j} x[b, c, oh*sh - ph + i*dh, ow*sw - pw + j*dw] * w[n, c, i, j]  (+ bias[n])       (8-bit weights)
+//   y = conv(x, dequantize(w)) (+ bias), w dequantized with the reference's roundings (tensor/qbits.py:27-49)                  (int4 weights)
+//
+// GEMM view: M = B*OH*OW output pixels, N = OC, K = cin*KH*KW in the weight's own (c, i, j) order - the axis-0 quantized weight [OC, K] is the
+// operand byte for byte (int4: the generic packed layout, byte (p, k) = q[p, k] | q[p + OC/2, k] << 4, groups along K).  Nothing is
+// materialised: no im2col tensor, no dequantized weight.
+//
+// One workgroup = 128 pixels x 128 channels, EIGHT waves (2 x 4, 64 pixels x 32 channels each), K-tiles of 64, two LDS buffers.  The cost of
+// this kernel is the gather, not the MFMAs, and the gather is instruction issue (a lone wave per SIMD issues a VALU op every ~8 cycles, two
+// waves one every ~4.75 between them: qmm_mfma_large.hip's issue probe), so it is organised around instructions per gathered element:
+//   * a thread stages ONE pixel (tile row tid & 127) and two 8-element chunks of it per K-tile: kc = (tid >> 7) + 4 j.  k is therefore uniform
+//     across a wave and the 64 lanes of a load are 64 neighbouring pixels (one or two cache lines);
+//   * what depends on k only - byte offset of tap (c, i, j) relative to the window's top-left tap, and the tap's number i*KW + j - is computed
+//     once per K-tile by 64 threads into an LDS table (two buffers, rides on the K loop's barrier) and read back by broadcast ds_reads;
+//   * what depends on the pixel only - its base offset and ONE validity bit per tap (64-bit mask: windows of up to 64 taps) - lives in three
+//     registers.  An element costs add + shift + and + and (+ its two-byte load): taps over the padding read element 0 and are zeroed;
+//   * the 16 loads of a K-tile are issued back to back before the MFMAs of the current tile and masked / packed after them.
+// History (profiles/r04_qconv2d_*.jsonl): first form - four pixels per thread, a counted (c, i, j) walk and four compares per element, four waves
+// (inside qmm_mfma.hip) - spent 3.7 us per K-tile whatever M was; the table on four waves 2.0 us; this file's eight waves: see DESIGN.md 8.
+#include "qh_common.h"
+
+namespace qh {
+namespace conv {
+
+constexpr int BM = 128, BN = 128, BK = 64, NT = 512;
+constexpr int TILE_BYTES = BM * BK * 2;  // one operand tile in LDS (16 KiB)
+constexpr int LDS_BYTES = 2 * 2 * TILE_BYTES + 2 * BK * 8;
+
+enum WFmt { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2, W_I4R = 3 };
+
+// 128-byte rows of eight 16-byte chunks; chunk kc of row r sits at position kc ^ (r & 7): the fragment reads (16 rows x 4 chunks) and the staging
+// writes are conflict-free
+__device__ __forceinline__ int lds_off(int row, int kc) { return row * (BK * 2) + ((kc ^ (row & 7)) << 4); }
+
+template <int DT>
+struct Mma;
+template <>
+struct Mma<QUANTO_HIP_BF16> {
+  using V8 = bf16x8;
+  static __device__ __forceinline__ f32x4 run(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Mma<QUANTO_HIP_F16> {
+  using V8 = f16x8;
+  static __device__ __forceinline__ f32x4 run(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+template <int DT>
+__device__ __forceinline__ uint32_t pack_rne(float a, float b) {
+  using E = Elem<DT>;
+  return (uint32_t)__builtin_bit_cast(uint16_t, E::from_f32(a)) | ((uint32_t)__builtin_bit_cast(uint16_t, E::from_f32(b)) << 16);
+}
+
+// 16 one-byte weights -> 16 elements of the activation dtype (every int8 / fp8 value is exact in bf16 and fp16)
+template <int DT, int FMT>
+__device__ __forceinline__ void convert16(const uint4& w, uint4& c0, uint4& c1) {
+  const uint32_t in[4] = {w.x, w.y, w.z, w.w};
+  uint32_t out[8];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    float f0, f1, f2, f3;
+    if constexpr (FMT == W_I8) {
+      f0 = (float)(int8_t)(in[d] & 0xFFu);
+      f1 = (float)(int8_t)((in[d] >> 8) & 0xFFu);
+      f2 = (float)(int8_t)((in[d] >> 16) & 0xFFu);
+      f3 = (float)(int8_t)(in[d] >> 24);
+    } else if constexpr (FMT == W_F8E4M3) {
+      const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)in[d], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)in[d], true);
+      f0 = lo.x; f1 = lo.y; f2 = hi.x; f3 = hi.y;
+    } else {
+      const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_bf8((int)in[d], false), hi = __builtin_amdgcn_cvt_pk_f32_bf8((int)in[d], true);
+      f0 = lo.x; f1 = lo.y; f2 = hi.x; f3 = hi.y;
+    }
+    out[2 * d] = pack_rne<DT>(f0, f1);
+    out[2 * d + 1] = pack_rne<DT>(f2, f3);
+  }
+  c0 = make_uint4(out[0], out[1], out[2], out[3]);
+  c1 = make_uint4(out[4], out[5], out[6], out[7]);
+}
+
+// 8 packed bytes -> 8 low-nibble and 8 high-nibble weights dequantized as the reference does: T(T(s q) - z) for float shifts, T(s (q - zp)) for
+// integer zero-points, round-to-nearest-even - the LDS operand is the dense weight the reference would have materialised
+template <int DT, bool INT_SHIFT>
+__device__ __forceinline__ void convert8_i4r(const uint2& w, float s_lo, float z_lo, float s_hi, float z_hi, uint4& lo, uint4& hi) {
+  using E = Elem<DT>;
+  auto deq = [](uint32_t q, float sc, float z) -> float {
+    if constexpr (INT_SHIFT)
+      return sc * ((float)q - z);
+    else
+      return E::to_f32(E::from_f32(sc * (float)q)) - z;
+  };
+  const uint32_t in[2] = {w.x, w.y};
+  uint32_t l[4], h[4];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const uint32_t two = in[d] >> (16 * b);  // bytes 2b, 2b + 1
+      l[2 * d + b] = pack_rne<DT>(deq(two & 0xFu, s_lo, z_lo), deq((two >> 8) & 0xFu, s_lo, z_lo));
+      h[2 * d + b] = pack_rne<DT>(deq((two >> 4) & 0xFu, s_hi, z_hi), deq((two >> 12) & 0xFu, s_hi, z_hi));
+    }
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+}
+
+struct Args {
+  const void* x;        // [B, cin, H, W] activation dtype
+  const uint8_t* w;     // 8-bit: [OC, K] bytes; int4: packed [OC/2, K] bytes
+  const void* scale;    // 8-bit: [OC]; int4: [OC * G]
+  const void* shift;    // int4 only: [OC * G] (activation dtype, or uint8 / int8 zero-points)
+  const void* bias;     // [OC] or null
+  void* y;              // [B, OC, OH, OW]
+  int M, N, K, C, G;    // M = B OH OW, N = OC, K = cin KH KW; int4: group size C, G = K / C groups per channel
+  int cin, H, W, KH, KW, OH, OW, sh, sw, ph, pw, dh, dw;
+};
+
+template <int DT, int FMT, bool INT_SHIFT>
+__global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
+  constexpr bool PACKED4 = FMT == W_I4R;  // a tile's 128 columns are 64 packed rows x both nibble planes
+  using E = Elem<DT>;
+  using T = typename E::T;
+  using V8 = typename Mma<DT>::V8;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // [2 buffers][A tile | B tile] [2 tap tables]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // 64 pixels x 32 channels per wave
+  const int m0 = blockIdx.y * BM, nt = blockIdx.x;
+  const int M = a.M, N = a.N, K = a.K;
+  const int nk = K / BK;
+  const int P = N >> 1;  // packed rows (int4)
+  const uint8_t* xb = reinterpret_cast<const uint8_t*>(a.x);
+
+  // ---- the thread's pixel ----------------------------------------------------------------------------------------------------------------
+  uint32_t px_off;        // byte offset of input element (b, 0, oh sh, ow sw): the window's top-left tap shifted right / down by the padding
+  uint64_t px_taps = 0;   // bit i KW + j: tap (i, j) of this pixel's window lies inside the image
+  {
+    const int L = a.OH * a.OW;
+    int m = m0 + (tid & 127);
+    m = m < M ? m : M - 1;
+    const int b = m / L, l = m - b * L, oh = l / a.OW, ow = l - oh * a.OW;
+    const int ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
+    px_off = 2u * (uint32_t)(b * a.cin * a.H * a.W + oh * a.sh * a.W + ow * a.sw);
+    for (int ki = 0; ki < a.KH; ++ki)
+      for (int kj = 0; kj < a.KW; ++kj) {
+        const int ih = ih0 + ki * a.dh, iw = iw0 + kj * a.dw;
+        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) px_taps |= 1ull << (ki * a.KW + kj);
+      }
+  }
+  int2* ktab = reinterpret_cast<int2*>(smem + 2 * 2 * TILE_BYTES);  // [2][64] {byte offset relative to px_off (signed), tap number}
+  auto fill_ktab = [&](int kt) {
+    if (tid < BK) {
+      const int khw = a.KH * a.KW, k = kt * BK + tid;
+      const int ci = k / khw, rem = k - ci * khw, ki = rem / a.KW, kj = rem - ki * a.KW;
+      ktab[(kt & 1) * BK + tid] = make_int2(2 * ((ci * a.H + ki * a.dh) * a.W + kj * a.dw - (a.ph * a.W + a.pw)), rem);
+    }
+  };
+
+  // ---- staging registers --------------------------------------------------------------------------------------------------------------------
+  uint32_t g_raw[2][8], g_keep = 0;  // gathered elements of the K-tile in flight (taps over the padding hold x[0]) and their validity bits
+  uint4 rw;                          // 8-bit: 16 weights of row tid >> 2, part tid & 3; int4: 8 packed bytes (rw.x, rw.y) of packed row tid >> 3, part tid & 7
+  float rs[2] = {0.f, 0.f}, rz[2] = {0.f, 0.f};  // int4: scale / shift of the thread's packed row (low and high plane) in the group of its 8 k
+  auto issue_loads = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kc = __builtin_amdgcn_readfirstlane(tid >> 7) + 4 * j;
+      const int4* tp = reinterpret_cast<const int4*>(ktab + (kt & 1) * BK + kc * 8);
+      const int4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+      const int off[8] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z}, tap[8] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t ok = (uint32_t)((px_taps >> tap[q]) & 1ull);
+        g_keep = j == 0 && q == 0 ? ok : g_keep | (ok << (8 * j + q));
+        const uint32_t voff = (px_off + (uint32_t)off[q]) & (0u - ok);
+        g_raw[j][q] = *reinterpret_cast<const uint16_t*>(xb + voff);
+      }
+    }
+    if constexpr (PACKED4) {
+      int p = nt * 64 + (tid >> 3);
+      p = p < P ? p : P - 1;
+      const uint2 v = *reinterpret_cast<const uint2*>(a.w + (size_t)p * K + k0 + (tid & 7) * 8);
+      rw = make_uint4(v.x, v.y, 0u, 0u);
+      const int g = (k0 + (tid & 7) * 8) / a.C;  // the 8 k of a chunk lie in one group (C % 8 == 0)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const size_t idx = (size_t)(pl * P + p) * a.G + g;
+        rs[pl] = E::to_f32(reinterpret_cast<const T*>(a.scale)[idx]);
+        if constexpr (INT_SHIFT)
+          rz[pl] = (float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[idx];
+        else
+          rz[pl] = E::to_f32(reinterpret_cast<const T*>(a.shift)[idx]);
+      }
+    } else {
+      int n = nt * BN + (tid >> 2);
+      n = n < N ? n : N - 1;
+      rw = *reinterpret_cast<const uint4*>(a.w + (size_t)n * K + k0 + (tid & 3) * 16);
+    }
+  };
+  auto write_lds = [&](int buf) {
+    uint8_t* sa = smem + buf * 2 * TILE_BYTES;
+    uint8_t* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      uint32_t e[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) e[q] = g_raw[j][q] & (uint32_t)__builtin_amdgcn_sbfe(g_keep, 8 * j + q, 1);  // zero where the tap hangs over the padding
+      *reinterpret_cast<uint4*>(sa + lds_off(tid & 127, (tid >> 7) + 4 * j)) =
+          make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    }
+    if constexpr (PACKED4) {
+      uint4 lo, hi;
+      convert8_i4r<DT, INT_SHIFT>(make_uint2(rw.x, rw.y), rs[0], rz[0], rs[1], rz[1], lo, hi);
+      const int row = tid >> 3, part = tid & 7;
+      *reinterpret_cast<uint4*>(sb + lds_off(row, part)) = lo;
+      *reinterpret_cast<uint4*>(sb + lds_off(64 + row, part)) = hi;
+    } else {
+      uint4 c0, c1;
+      convert16<DT, FMT>(rw, c0, c1);
+      const int row = tid >> 2, part = tid & 3;
+      *reinterpret_cast<uint4*>(sb + lds_off(row, 2 * part)) = c0;
+      *reinterpret_cast<uint4*>(sb + lds_off(row, 2 * part + 1)) = c1;
+    }
+  };
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  fill_ktab(0);
+  if (nk > 1) fill_ktab(1);
+  __syncthreads();
+  issue_loads(0);
+  write_lds(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) issue_loads(kt + 1);
+    // table of tile kt + 2 into the buffer whose last reader was tile kt's gather (an iteration ago); visible after this iteration's barrier
+    if (kt + 2 < nk) fill_ktab(kt + 2);
+    const uint8_t* sa = smem + cur * 2 * TILE_BYTES;
+    const uint8_t* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      V8 fa[4], fb[2];
+      const int kc = kk * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const V8*>(sa + lds_off(wm * 64 + i * 16 + (lane & 15), kc));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const V8*>(sb + lds_off(wn * 32 + j * 16 + (lane & 15), kc));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mma<DT>::run(fa[i], fb[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) write_lds(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: D row = pixel (lane >> 4) * 4 + r of fragment i, D column = channel lane & 15 of fragment j; NCHW: the lane's four rows are
+  // four neighbouring pixels of one channel plane ------------------------------------------------------------------------------------------------
+  T* yg = reinterpret_cast<T*>(a.y);
+  const int L = a.OH * a.OW;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int tc = wn * 32 + j * 16 + (lane & 15);
+    int n;
+    if constexpr (PACKED4) {
+      const int p = nt * 64 + (tc & 63);
+      n = p < P ? p + (tc >> 6) * P : -1;
+    } else {
+      n = nt * BN + tc;
+      n = n < N ? n : -1;
+    }
+    if (n < 0) continue;
+    float sc = 1.f;
+    if constexpr (!PACKED4) sc = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
+    const bool has_bias = a.bias != nullptr;
+    const float bv = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (m < M) {
+          float v = acc[i][j][r] * sc;
+          asm volatile("" : "+v"(v));  // product rounded to fp32 first, with and without bias (no single-rounding v_fma_mixlo_f16)
+          if (has_bias) v = E::to_f32(E::from_f32(v)) + bv;  // the reference's order: rounded convolution output + bias, rounded again
+          const int b = m / L;
+          yg[((size_t)b * N + n) * L + (m - b * L)] = E::from_f32(v);
+        }
+      }
+    }
+  }
+}
+
+template <int DT, int FMT, bool INT_SHIFT>
+static int launch(const Args& a, hipStream_t stream) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_mfma_kernel<DT, FMT, INT_SHIFT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  const int ntiles = FMT == W_I4R ? (a.N / 2 + 63) / 64 : (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((qconv2d_mfma_kernel<DT, FMT, INT_SHIFT>), dim3(ntiles, (a.M + BM - 1) / BM), dim3(NT), LDS_BYTES, stream, a);
+  return launch_status();
+}
+
+static bool geometry_ok(int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW) {
+  const int64_t K = cin * KH * KW;
+  // K in whole K-tiles; one validity bit per tap; byte offsets into x and element offsets into y / w in 31 bits; grid.y
+  return B >= 1 && OH >= 1 && OW >= 1 && K % BK == 0 && KH * KW <= 64 && B * cin * H * W < (1ll << 30) && B * OC * OH * OW < (1ll << 31) &&
+         OC * K < (1ll << 31) && (B * OH * OW + BM - 1) / BM <= 65535;
+}
+
+}  // namespace conv
+
+bool qbytes_conv2d_supported(int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int a_dtype,
+                             int b_dtype, int out_dtype) {
+  const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2;
+  return bd && a_dtype == out_dtype && (out_dtype == QUANTO_HIP_BF16 || out_dtype == QUANTO_HIP_F16) && conv::geometry_ok(B, cin, H, W, OC, KH, KW, OH, OW);
+}
+
+int qbytes_conv2d_mfma(const void* x, const void* w, const void* s, const void* bias, void* y, int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC,
+                       int64_t KH, int64_t KW, int64_t OH, int64_t OW, int sh, int sw, int ph, int pw, int dh, int dw, int a_dtype, int b_dtype,
+                       int out_dtype, hipStream_t stream) {
+  if (!qbytes_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
+  if (reinterpret_cast<uintptr_t>(w) % 16) return QUANTO_HIP_EALIGN;
+  const conv::Args a{x, reinterpret_cast<const uint8_t*>(w), s, nullptr, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), 0, 0,
+                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw};
+  using namespace conv;
+#define QH_CASE(DT, FMT) return launch<DT, FMT, false>(a, stream)
+  if (out_dtype == QUANTO_HIP_BF16) {
+    if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_BF16, W_I8);
+    if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_BF16, W_F8E4M3);
+    QH_CASE(QUANTO_HIP_BF16, W_F8E5M2);
+  }
+  if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_F16, W_I8);
+  if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_F16, W_F8E4M3);
+  QH_CASE(QUANTO_HIP_F16, W_F8E5M2);
+#undef QH_CASE
+}
+
+// int4: group sizes that are multiples of 8 (a staging chunk of 8 k must not straddle groups) and per-channel scales; OC even
+bool qbits_conv2d_supported(int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, const PackedGeom& g,
+                            int dtype) {
+  return g.bits == 4 && g.N == OC && g.K == cin * KH * KW && OC % 2 == 0 && g.C % 8 == 0 && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) &&
+         OC * g.G < (1ll << 31) && conv::geometry_ok(B, cin, H, W, OC, KH, KW, OH, OW);
+}
+
+int qbits_conv2d_mfma(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t B, int64_t cin,
+                      int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int sh, int sw, int ph, int pw, int dh, int dw,
+                      const PackedGeom& g, int dtype, bool int_shift, hipStream_t stream) {
+  if (!qbits_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, g, dtype)) return QUANTO_HIP_ENOTSUP;
+  if (reinterpret_cast<uintptr_t>(packed) % 8) return QUANTO_HIP_EALIGN;
+  const conv::Args a{x, packed, scale, shift, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), (int)g.C, (int)g.G,
+                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw};
+  using namespace conv;
+  if (dtype == QUANTO_HIP_BF16) return int_shift ? launch<QUANTO_HIP_BF16, W_I4R, true>(a, stream) : launch<QUANTO_HIP_BF16, W_I4R, false>(a, stream);
+  return int_shift ? launch<QUANTO_HIP_F16, W_I4R, true>(a, stream) : launch<QUANTO_HIP_F16, W_I4R, false>(a, stream);
+}
+
+}  // namespace qh

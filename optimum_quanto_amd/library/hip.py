@@ -249,9 +249,10 @@ class _Bindings:
         return (size + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
     def qbytes_conv2d_supported(self, x, w) -> bool:
-        """What the kernel takes: NCHW 16-bit activations, an 8-bit OCP weight, cin * KH * KW a multiple of the K-tile (64)."""
+        """What the kernel takes: NCHW 16-bit activations, an 8-bit OCP weight, cin * KH * KW a multiple of the K-tile (64), windows of up to 64 taps."""
         return (x.is_cuda and x.dim() == 4 and w.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and
-                w.dtype in (torch.int8, torch.float8_e4m3fn, torch.float8_e5m2) and (w.shape[1] * w.shape[2] * w.shape[3]) % 64 == 0)
+                w.dtype in (torch.int8, torch.float8_e4m3fn, torch.float8_e5m2) and (w.shape[1] * w.shape[2] * w.shape[3]) % 64 == 0 and
+                w.shape[2] * w.shape[3] <= 64)
 
     def qbytes_conv2d(self, x, w, scales, bias, stride, padding, dilation):
         """Dense convolution with an 8-bit weight [OC, C, KH, KW] and per-channel scales: im2col happens inside the kernel's staging loads."""
@@ -276,11 +277,11 @@ class _Bindings:
     # -- quanto::qbits_conv2d (implicit GEMM, int4 dequantized while staged) -----------------------------------
     def qbits_conv2d_supported(self, x, weight_size, bits: int, group_size) -> bool:
         """NCHW 16-bit activations, generic packed int4 weight [OC, C, KH, KW] with OC even, C * KH * KW a multiple of 64 and groups of a
-        multiple of 16 (or per-channel scales)."""
+        multiple of 8 (or per-channel scales), windows of up to 64 taps."""
         oc, c, kh, kw = weight_size
         k = c * kh * kw
         return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and bits == 4 and oc % 2 == 0 and k % 64 == 0 and
-                (not group_size or (group_size % 16 == 0 and k % group_size == 0)))
+                kh * kw <= 64 and (not group_size or (group_size % 8 == 0 and k % group_size == 0)))
 
     def qbits_conv2d(self, x, packed, scale, shift, bias, bits: int, group_size, weight_size, stride, padding, dilation):
         """Dense convolution with a generic packed int4 weight (its [OC, C, KH, KW] shape in ``weight_size``): im2col inside the staging loads,
@@ -492,7 +493,7 @@ class QuantoHipExtension(NativeLibrary):
             "quanto_hip",
             root_dir=csrc,
             lib_path=os.path.join(_PKG_DIR, "lib", "libquanto_hip.so"),
-            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qmm_mfma_large.hip", "qmm_mfma_large32.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbits_mfma_large.hip", "qbytes_skinny.hip", "qmm_native8.hip", "quantize.hip",
+            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qconv_mfma.hip", "qmm_mfma_large.hip", "qmm_mfma_large32.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbits_mfma_large.hip", "qbytes_skinny.hip", "qmm_native8.hip", "quantize.hip",
                      "qh_common.h", os.path.join("..", "..", "include", "quanto_hip.h")],
         )
         self._bindings = None
