@@ -285,7 +285,16 @@ int quanto_hip_pack(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int6
  */
 int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, const void* bias, void* y, int64_t B, int64_t cin, int64_t H,
                              int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,
-                             int pad_w, int dil_h, int dil_w, int a_dtype, int b_dtype, int out_dtype, void* stream);
+                             int pad_w, int dil_h, int dil_w, int a_dtype, int b_dtype, int out_dtype, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+/*
+ * Scratch bytes the convolution kernels want for their K split (0: the problem is not split): when the 128 x 128 output tiles alone cannot
+ * occupy the chip the K-tiles are dealt over up to 64 workgroups per tile, whose fp32 sums a second kernel adds in split order (deterministic,
+ * no atomics, nothing to zero).  K = cin * KH * KW.  Both quanto_hip_q*_conv2d entries take the buffer (16-byte aligned); with NULL / too few
+ * bytes they run unsplit.  -1 on invalid arguments.
+ */
+int64_t quanto_hip_conv2d_workspace_size(int64_t B, int64_t OH, int64_t OW, int64_t OC, int64_t K);
 
 /*
  * F.conv2d with an int4 weight - what QConv2d.forward (nn/qconv2d.py:54-55) reaches through WeightQBitsTensor's dispatch (qfallback: dequantize
@@ -300,7 +309,8 @@ int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, c
  */
 int quanto_hip_qbits_conv2d(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t B, int64_t cin,
                             int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,
-                            int pad_w, int dil_h, int dil_w, int bits, int group_size, int dtype, int shift_dtype, void* stream);
+                            int pad_w, int dil_h, int dil_w, int bits, int group_size, int dtype, int shift_dtype, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -32,9 +32,10 @@ int quantize_affine_packed(const void*, const void*, const void*, void*, int64_t
 int pack_weights(const uint8_t*, uint8_t*, int64_t, int64_t, int, hipStream_t);
 bool qbits_conv2d_supported(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, const PackedGeom&, int);
 int qbits_conv2d_mfma(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
-                      int64_t, int64_t, int, int, int, int, int, int, const PackedGeom&, int, bool, hipStream_t);
+                      int64_t, int64_t, int, int, int, int, int, int, const PackedGeom&, int, bool, void*, size_t, hipStream_t);
+size_t conv2d_workspace(int64_t, int64_t, int64_t);
 int qbytes_conv2d_mfma(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
-                       int64_t, int, int, int, int, int, int, int, int, int, hipStream_t);
+                       int64_t, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t);
 int qbytes_mm_gemv_multi(const void*, int, const void* const*, const void* const*, const void* const*, void* const*, const int64_t*, int64_t,
                          int64_t, int, int, hipStream_t);
 bool qbytes_skinny_multi_supported(int, const int64_t*, int64_t, int64_t, int, int, int);
@@ -597,9 +598,16 @@ int quanto_hip_pack(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int6
   return pack_weights(unpacked, packed, rows, cols, bits, reinterpret_cast<hipStream_t>(stream));
 }
 
+int64_t quanto_hip_conv2d_workspace_size(int64_t B, int64_t OH, int64_t OW, int64_t OC, int64_t K) {
+  if (B < 0 || OH < 0 || OW < 0 || OC <= 0 || K <= 0) return -1;
+  if (B == 0 || OH == 0 || OW == 0 || K % 64) return 0;
+  return (int64_t)conv2d_workspace(B * OH * OW, OC, K);
+}
+
 int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, const void* bias, void* y, int64_t B, int64_t cin, int64_t H,
                              int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,
-                             int pad_w, int dil_h, int dil_w, int a_dtype, int b_dtype, int out_dtype, void* stream) {
+                             int pad_w, int dil_h, int dil_w, int a_dtype, int b_dtype, int out_dtype, void* workspace, size_t workspace_bytes,
+                             void* stream) {
   if (B < 0 || cin <= 0 || H <= 0 || W <= 0 || OC <= 0 || KH <= 0 || KW <= 0 || OH < 0 || OW < 0) return QUANTO_HIP_EINVAL;
   if (stride_h <= 0 || stride_w <= 0 || pad_h < 0 || pad_w < 0 || dil_h <= 0 || dil_w <= 0) return QUANTO_HIP_EINVAL;
   if (OH != (H + 2 * pad_h - dil_h * (KH - 1) - 1) / stride_h + 1 || OW != (W + 2 * pad_w - dil_w * (KW - 1) - 1) / stride_w + 1) return QUANTO_HIP_EINVAL;
@@ -607,14 +615,15 @@ int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, c
   if (B == 0 || OH == 0 || OW == 0) return QUANTO_HIP_OK;
   if (!x || !w || !scales || !y) return QUANTO_HIP_EINVAL;
   const int r = qbytes_conv2d_mfma(x, w, scales, bias, y, B, cin, H, W, OC, KH, KW, OH, OW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, a_dtype,
-                                   b_dtype, out_dtype, reinterpret_cast<hipStream_t>(stream));
+                                   b_dtype, out_dtype, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
   if (r == QUANTO_HIP_OK) set_last_kernel("conv2d_mfma");
   return r;
 }
 
 int quanto_hip_qbits_conv2d(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t B, int64_t cin,
                             int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,
-                            int pad_w, int dil_h, int dil_w, int bits, int group_size, int dtype, int shift_dtype, void* stream) {
+                            int pad_w, int dil_h, int dil_w, int bits, int group_size, int dtype, int shift_dtype, void* workspace,
+                            size_t workspace_bytes, void* stream) {
   if (B < 0 || cin <= 0 || H <= 0 || W <= 0 || OC <= 0 || KH <= 0 || KW <= 0 || OH < 0 || OW < 0) return QUANTO_HIP_EINVAL;
   if (stride_h <= 0 || stride_w <= 0 || pad_h < 0 || pad_w < 0 || dil_h <= 0 || dil_w <= 0) return QUANTO_HIP_EINVAL;
   if (OH != (H + 2 * pad_h - dil_h * (KH - 1) - 1) / stride_h + 1 || OW != (W + 2 * pad_w - dil_w * (KW - 1) - 1) / stride_w + 1) return QUANTO_HIP_EINVAL;
@@ -626,7 +635,7 @@ int quanto_hip_qbits_conv2d(const void* x, const uint8_t* packed, const void* sc
   if (!x || !packed || !scale || !shift || !y) return QUANTO_HIP_EINVAL;
   const PackedGeom g = make_geom(OC, K, bits, group_size);
   const int r = qbits_conv2d_mfma(x, packed, scale, shift, bias, y, B, cin, H, W, OC, KH, KW, OH, OW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, g, dtype,
-                                  int_shift, reinterpret_cast<hipStream_t>(stream));
+                                  int_shift, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
   if (r == QUANTO_HIP_OK) set_last_kernel("conv2d_mfma_int4");
   return r;
 }

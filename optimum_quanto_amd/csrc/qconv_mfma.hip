@@ -115,7 +115,52 @@ struct Args {
   void* y;              // [B, OC, OH, OW]
   int M, N, K, C, G;    // M = B OH OW, N = OC, K = cin KH KW; int4: group size C, G = K / C groups per channel
   int cin, H, W, KH, KW, OH, OW, sh, sw, ph, pw, dh, dw;
+  // K split over blockIdx.z (S > 1): split z multiplies K-tiles [z nk / S, (z + 1) nk / S) and parks its fp32 sums in `partials`
+  // ([S][tiles][8 waves][8 fragments][64 lanes] float4: whole lines per store); qconv2d_reduce_kernel adds them in split order and runs the epilogue
+  int S;
+  float* partials;
 };
+
+// the lane's 4 x 2 accumulator fragments -> output: D row = pixel (lane >> 4) * 4 + r of fragment i, D column = channel lane & 15 of fragment j; NCHW:
+// the lane's four rows are four neighbouring pixels of one channel plane
+template <int DT, bool PACKED4>
+__device__ __forceinline__ void store_tile(const Args& a, const f32x4 (&acc)[4][2], int m0, int nt, int wm, int wn, int lane) {
+  using E = Elem<DT>;
+  using T = typename E::T;
+  T* yg = reinterpret_cast<T*>(a.y);
+  const int M = a.M, N = a.N, P = N >> 1, L = a.OH * a.OW;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int tc = wn * 32 + j * 16 + (lane & 15);
+    int n;
+    if constexpr (PACKED4) {
+      const int p = nt * 64 + (tc & 63);
+      n = p < P ? p + (tc >> 6) * P : -1;
+    } else {
+      n = nt * BN + tc;
+      n = n < N ? n : -1;
+    }
+    if (n < 0) continue;
+    float sc = 1.f;
+    if constexpr (!PACKED4) sc = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
+    const bool has_bias = a.bias != nullptr;
+    const float bv = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (m < M) {
+          float v = acc[i][j][r] * sc;
+          asm volatile("" : "+v"(v));  // product rounded to fp32 first, with and without bias (no single-rounding v_fma_mixlo_f16)
+          if (has_bias) v = E::to_f32(E::from_f32(v)) + bv;  // the reference's order: rounded convolution output + bias, rounded again
+          const int b = m / L;
+          yg[((size_t)b * N + n) * L + (m - b * L)] = E::from_f32(v);
+        }
+      }
+    }
+  }
+}
 
 template <int DT, int FMT, bool INT_SHIFT>
 __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
@@ -130,7 +175,8 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
   const int wm = wave >> 2, wn = wave & 3;  // 64 pixels x 32 channels per wave
   const int m0 = blockIdx.y * BM, nt = blockIdx.x;
   const int M = a.M, N = a.N, K = a.K;
-  const int nk = K / BK;
+  const int S = a.S, sp = blockIdx.z;
+  const int kt_lo = (int)((long)sp * (K / BK) / S), nk = (int)((long)(sp + 1) * (K / BK) / S) - kt_lo;  // this split's K-tiles: kt_lo + t, t = 0 .. nk - 1
   const int P = N >> 1;  // packed rows (int4)
   const uint8_t* xb = reinterpret_cast<const uint8_t*>(a.x);
 
@@ -151,11 +197,11 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
       }
   }
   int2* ktab = reinterpret_cast<int2*>(smem + 2 * 2 * TILE_BYTES);  // [2][64] {byte offset relative to px_off (signed), tap number}
-  auto fill_ktab = [&](int kt) {
+  auto fill_ktab = [&](int t) {
     if (tid < BK) {
-      const int khw = a.KH * a.KW, k = kt * BK + tid;
+      const int khw = a.KH * a.KW, k = (kt_lo + t) * BK + tid;
       const int ci = k / khw, rem = k - ci * khw, ki = rem / a.KW, kj = rem - ki * a.KW;
-      ktab[(kt & 1) * BK + tid] = make_int2(2 * ((ci * a.H + ki * a.dh) * a.W + kj * a.dw - (a.ph * a.W + a.pw)), rem);
+      ktab[(t & 1) * BK + tid] = make_int2(2 * ((ci * a.H + ki * a.dh) * a.W + kj * a.dw - (a.ph * a.W + a.pw)), rem);
     }
   };
 
@@ -163,12 +209,12 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
   uint32_t g_raw[2][8], g_keep = 0;  // gathered elements of the K-tile in flight (taps over the padding hold x[0]) and their validity bits
   uint4 rw;                          // 8-bit: 16 weights of row tid >> 2, part tid & 3; int4: 8 packed bytes (rw.x, rw.y) of packed row tid >> 3, part tid & 7
   float rs[2] = {0.f, 0.f}, rz[2] = {0.f, 0.f};  // int4: scale / shift of the thread's packed row (low and high plane) in the group of its 8 k
-  auto issue_loads = [&](int kt) {
-    const int k0 = kt * BK;
+  auto issue_loads = [&](int t) {
+    const int k0 = (kt_lo + t) * BK;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int kc = __builtin_amdgcn_readfirstlane(tid >> 7) + 4 * j;
-      const int4* tp = reinterpret_cast<const int4*>(ktab + (kt & 1) * BK + kc * 8);
+      const int4* tp = reinterpret_cast<const int4*>(ktab + (t & 1) * BK + kc * 8);
       const int4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
       const int off[8] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z}, tap[8] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w};
 #pragma unroll
@@ -263,48 +309,73 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
     cur ^= 1;
   }
 
-  // ---- epilogue: D row = pixel (lane >> 4) * 4 + r of fragment i, D column = channel lane & 15 of fragment j; NCHW: the lane's four rows are
-  // four neighbouring pixels of one channel plane ------------------------------------------------------------------------------------------------
-  T* yg = reinterpret_cast<T*>(a.y);
-  const int L = a.OH * a.OW;
+  if (S > 1) {  // park the partial sums: one 1 KiB store per wave and fragment
+    f32x4* mine = reinterpret_cast<f32x4*>(a.partials) + ((size_t)(sp * gridDim.y + blockIdx.y) * gridDim.x + nt) * (8 * 8 * 64) + (wave * 8) * 64 + lane;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int tc = wn * 32 + j * 16 + (lane & 15);
-    int n;
-    if constexpr (PACKED4) {
-      const int p = nt * 64 + (tc & 63);
-      n = p < P ? p + (tc >> 6) * P : -1;
-    } else {
-      n = nt * BN + tc;
-      n = n < N ? n : -1;
-    }
-    if (n < 0) continue;
-    float sc = 1.f;
-    if constexpr (!PACKED4) sc = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
-    const bool has_bias = a.bias != nullptr;
-    const float bv = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        if (m < M) {
-          float v = acc[i][j][r] * sc;
-          asm volatile("" : "+v"(v));  // product rounded to fp32 first, with and without bias (no single-rounding v_fma_mixlo_f16)
-          if (has_bias) v = E::to_f32(E::from_f32(v)) + bv;  // the reference's order: rounded convolution output + bias, rounded again
-          const int b = m / L;
-          yg[((size_t)b * N + n) * L + (m - b * L)] = E::from_f32(v);
-        }
-      }
-    }
+      for (int j = 0; j < 2; ++j) mine[(i * 2 + j) * 64] = acc[i][j];
+    return;
   }
+  store_tile<DT, PACKED4>(a, acc, m0, nt, wm, wn, lane);
 }
 
+// split-K tail: one WAVE per (output tile, wave slot of the tile kernel) adds that slot's eight fragments over the S partial tiles in split order
+// (deterministic), four splits' loads in flight together, and runs the epilogue.  (First form: one 512-thread workgroup per tile with one split per
+// loop iteration - 14 workgroups each waiting 12 times for a round trip cost more than the convolution itself.)
+template <int DT, bool PACKED4>
+__global__ void __launch_bounds__(64) qconv2d_reduce_kernel(const Args a) {
+  const int lane = threadIdx.x, wave = blockIdx.z, S = a.S;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4* base = reinterpret_cast<const f32x4*>(a.partials) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (8 * 8 * 64) + (wave * 8) * 64 + lane;
+  const size_t split_stride = (size_t)gridDim.y * gridDim.x * (8 * 8 * 64);
+  for (int sp0 = 0; sp0 < S; sp0 += 4) {
+    f32x4 v[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int sp = sp0 + u < S ? sp0 + u : S - 1;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) v[u][f] = base[sp * split_stride + f * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (sp0 + u < S) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[f >> 1][f & 1][r] += v[u][f][r];
+      }
+  }
+  store_tile<DT, PACKED4>(a, acc, blockIdx.y * BM, blockIdx.x, wave >> 2, wave & 3, lane);
+}
+
+// K split: the tile kernel is bound by its gather per K-tile (~1.9 us per workgroup and K-tile whatever M is), so what matters is how many
+// workgroups run at once: split until the grid reaches ~2 workgroups per CU, keeping at least 3 K-tiles per split.  1 = no split (and no workspace).
+static int pick_split(int64_t M, int64_t N, int64_t K) {
+  const int forced = env_int("QUANTO_HIP_CONV_SPLIT", 0);  // experiments
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nk = K / BK;
+  if (forced > 0) return (int)(forced <= nk ? forced : nk);
+  if (tiles > 128) return 1;  // measured: at 196 tiles a split of 2 costs more in partial sums than the second workgroup per CU brings
+  int s = 1;
+  while (tiles * (s + 1) <= 512 && nk / (s + 1) >= 3 && s < 64) ++s;
+  return s;
+}
+static size_t split_workspace(int64_t M, int64_t N, int S) { return S <= 1 ? 0 : (size_t)S * ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (BM * BN * 4); }
+
 template <int DT, int FMT, bool INT_SHIFT>
-static int launch(const Args& a, hipStream_t stream) {
+static int launch(Args a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_mfma_kernel<DT, FMT, INT_SHIFT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  const int ntiles = FMT == W_I4R ? (a.N / 2 + 63) / 64 : (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((qconv2d_mfma_kernel<DT, FMT, INT_SHIFT>), dim3(ntiles, (a.M + BM - 1) / BM), dim3(NT), LDS_BYTES, stream, a);
+  const int ntiles = FMT == W_I4R ? (a.N / 2 + 63) / 64 : (a.N + BN - 1) / BN, mtiles = (a.M + BM - 1) / BM;
+  int S = pick_split(a.M, a.N, a.K);
+  if (S > 1 && (!workspace || workspace_bytes < split_workspace(a.M, a.N, S) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
+  a.S = S;
+  a.partials = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL((qconv2d_mfma_kernel<DT, FMT, INT_SHIFT>), dim3(ntiles, mtiles, S), dim3(NT), LDS_BYTES, stream, a);
+  if (S > 1) hipLaunchKernelGGL((qconv2d_reduce_kernel<DT, FMT == W_I4R>), dim3(ntiles, mtiles, 8), dim3(64), 0, stream, a);
   return launch_status();
 }
 
@@ -312,7 +383,7 @@ static bool geometry_ok(int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC
   const int64_t K = cin * KH * KW;
   // K in whole K-tiles; one validity bit per tap; byte offsets into x and element offsets into y / w in 31 bits; grid.y
   return B >= 1 && OH >= 1 && OW >= 1 && K % BK == 0 && KH * KW <= 64 && B * cin * H * W < (1ll << 30) && B * OC * OH * OW < (1ll << 31) &&
-         OC * K < (1ll << 31) && (B * OH * OW + BM - 1) / BM <= 65535;
+         OC * K < (1ll << 31) && (B * OH * OW + BM - 1) / BM <= 65535;  // (the K split is at most 64: grid.z)
 }
 
 }  // namespace conv
@@ -323,15 +394,18 @@ bool qbytes_conv2d_supported(int64_t B, int64_t cin, int64_t H, int64_t W, int64
   return bd && a_dtype == out_dtype && (out_dtype == QUANTO_HIP_BF16 || out_dtype == QUANTO_HIP_F16) && conv::geometry_ok(B, cin, H, W, OC, KH, KW, OH, OW);
 }
 
+// scratch bytes the K split of a convolution wants (0: not split); the same for every weight format (128 x 128 tiles either way)
+size_t conv2d_workspace(int64_t M, int64_t N, int64_t K) { return conv::split_workspace(M, N, conv::pick_split(M, N, K)); }
+
 int qbytes_conv2d_mfma(const void* x, const void* w, const void* s, const void* bias, void* y, int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC,
                        int64_t KH, int64_t KW, int64_t OH, int64_t OW, int sh, int sw, int ph, int pw, int dh, int dw, int a_dtype, int b_dtype,
-                       int out_dtype, hipStream_t stream) {
+                       int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbytes_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
   if (reinterpret_cast<uintptr_t>(w) % 16) return QUANTO_HIP_EALIGN;
   const conv::Args a{x, reinterpret_cast<const uint8_t*>(w), s, nullptr, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), 0, 0,
-                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw};
+                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr};
   using namespace conv;
-#define QH_CASE(DT, FMT) return launch<DT, FMT, false>(a, stream)
+#define QH_CASE(DT, FMT) return launch<DT, FMT, false>(a, workspace, workspace_bytes, stream)
   if (out_dtype == QUANTO_HIP_BF16) {
     if (b_dtype == QUANTO_HIP_I8) QH_CASE(QUANTO_HIP_BF16, W_I8);
     if (b_dtype == QUANTO_HIP_F8_E4M3FN) QH_CASE(QUANTO_HIP_BF16, W_F8E4M3);
@@ -352,14 +426,17 @@ bool qbits_conv2d_supported(int64_t B, int64_t cin, int64_t H, int64_t W, int64_
 
 int qbits_conv2d_mfma(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t B, int64_t cin,
                       int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int sh, int sw, int ph, int pw, int dh, int dw,
-                      const PackedGeom& g, int dtype, bool int_shift, hipStream_t stream) {
+                      const PackedGeom& g, int dtype, bool int_shift, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbits_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, g, dtype)) return QUANTO_HIP_ENOTSUP;
   if (reinterpret_cast<uintptr_t>(packed) % 8) return QUANTO_HIP_EALIGN;
   const conv::Args a{x, packed, scale, shift, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), (int)g.C, (int)g.G,
-                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw};
+                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr};
   using namespace conv;
-  if (dtype == QUANTO_HIP_BF16) return int_shift ? launch<QUANTO_HIP_BF16, W_I4R, true>(a, stream) : launch<QUANTO_HIP_BF16, W_I4R, false>(a, stream);
-  return int_shift ? launch<QUANTO_HIP_F16, W_I4R, true>(a, stream) : launch<QUANTO_HIP_F16, W_I4R, false>(a, stream);
+  if (dtype == QUANTO_HIP_BF16)
+    return int_shift ? launch<QUANTO_HIP_BF16, W_I4R, true>(a, workspace, workspace_bytes, stream)
+                     : launch<QUANTO_HIP_BF16, W_I4R, false>(a, workspace, workspace_bytes, stream);
+  return int_shift ? launch<QUANTO_HIP_F16, W_I4R, true>(a, workspace, workspace_bytes, stream)
+                   : launch<QUANTO_HIP_F16, W_I4R, false>(a, workspace, workspace_bytes, stream);
 }
 
 }  // namespace qh

@@ -107,9 +107,11 @@ class _Bindings:
         c.quanto_hip_pack.restype = ci
         c.quanto_hip_pack.argtypes = [vp, vp, i64, i64, ci, vp]
         c.quanto_hip_qbytes_conv2d.restype = ci
-        c.quanto_hip_qbytes_conv2d.argtypes = [vp, vp, vp, vp, vp] + [i64] * 9 + [ci] * 9 + [vp]
+        c.quanto_hip_qbytes_conv2d.argtypes = [vp, vp, vp, vp, vp] + [i64] * 9 + [ci] * 9 + [vp, ctypes.c_size_t, vp]
+        c.quanto_hip_conv2d_workspace_size.restype = i64
+        c.quanto_hip_conv2d_workspace_size.argtypes = [i64] * 5
         c.quanto_hip_qbits_conv2d.restype = ci
-        c.quanto_hip_qbits_conv2d.argtypes = [vp] * 6 + [i64] * 9 + [ci] * 10 + [vp]
+        c.quanto_hip_qbits_conv2d.argtypes = [vp] * 6 + [i64] * 9 + [ci] * 10 + [vp, ctypes.c_size_t, vp]
         self._c = c
         if c.quanto_hip_abi_version() != 1:
             raise QuantoHipError("libquanto_hip.so ABI version mismatch: rebuild with __graft_entry__.build()")
@@ -248,6 +250,13 @@ class _Bindings:
     def conv2d_out_size(size, k, stride, pad, dil):
         return (size + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
+    def _conv2d_scratch(self, x, B, OH, OW, OC, K):
+        """(buffer, bytes) for the convolution kernels' K split - plain scratch, nothing to zero; (None, 0) when the problem is not split."""
+        nbytes = int(self._c.quanto_hip_conv2d_workspace_size(B, max(OH, 0), max(OW, 0), OC, K))
+        if nbytes <= 0:
+            return None, 0
+        return self._scratch(x.device, nbytes, self._stream(x).value), nbytes
+
     def qbytes_conv2d_supported(self, x, w) -> bool:
         """What the kernel takes: NCHW 16-bit activations, an 8-bit OCP weight, cin * KH * KW a multiple of the K-tile (64), windows of up to 64 taps."""
         return (x.is_cuda and x.dim() == 4 and w.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and
@@ -269,8 +278,10 @@ class _Bindings:
             bias = bias.to(x.dtype).contiguous()
         y = torch.empty((B, OC, max(OH, 0), max(OW, 0)), dtype=x.dtype, device=x.device)
         with torch.cuda.device(x.device):
+            ws, ws_bytes = self._conv2d_scratch(x, B, OH, OW, OC, C * KH * KW)
             st = self._c.quanto_hip_qbytes_conv2d(_ptr(x), _ptr(w), _ptr(s), _ptr(bias), _ptr(y), B, C, H, W, OC, KH, KW, OH, OW, stride[0], stride[1],
-                                                  padding[0], padding[1], dilation[0], dilation[1], _dt(x), _dt(w), _dt(y), self._stream(x))
+                                                  padding[0], padding[1], dilation[0], dilation[1], _dt(x), _dt(w), _dt(y), _ptr(ws), ws_bytes,
+                                                  self._stream(x))
         self._check(st, "qbytes_conv2d")
         return y
 
@@ -298,9 +309,10 @@ class _Bindings:
             bias = bias.to(x.dtype).contiguous()
         y = torch.empty((B, OC, max(OH, 0), max(OW, 0)), dtype=x.dtype, device=x.device)
         with torch.cuda.device(x.device):
+            ws, ws_bytes = self._conv2d_scratch(x, B, OH, OW, OC, C * KH * KW)
             st = self._c.quanto_hip_qbits_conv2d(_ptr(x), _ptr(packed), _ptr(scale), _ptr(shift), _ptr(bias), _ptr(y), B, C, H, W, OC, KH, KW, OH, OW,
                                                  stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], bits, group_size or 0, _dt(x),
-                                                 _dt(shift), self._stream(x))
+                                                 _dt(shift), _ptr(ws), ws_bytes, self._stream(x))
         self._check(st, "qbits_conv2d")
         return y
 

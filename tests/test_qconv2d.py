@@ -207,6 +207,41 @@ def test_qconv2d_int4_implicit_gemm_gpu(dt, zp, cin, cout, k, s, p, d, gs):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wq", ["qint8", "qint4"])
+@pytest.mark.parametrize("split", [1, 2, 7])
+def test_qconv2d_implicit_gemm_k_split_gpu(monkeypatch, wq, split):
+    """The convolution kernel's K split (blockIdx.z + a reduce kernel that adds the fp32 partial tiles in split order): forced to 1 (no
+    workspace use), 2 and 7 (ragged: 18 K-tiles), every result against the float64 gate; and a call WITHOUT a workspace runs unsplit."""
+    monkeypatch.setenv("QUANTO_HIP_CONV_SPLIT", str(split))
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(128, 200, 3, padding=1).to(torch.bfloat16)
+    q = Q.QConv2d.from_module(conv, weights=getattr(Q, wq))
+    Q.freeze(q)
+    q = q.cuda()
+    x = torch.randn(2, 128, 17, 9).to(torch.bfloat16)
+    with torch.no_grad():
+        y = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == ("conv2d_mfma" if wq == "qint8" else "conv2d_mfma_int4")
+        if wq == "qint8":  # exact integers, the per-channel scale on the accumulator
+            prod = torch.nn.functional.conv2d(x.double(), q.weight._data.cpu().double(), None, 1, 1) * q.weight._scale.cpu().double().reshape(1, -1, 1, 1)
+        else:              # the weight the reference dequantizes
+            prod = torch.nn.functional.conv2d(x.double(), q.weight.dequantize().cpu().double(), None, 1, 1)
+    bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
+    assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), "bf16", f"conv K split {split} {wq}")
+    if split == 7 and wq == "qint8":  # the C entry without a workspace: same problem, unsplit, same gate
+        lib = quanto_hip.lib
+        w = q.weight
+        yy = torch.empty_like(y)
+        s = w._scale.reshape(-1).to(torch.bfloat16).contiguous()
+        xc = x.cuda()
+        st = lib._c.quanto_hip_qbytes_conv2d(xc.data_ptr(), w._data.data_ptr(), s.data_ptr(), q.bias.data_ptr(), yy.data_ptr(), 2, 128, 17, 9, 200, 3, 3, 17, 9,
+                                             1, 1, 1, 1, 1, 1, 2, 3, 2, None, 0, None)
+        torch.cuda.synchronize()
+        assert st == 0
+        assert_close_with_bias(to_numpy(yy), prod.numpy(), np.broadcast_to(bias, prod.shape), "bf16", "conv without a workspace")
+
+
+@pytest.mark.gpu
 def test_qconv2d_grouped_convolution_keeps_reference_behaviour_gpu():
     """groups != 1 is not lowered to a GEMM: dequantize + float convolution on the device, as the reference does."""
     torch.manual_seed(9)
