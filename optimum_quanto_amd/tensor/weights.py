@@ -45,8 +45,8 @@ def conv2d_patches(input, kernel_size, stride, padding, dilation):
 
 def _implicit_conv2d(input, weight, scale, bias, stride, padding, dilation, groups):
     """``quanto::qbytes_conv2d`` - the convolution as an implicit GEMM, im2col inside the kernel's staging loads (r4) - when the call is
-    eligible: dense (groups = 1), batched NCHW 16-bit input on a ROCm device, int8 / OCP fp8 weight, C*kh*kw a multiple of 64, no gradient
-    wanted.  None otherwise: the caller then lowers to a materialised im2col + GEMM (conv2d_as_gemm) or keeps the reference behaviour."""
+    eligible: dense (groups = 1), batched NCHW 16-bit input on a ROCm device, int8 / OCP fp8 weight, C*kh*kw a multiple of 64, windows of up
+    to 64 taps, no gradient wanted.  None otherwise: the caller then lowers to a materialised im2col + GEMM (conv2d_as_gemm) or keeps the reference behaviour."""
     from ..library.hip import quanto_hip
 
     if groups != 1 or isinstance(padding, str) or type(input) is not torch.Tensor or input.dim() != 4 or input.device.type != "cuda":
@@ -56,8 +56,10 @@ def _implicit_conv2d(input, weight, scale, bias, stride, padding, dilation, grou
     if weight.dim() != 4 or input.shape[1] != weight.shape[1] or not quanto_hip.lib.qbytes_conv2d_supported(input, weight._data):
         return None
     pair = lambda v: [v, v] if isinstance(v, int) else list(v)  # noqa: E731
-    if tuple(weight.shape[2:]) == (1, 1) and pair(stride) == [1, 1] and pair(padding) == [0, 0]:
-        return None  # pointwise: the "patches" are a permuted view of the input, one copy + the tuned GEMM kernels is faster (29 vs 38 us)
+    if tuple(weight.shape[2:]) == (1, 1) and pair(stride) == [1, 1] and pair(padding) == [0, 0] and weight.shape[1] < 128:
+        # pointwise with ONE K-tile: the "patches" are a permuted view of the input, one copy + the tuned GEMM kernels is ahead ((8,64,56,56) -> 256:
+        # 21.5 vs 25.0 us); from two K-tiles on the convolution kernel is ((8,256,56,56) -> 64: 14.9 vs 37.6, (8,512,28,28) -> 128: 19.4 vs 29.2)
+        return None
     return torch.ops.quanto.qbytes_conv2d(input, weight._data, scale, bias, pair(stride), pair(padding), pair(dilation))
 
 
@@ -76,8 +78,8 @@ def _implicit_conv2d_qbits(input, weight, bias, stride, padding, dilation, group
     if not quanto_hip.lib.qbits_conv2d_supported(input, tuple(weight.shape), packed.bits, weight._group_size):
         return None
     pair = lambda v: [v, v] if isinstance(v, int) else list(v)  # noqa: E731
-    if tuple(weight.shape[2:]) == (1, 1) and pair(stride) == [1, 1] and pair(padding) == [0, 0]:
-        return None  # pointwise: a permuted view of the input + the tuned GEMM kernels
+    if tuple(weight.shape[2:]) == (1, 1) and pair(stride) == [1, 1] and pair(padding) == [0, 0] and weight.shape[1] < 128:
+        return None  # pointwise with one K-tile: a permuted view of the input + the tuned GEMM kernels (see _implicit_conv2d)
     return torch.ops.quanto.qbits_conv2d(input, packed._data, weight._scale, weight._shift, bias, packed.bits, weight._group_size,
                                          list(weight.shape), pair(stride), pair(padding), pair(dilation))
 

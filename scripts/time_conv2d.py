@@ -21,7 +21,8 @@ if len(sys.argv) > 2 and sys.argv[2] == "grid":  # the sweep behind the dispatch
     SHAPES = [(8, 64, 56, 64, 3, 1, 1), (32, 64, 56, 64, 3, 1, 1), (8, 128, 28, 128, 3, 1, 1), (32, 128, 28, 128, 3, 1, 1), (8, 192, 28, 192, 3, 1, 1),
               (8, 256, 14, 256, 3, 1, 1), (32, 256, 14, 256, 3, 1, 1), (8, 256, 28, 256, 3, 1, 1), (8, 320, 32, 320, 3, 1, 1), (8, 512, 7, 512, 3, 1, 1),
               (32, 512, 7, 512, 3, 1, 1), (1, 128, 56, 128, 3, 1, 1), (1, 256, 28, 256, 3, 1, 1), (8, 64, 56, 256, 1, 1, 0), (8, 256, 56, 64, 1, 1, 0),
-              (8, 128, 28, 128, 5, 1, 2), (8, 64, 64, 64, 7, 1, 3), (8, 128, 56, 256, 3, 2, 1)]
+              (8, 128, 28, 128, 5, 1, 2), (8, 64, 64, 64, 7, 1, 3), (8, 128, 56, 256, 3, 2, 1), (8, 512, 28, 128, 1, 1, 0), (8, 256, 14, 1024, 1, 1, 0),
+              (8, 1024, 14, 256, 1, 1, 0), (1, 512, 28, 128, 1, 1, 0)]
 for (B, C, H, OC, k, s, p) in SHAPES:
     torch.manual_seed(0)
     conv = torch.nn.Conv2d(C, OC, k, stride=s, padding=p).to(torch.bfloat16)
@@ -37,12 +38,17 @@ for (B, C, H, OC, k, s, p) in SHAPES:
     else:
         gemm = lambda a: torch.ops.quanto.qbits_mm(a, w._data._data, w._scale, w._shift, q.bias, 4, w._group_size, OC, C * k * k)  # noqa: E731
     wdq = w.dequantize()
+    if WEIGHTS == "qint8":  # the convolution kernel called directly (the module routes pointwise convolutions to permute + GEMM)
+        direct = lambda: torch.ops.quanto.qbytes_conv2d(x, w._data, w._scale, q.bias, [s, s], [p, p], [1, 1])  # noqa: E731
+    else:
+        direct = lambda: torch.ops.quanto.qbits_conv2d(x, w._data._data, w._scale, w._shift, q.bias, 4, w._group_size, list(w.shape), [s, s], [p, p], [1, 1])  # noqa: E731
     with torch.no_grad():
+        t_dir = _time_graph(direct, 5) if (C * k * k) % 64 == 0 else None
         t_imp = _time_graph(lambda: q(x), 5)
         t_unf = _time_graph(lambda: conv2d_as_gemm(x, w, q.bias, (s, s), (p, p), (1, 1), 1, gemm), 5)
         t_ref = _time_graph(lambda: torch.nn.functional.conv2d(x, w.dequantize(), q.bias, s, p), 5)
         t_dense = _time_graph(lambda: torch.nn.functional.conv2d(x, wdq, q.bias, s, p), 5)
     OHW = (H + 2 * p - k) // s + 1
-    print(json.dumps({"weights": WEIGHTS, "group_size": getattr(w, "_group_size", None), "B": B, "C": C, "H": H, "OC": OC, "k": k, "stride": s, "M": B * OHW * OHW, "K": C * k * k, "implicit_gemm_us": round(t_imp, 1),
+    print(json.dumps({"weights": WEIGHTS, "group_size": getattr(w, "_group_size", None), "B": B, "C": C, "H": H, "OC": OC, "k": k, "stride": s, "M": B * OHW * OHW, "K": C * k * k, "implicit_gemm_us": round(t_imp, 1), "conv_kernel_direct_us": None if t_dir is None else round(t_dir, 1),
                       "unfold_plus_gemm_us": round(t_unf, 1), "reference_dequantize_plus_conv_us": round(t_ref, 1), "float_conv_only_us": round(t_dense, 1),
                       "im2col_bytes_not_written": B * OHW * OHW * C * k * k * 2}), flush=True)
