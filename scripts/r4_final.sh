@@ -21,5 +21,5 @@ done
 echo "== kernel stats: group-size-96 streaming kernel and the int4 implicit-GEMM convolution"
 D=$OUT/prof_r04_new; rm -rf $D
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o new -- python $REPO/scripts/profile_new_kernels.py > $D.log 2>&1)
-f=$(find $D -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "^\"Name|qbits_skinny_kernel|qmm_mfma_kernel" "$f" | cut -c1-300 > $OUT/r04_group96_and_int4_conv_kernel_stats.csv; cut -c1-200 $OUT/r04_group96_and_int4_conv_kernel_stats.csv
+f=$(find $D -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "^\"Name|qbits_skinny_kernel|qconv2d_" "$f" | cut -c1-300 > $OUT/r04_group96_and_int4_conv_kernel_stats.csv; cut -c1-200 $OUT/r04_group96_and_int4_conv_kernel_stats.csv
 rm -rf $OUT/prof_r04_* $OUT/g4
