@@ -578,6 +578,43 @@ def run_layer_decode(name, args, device, rank, world, dist, steps):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
+# QConv2d.forward as an implicit GEMM (csrc/qconv_mfma.hip) beside the reference's behaviour on the same device
+# ------------------------------------------------------------------------------------------------------------------------
+QCONV = {"B": 8, "C": 128, "H": 28, "W": 28, "OC": 128, "k": 3, "stride": 1, "pad": 1}
+
+
+def run_qconv2d(args, device, steps=50):
+    """One ResNet-style 3x3 layer, bf16 activations: ``QConv2d`` with qint8 and qint4 weights through this library (quanto::qbytes_conv2d /
+    quanto::qbits_conv2d: im2col gathered inside the kernel, K split + deterministic reduce) and what the reference computes for the same
+    module on a ROCm device (nn/qconv2d.py:54-55 -> qfallback: dequantize the weight, aten convolution = MIOpen).  hipGraph-timed like every
+    other record; the weight is small (147 KB / 74 KB), so nothing is rotated."""
+    import optimum_quanto_amd as Q
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    c = QCONV
+    torch.manual_seed(0)
+    x = torch.randn(c["B"], c["C"], c["H"], c["W"], device=device).to(torch.bfloat16)
+    OH = (c["H"] + 2 * c["pad"] - c["k"]) // c["stride"] + 1
+    M, K, N = c["B"] * OH * OH, c["C"] * c["k"] * c["k"], c["OC"]
+    out = {"name": "qconv2d_3x3", "shape": f"({c['B']},{c['C']},{c['H']},{c['W']})->{c['OC']} 3x3 pad 1", "M": M, "K": K, "N": N,
+           "alg_flops": 2 * M * K * N, "bound": "gather issue (128 two-byte load instructions per 128x64 tile), not mfma / hbm", "steps": steps}
+    with torch.no_grad():
+        for wq in ("qint8", "qint4"):
+            conv = torch.nn.Conv2d(c["C"], c["OC"], c["k"], stride=c["stride"], padding=c["pad"]).to(torch.bfloat16)
+            q = Q.QConv2d.from_module(conv, weights=getattr(Q, wq))
+            Q.freeze(q)
+            q = q.to(device)
+            w, bias = q.weight, q.bias
+            el, _ = timed_replay(lambda: q(x), steps, args, None, device, warmup=3)
+            out[f"{wq[1:]}_us"] = round(el * 1e6 / steps, 2)
+            out[f"{wq[1:]}_kernel"] = quanto_hip.lib.last_kernel()
+            el, _ = timed_replay(lambda: torch.nn.functional.conv2d(x, w.dequantize(), bias, c["stride"], c["pad"]), steps, args, None, device, warmup=3)
+            out[f"ref_rocm_{wq[1:]}_us"] = round(el * 1e6 / steps, 2)
+    out["ref_rocm"] = "the reference's QConv2d.forward on this device: dequantize the weight + aten convolution (MIOpen)"
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[4]: Llama-3-8B random-init, weights=qint4 with lm_head excluded, end-to-end tokens/s at batch 1 and 32
 # ------------------------------------------------------------------------------------------------------------------------
 def run_cfg5(args, device, batches=(1, 32), prompt=512, new=512):
@@ -892,6 +929,11 @@ def main():
                 apply_profile(sr, prof.get(sr["name"]), compacted=True)
             out["profile_passes"] = {"ok": bool(prof), "seconds": round(time.perf_counter() - t_prof, 1),
                                      "what": "rocprofv3 --kernel-trace, --pmc FETCH_SIZE, --pmc WRITE_SIZE child runs of this file"}
+        if world == 1 and rank == 0 and default_run and out is not None:
+            try:
+                sub_results.append(run_qconv2d(args, device))
+            except Exception as e:
+                sub_results.append({"name": "qconv2d_3x3", "error": repr(e)[:200]})
         if world == 1 and rank == 0 and default_run and not args.no_cfg5 and out is not None:
             try:
                 sub_results.append(run_cfg5(args, device))
