@@ -162,7 +162,7 @@ def qbytes_conv2d_hip(input, weight, scales, bias, stride, padding, dilation):
     return quanto_hip.lib.qbytes_conv2d(input, weight, scales, bias, tuple(stride), tuple(padding), tuple(dilation))
 
 
-# new op: dense convolution with an int8 / fp8 weight as an implicit GEMM on the device (csrc/qmm_mfma.hip, CONV): no im2col tensor
+# new op: dense convolution with an int8 / fp8 weight as an implicit GEMM on the device (csrc/qconv_mfma.hip): no im2col tensor
 if _define("qbytes_conv2d", "(Tensor input, Tensor weight, Tensor scales, Tensor? bias, int[] stride, int[] padding, int[] dilation) -> Tensor"):
     _impl("qbytes_conv2d", "CompositeExplicitAutograd", qbytes_conv2d_default, True)
     _impl("qbytes_conv2d", "CUDA", qbytes_conv2d_hip, True)
@@ -307,7 +307,7 @@ def qbits_conv2d_hip(input, packed, scale, shift, bias, bits: int, group_size: O
                                        tuple(dilation))
 
 
-# new op: dense convolution with a packed int4 weight as an implicit GEMM on the device (csrc/qmm_mfma.hip, CONV + W_I4R): no im2col tensor,
+# new op: dense convolution with a packed int4 weight as an implicit GEMM on the device (csrc/qconv_mfma.hip, W_I4R staging): no im2col tensor,
 # no dequantized weight in memory
 if _define("qbits_conv2d",
            "(Tensor input, Tensor packed, Tensor scale, Tensor shift, Tensor? bias, int bits, int? group_size, int[] weight_size, "
