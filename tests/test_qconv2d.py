@@ -95,6 +95,26 @@ def test_qconv2d_quantize_freeze_state_dict_roundtrip():
     torch.testing.assert_close(fresh(x), y, rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("wq,gs,zp", [("qint8", None, False), ("qint4", 96, False), ("qint4", 64, True), ("qint4", None, False)])
+def test_conv2d_ops_default_implementations_are_the_reference_behaviour(wq, gs, zp):
+    """quanto::qbytes_conv2d / quanto::qbits_conv2d off the device (CompositeExplicitAutograd): dequantize the weight, float convolution -
+    bit for bit what the reference's QConv2d.forward computes through qfallback (nn/qconv2d.py:54-55)."""
+    torch.manual_seed(11)
+    conv = torch.nn.Conv2d(64, 96, 3, stride=2, padding=1).to(torch.bfloat16)
+    x = torch.randn(2, 64, 9, 7).to(torch.bfloat16)
+    if wq == "qint8":
+        q = Q.QConv2d.from_module(conv, weights=Q.qint8)
+        Q.freeze(q)
+        w = q.weight
+        y = torch.ops.quanto.qbytes_conv2d(x, w._data, w._scale, conv.bias, [2, 2], [1, 1], [1, 1])
+    else:
+        scale, shift = Q.MaxOptimizer()(conv.weight.detach(), Q.qint4, 0, gs, zeropoint=zp)
+        w = Q.quantize_weight(conv.weight.detach(), Q.qint4, 0, scale, shift, group_size=gs, optimized=False)
+        y = torch.ops.quanto.qbits_conv2d(x, w._data._data, w._scale, w._shift, conv.bias, 4, gs, list(w.shape), [2, 2], [1, 1], [1, 1])
+    want = torch.nn.functional.conv2d(x, w.dequantize(), conv.bias, 2, 1)
+    assert y.dtype == torch.bfloat16 and torch.equal(y, want)
+
+
 # ------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,cname,dt", CASES)
