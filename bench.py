@@ -597,7 +597,7 @@ def run_qconv2d(args, device, steps=50):
     OH = (c["H"] + 2 * c["pad"] - c["k"]) // c["stride"] + 1
     M, K, N = c["B"] * OH * OH, c["C"] * c["k"] * c["k"], c["OC"]
     out = {"name": "qconv2d_3x3", "shape": f"({c['B']},{c['C']},{c['H']},{c['W']})->{c['OC']} 3x3 pad 1", "M": M, "K": K, "N": N,
-           "alg_flops": 2 * M * K * N, "bound": "gather issue (128 two-byte load instructions per 128x64 tile), not mfma / hbm", "steps": steps}
+           "alg_flops": 2 * M * K * N, "bound": "gather issue (DESIGN 8)", "steps": steps}
     with torch.no_grad():
         for wq in ("qint8", "qint4"):
             conv = torch.nn.Conv2d(c["C"], c["OC"], c["k"], stride=c["stride"], padding=c["pad"]).to(torch.bfloat16)
@@ -610,7 +610,7 @@ def run_qconv2d(args, device, steps=50):
             out[f"{wq[1:]}_kernel"] = quanto_hip.lib.last_kernel()
             el, _ = timed_replay(lambda: torch.nn.functional.conv2d(x, w.dequantize(), bias, c["stride"], c["pad"]), steps, args, None, device, warmup=3)
             out[f"ref_rocm_{wq[1:]}_us"] = round(el * 1e6 / steps, 2)
-    out["ref_rocm"] = "the reference's QConv2d.forward on this device: dequantize the weight + aten convolution (MIOpen)"
+    out["ref_rocm"] = "reference behaviour on the device: dequantize + MIOpen convolution"
     return out
 
 
