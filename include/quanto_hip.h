@@ -282,6 +282,7 @@ int quanto_hip_pack(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int6
  *   y: dtype[B, OC, OH, OW] with OH = (H + 2 ph - dh (KH - 1) - 1) / sh + 1 (OW alike), passed by the caller.  dtype in {F16, BF16}.
  *   Requires cin * KH * KW to be a multiple of 64 and KH * KW <= 64; QUANTO_HIP_ENOTSUP otherwise (the caller then lowers the convolution to
  *   im2col + qbytes_mm or keeps the reference's dequantize + float convolution).  Kernel: csrc/qconv_mfma.hip.
+ *   workspace / workspace_bytes: optional scratch for the K split, see quanto_hip_conv2d_workspace_size below (NULL, 0: unsplit).
  */
 int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, const void* bias, void* y, int64_t B, int64_t cin, int64_t H,
                              int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,
@@ -300,7 +301,8 @@ int64_t quanto_hip_conv2d_workspace_size(int64_t B, int64_t OH, int64_t OW, int6
  * F.conv2d with an int4 weight - what QConv2d.forward (nn/qconv2d.py:54-55) reaches through WeightQBitsTensor's dispatch (qfallback: dequantize
  * the whole weight, float convolution).  The same implicit GEMM as quanto_hip_qbytes_conv2d; the packed bytes are dequantized while they are
  * staged, with the reference's own roundings (tensor/qbits.py:27-49: T(T(scale q) - shift) for float shifts, T(scale (q - zero_point)) for
- * integer zero-points), so the matrix cores multiply by exactly the dense weight the reference would have materialised.  No workspace.
+ * integer zero-points), so the matrix cores multiply by exactly the dense weight the reference would have materialised.  No dense weight and no
+ * im2col tensor in memory; `workspace` (optional) is the K split's scratch of quanto_hip_conv2d_workspace_size.
  *   x: dtype[B, cin, H, W]; packed: the generic PackedTensor bytes of the axis-0 quantized weight [OC, cin, KH, KW] viewed as [OC, K = cin KH KW]
  *   (byte (p, k) = q[p, k] | q[p + OC/2, k] << 4); scale / shift: [OC * K / group_size] as for quanto_hip_qbits_mm (group_size 0 = per-channel);
  *   bias: dtype[OC] or NULL; y: dtype[B, OC, OH, OW].  dtype in {F16, BF16}; shift_dtype = dtype or U8 / I8.
