@@ -360,8 +360,9 @@ static int pick_split(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nk = K / BK;
   if (forced > 0) return (int)(forced <= nk ? forced : nk);
   // measured (profiles/r04_qconv2d_forced_split.jsonl): at 196 tiles a split of 2 costs more in partial sums than the second workgroup per CU
-  // brings (23.9 -> 31.9, 43.0 -> 44.7 us; only 192 tiles x 45 K-tiles gains: 81.6 -> 72.9)
-  if (tiles > 128) return 1;
+  // brings while K is short (9 K-tiles 23.9 -> 31.9 us, 18 K-tiles 43.0 -> 44.7) and pays from ~32 K-tiles on (192 tiles x 45: 81.6 -> 72.9,
+  // 256 tiles x 49: 86.8 -> 84.3)
+  if (tiles > 128) return tiles <= 256 && nk >= 32 ? 2 : 1;
   int s = 1;
   while (tiles * (s + 1) <= 512 && nk / (s + 1) >= 3 && s < 64) ++s;
   return s;

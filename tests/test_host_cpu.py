@@ -147,6 +147,8 @@ def test_conv2d_k_split_plan_without_a_gpu():
     assert f(1, 28, 28, 256, 2304) == 12 * (7 * 2) * tile      # 14 tiles, 36 K-tiles
     assert f(8, 28, 28, 256, 2304) == 5 * (49 * 2) * tile      # 98 tiles: 5 splits keep the grid under 512 workgroups
     assert f(8, 56, 56, 64, 576) == 0 and f(32, 56, 56, 64, 576) == 0   # 196 / 784 tiles: not split
+    assert f(8, 32, 32, 320, 2880) == 2 * (64 * 3) * tile      # 129 .. 256 tiles: two splits once K is at least 32 K-tiles deep (45 here)
+    assert f(32, 28, 28, 128, 1152) == 0                       # 196 tiles, 18 K-tiles: not split
     assert f(8, 56, 56, 256, 64) == 0                          # one K-tile
     assert f(8, 28, 28, 128, 1100) == 0 and f(0, 28, 28, 128, 1152) == 0   # K not in whole K-tiles (the kernel rejects it anyway); empty batch
     assert f(-1, 28, 28, 128, 1152) == -1 and f(8, 28, 28, 0, 1152) == -1
