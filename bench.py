@@ -87,6 +87,8 @@ WORKLOADS = {
     # SURVEY.md 8f rank 1 (quantized activations) and the int4 prefill / batched-decode shapes of the same layer size
     "w8a8": ("qbytes_i8i8", 4096, 4096, 4096, "int8 x int8 qbytes_mm (quantized activations), int32 accumulate, (M,K,N)=(4096,4096,4096)"),
     "fp8a8": ("qbytes_f8f8", 4096, 4096, 4096, "fp8-e4m3fn x fp8-e4m3fn qbytes_mm (quantized activations), (M,K,N)=(4096,4096,4096)"),
+    "cfg4_fp8a8": ("qbytes_f8f8", 512, 8192, 8192, "fp8-e4m3fn x fp8-e4m3fn qbytes_mm on the native fp8 MFMA (BASELINE configs[3] with quantized activations), (M,K,N)=(512,8192,8192)"),
+    "cfg4_w8a8": ("qbytes_i8i8", 512, 8192, 8192, "int8 x int8 qbytes_mm (quantized activations), (M,K,N)=(512,8192,8192)"),
     "int4_prefill": ("qbits_i4", 4096, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, prefill (M,K,N)=(4096,4096,4096)"),
     "int4_prefill512": ("qbits_i4", 512, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, (M,K,N)=(512,4096,4096)"),
     "int8_8k": ("qbytes_i8", 8192, 8192, 8192, "bf16 x int8 qbytes_mm, per-channel scale, (M,K,N)=(8192,8192,8192)"),

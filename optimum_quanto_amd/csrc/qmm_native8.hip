@@ -62,6 +62,83 @@ struct Args {
   int M, N, K;
 };
 
+// ---- epilogue: (int32 | fp32) accumulator * scale[n] (+ bias), parked per wave in LDS, stored as full 128-byte lines ----
+// (shared by the 64-byte-row and the 128-byte-row kernels; every wave must be done with the operand stages: the barrier below)
+template <int ODT, int KIND, int NJ, int BM, int BN>
+__device__ __forceinline__ void epilogue(const Args& a, typename Acc<KIND>::V (&acc)[NJ][8], uint8_t* smem, int m0, int n0, int wm, int wn, int wave,
+                                         int lane) {
+  using E = Elem<ODT>;
+  using T = typename E::T;
+  const int M = a.M, N = a.N;
+  T* yg = reinterpret_cast<T*>(a.y);
+  const bool has_bias = a.bias != nullptr;
+  const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (N % 8 == 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  constexpr int FP = NJ * 16 < 128 / (int)sizeof(T) ? NJ * 16 : 128 / (int)sizeof(T);  // features per pass (rows of <= 128 bytes)
+  constexpr int JP = FP / 16, PASSES = NJ / JP;  // feature fragments per pass
+  constexpr int ROWB = FP * (int)sizeof(T), LPR = ROWB / 16;  // bytes per parked row, lanes per row on the read side
+  uint8_t* park = smem + wave * (128 * ROWB);     // <= 16 KiB per wave
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+#pragma unroll
+    for (int jj = 0; jj < JP; ++jj) {
+      const int j = p * JP + jj;
+      const int nb = n0 + wn * (NJ * 16) + j * 16 + (lane >> 4) * 4;
+      float sc[4], bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nb + r < N ? nb + r : N - 1;
+        sc[r] = a.scale ? E::to_f32(reinterpret_cast<const T*>(a.scale)[n]) : 1.f;
+        bv[r] = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        T out[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = (float)acc[j][i][r] * sc[r];  // library/qbytes_mm.py:47-49: fp32(int32) * fp32(scale), rounded to fp32 ...
+          asm volatile("" : "+v"(v));             // ... and only then to the output dtype (no single-rounding v_fma_mixlo_f16)
+          if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[r];
+          out[r] = E::from_f32(v);
+        }
+        const int row = i * 16 + (lane & 15);
+        if constexpr (sizeof(T) == 2) {
+          const int chunk = (jj * 4 + (lane >> 4)) ^ ((row & (LPR - 1)) << 1);  // 8-byte chunks
+          *reinterpret_cast<uint2*>(park + row * ROWB + chunk * 8) = *reinterpret_cast<const uint2*>(out);
+        } else {
+          const int chunk = (jj * 4 + (lane >> 4)) ^ (row & (LPR - 1));  // 16-byte chunks
+          *reinterpret_cast<uint4*>(park + row * ROWB + chunk * 16) = *reinterpret_cast<const uint4*>(out);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 2 * LPR; ++t) {
+      const int row = t * (64 / LPR) + lane / LPR;
+      const int c16 = lane % LPR;
+      uint4 v;
+      if constexpr (sizeof(T) == 2)
+        v = *reinterpret_cast<const uint4*>(park + row * ROWB + (((c16 * 2) ^ ((row & (LPR - 1)) << 1)) * 8));
+      else
+        v = *reinterpret_cast<const uint4*>(park + row * ROWB + ((c16 ^ (row & (LPR - 1))) * 16));
+      const int m = m0 + wm * 128 + row;
+      const int n = n0 + wn * (NJ * 16) + p * FP + c16 * (16 / (int)sizeof(T));
+      if (full) {
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // non-temporal: see qmm_mfma_large.hip
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + (size_t)m * N + n));
+      } else if (m < M) {
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int r = 0; r < 16 / (int)sizeof(T); ++r)
+          if (n + r < N) yg[(size_t)m * N + n + r] = e[r];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 // PAIRED (fp8 kinds, K % 128 == 0): K-tiles are consumed two at a time by the K = 128 MX-format MFMA (unit scales), which runs
 // at twice the rate of the 16x16x32 fp8 MFMA - see the paired loop below.
 // SMALL: 128x128 tile with four waves of 128 x 32 (16 KiB stages: two workgroups share a CU) for shapes whose 256-tiles cannot
@@ -331,74 +408,250 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
 
   }
 
-  // ---- epilogue: (int32 | fp32) accumulator * scale[n] (+ bias), parked per wave in LDS, stored as full 128-byte lines ----
-  T* yg = reinterpret_cast<T*>(a.y);
-  const bool has_bias = a.bias != nullptr;
-  const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (N % 8 == 0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  epilogue<ODT, KIND, NJ, BM, BN>(a, acc, smem, m0, n0, wm, wn, wave, lane);
+}
+
+// =============================================================================================================================
+// 128-byte rows (r5).  The kernel above stages 64 bytes per row and K-tile: every 128-byte line of an operand row is fetched by
+// two instructions a K-tile apart, i.e. as two half-line vector-L1 fills (16.7 M requests per dense bf16 4096^3 launch against
+// the vendor kernel's 8.4 M full-line ones, profiles/r04_l1_fill_counters_vendor_vs_library.json).  Here a DMA piece is 8 rows x
+// 128 bytes - eight adjacent lanes fetch one whole line - and the LDS holds TWO buffers of 128-byte rows (a "pair" of the 64-byte
+// k-steps the MFMA stream still works in):
+//   * image: [row][128 B], lane l of a piece = (row l >> 3, slot l & 7); the lane fetches chunk slot ^ h(row), h = (row >> 1) & 7, and a
+//     fragment lane reads chunk c = 4 * half + (lane >> 4) at slot c ^ h(row) - conflict-free for the ds_read_b128 lane groups of
+//     gfx950 and byte-exact, both checked on the CPU by scripts/models/row128_lds_model.py;
+//   * int8 / 16-bit stream: the k-step pipeline of the kernel above (all twelve fragments of k-step s+1 fetched during k-step s, in
+//     place), with the buffer bookkeeping per pair: even step = second half of the current buffer, odd step = first half of the
+//     other buffer + the 8 DMA pieces of pair p+2 into the buffer that was just read out.  ONE barrier per pair (before the odd
+//     step: it publishes pair p+1 and retires the reads of pair p), half as many as before;
+//   * fp8: one v_mfma_scale_f32_16x16x128_f8f6f4 per fragment pair and 128-byte tile, as in the paired loop above.
+// Needs K * element size % 128 == 0; everything else stays on the 64-byte-row kernel (QUANTO_HIP_NATIVE8_ROW128=0 forces that one).
+// =============================================================================================================================
+__device__ __forceinline__ int swz128(int row) { return (row >> 1) & 7; }
+
+template <int ODT, int KIND, bool SMALL = false>
+__global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kernel(const Args a) {
+  using AV = typename Acc<KIND>::V;
+  constexpr bool MX = KIND == K_F8E4M3 || KIND == K_F8E5M2;
+  constexpr int BM = SMALL ? 128 : 256, BN = BM;
+  constexpr int NWAVES = SMALL ? 4 : 8;
+  constexpr int NJ = SMALL ? 2 : 4;
+  constexpr int RB = 128;                                   // bytes per row and pair
+  // LDS: [activations buffer 0 | activations buffer 1 | weights buffer 0 | weights buffer 1], 32 KiB each (16 KiB for the 128-tile): both
+  // buffers of an operand are within the 16-bit offset field of ds_read from ONE base register
+  constexpr int OP_BYTES = BM * RB, W_BASE = 2 * OP_BYTES;
+  constexpr int PPW = BM / 8 / NWAVES;                      // pieces per wave, operand and pair: 4 in both layouts
+  static_assert(PPW == 4, "piece bookkeeping below assumes four pieces per wave and operand");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = SMALL ? 0 : wave >> 2, wn = wave & 3;
+  constexpr int ES = (KIND == K_BF16 || KIND == K_F16) ? 2 : 1;
+  const int M = a.M, N = a.N, K = a.K;
+  const int np = K * ES / RB;  // pairs (128-byte K-tiles)
+
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int nwg = tiles_n * tiles_m;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- DMA: 4 + 4 pieces of 1 KiB per wave and pair; piece j of an operand covers tile rows (j * NWAVES + wave) * 8 .. + 7 ----
+  uint32_t asrc[PPW], wsrc[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int R = (j * NWAVES + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz128(R);
+    int m = m0 + R, n = n0 + R;
+    m = m < M ? m : M - 1;
+    n = n < N ? n : N - 1;
+    asrc[j] = (uint32_t)((size_t)m * K * ES + c * 16);
+    wsrc[j] = (uint32_t)((size_t)n * K * ES + c * 16);
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+  uint32_t mdst[2][2 * PPW];  // DMA destinations per buffer: loop constants, kept in SGPRs
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int q = 0; q < 2 * PPW; ++q)
+      mdst[b][q] = __builtin_amdgcn_readfirstlane(lds_base + (q < PPW ? 0 : W_BASE) + b * OP_BYTES + ((q % PPW) * NWAVES + wave) * 1024);
+  auto issue_piece = [&](int p, const uint32_t (&dst)[2 * PPW], int q) {  // piece q of pair p: q < 4 activations, else weights
+    if (q < PPW)
+      glds16(a.a + (size_t)p * RB, asrc[q], dst[q]);
+    else
+      glds16(a.w + (size_t)p * RB, wsrc[q - PPW], dst[q]);
+  };
+
+  // ---- fragment reads: one ds_read_b128 per 16-row fragment and k-step; chunk 4 * half + (lane >> 4) of the lane's row ----
+  const int ra = wm * 128 + (lane & 15), rw = wn * (NJ * 16) + (lane & 15);
+  const int aoff = ra * RB + ((((lane >> 4) ^ swz128(ra)) & 7) << 4);            // half 0; half 1 = ^ 64
+  const int boff = W_BASE + rw * RB + ((((lane >> 4) ^ swz128(rw)) & 7) << 4);
+  constexpr int FR = 16 * RB;  // bytes between consecutive 16-row fragments
+
+  AV acc[NJ][8];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = AV{0, 0, 0, 0};
+
+  // prologue (both loops): pairs 0 and 1 in flight, pair 0 visible
+#pragma unroll
+  for (int q = 0; q < 2 * PPW; ++q) issue_piece(0, mdst[0], q);
+  if (np > 1) {
+#pragma unroll
+    for (int q = 0; q < 2 * PPW; ++q) issue_piece(1, mdst[1], q);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  constexpr int FP = NJ * 16 < 128 / (int)sizeof(T) ? NJ * 16 : 128 / (int)sizeof(T);  // features per pass (rows of <= 128 bytes)
-  constexpr int JP = FP / 16, PASSES = NJ / JP;  // feature fragments per pass
-  constexpr int ROWB = FP * (int)sizeof(T), LPR = ROWB / 16;  // bytes per parked row, lanes per row on the read side
-  uint8_t* park = smem + wave * (128 * ROWB);     // <= 16 KiB per wave
+
+  if constexpr (MX) {
+    // ---- fp8 x fp8: an operand is the lane's 16 bytes of the first half followed by its 16 bytes of the second half of the row ----
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    constexpr int FMTSEL = KIND == K_F8E5M2 ? 1 : 0;  // cbsz / blgp: 0 = fp8 (e4m3), 1 = bf8 (e5m2)
+    i32x8 X[8], W[NJ];
+    auto load_pair = [&](i32x8& dst, const uint8_t* buf, int off) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(buf + off), hi = *reinterpret_cast<const uint4*>(buf + (off ^ 64));
+      dst = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    };
+    auto mma128 = [&](AV& c, const i32x8& w, const i32x8& x) {
+      c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, x, c, FMTSEL, FMTSEL, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);  // scales 2^0
+    };
 #pragma unroll
-  for (int p = 0; p < PASSES; ++p) {
+    for (int j = 0; j < NJ; ++j) load_pair(W[j], smem, boff + j * FR);
 #pragma unroll
-    for (int jj = 0; jj < JP; ++jj) {
-      const int j = p * JP + jj;
-      const int nb = n0 + wn * (NJ * 16) + j * 16 + (lane >> 4) * 4;
-      float sc[4], bv[4];
+    for (int i = 0; i < 4; ++i) load_pair(X[i], smem, aoff + i * FR);
+    for (int p = 0; p < np; ++p) {
+      const uint8_t* cur = smem + (p & 1) * OP_BYTES;
+      const uint8_t* nxt = smem + ((p + 1) & 1) * OP_BYTES;
+      // ---- half A: token fragments 0..3, while X[4..7] of this pair are fetched ----
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = nb + r < N ? nb + r : N - 1;
-        sc[r] = a.scale ? E::to_f32(reinterpret_cast<const T*>(a.scale)[n]) : 1.f;
-        bv[r] = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          mma128(acc[j][i], W[j], X[i]);
+          if (j == 1) load_pair(X[4 + i], cur, aoff + (4 + i) * FR);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (p + 1 < np) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own share of pair p+1 (issued one pair ago; nothing younger in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // X[4..7] returned: this wave is done reading the current buffer
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (p + 2 < np) {
+        if (p & 1) {
+#pragma unroll
+          for (int q = 0; q < 2 * PPW; ++q) issue_piece(p + 2, mdst[1], q);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 2 * PPW; ++q) issue_piece(p + 2, mdst[0], q);
+        }
+      }
+      // ---- half B: weight-fragment-major over token fragments 4..7; X[0..3] and each W[j] refetched for pair p+1 ----
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int i = 4; i < 8; ++i) {
+          mma128(acc[j][i], W[j], X[i]);
+          if (i - 4 < 4 / NJ) load_pair(X[j * (4 / NJ) + (i - 4)], nxt, aoff + (j * (4 / NJ) + (i - 4)) * FR);
+          if (i == 7) load_pair(W[j], nxt, boff + j * FR);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  } else {
+    // ---- int8 / 16-bit: k-steps of 64 bytes; xf is refilled in place, the weight fragments ping-pong between two register sets ----
+    uint4 xf[8], wq[2][NJ];
+    auto rd = [&](const uint8_t* p) -> uint4 { return *reinterpret_cast<const uint4*>(p); };
+    auto mma = [&](AV& c, const uint4& w, const uint4& x) {
+      if constexpr (KIND == K_I8) {
+        c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, w), __builtin_bit_cast(i32x4, x), c, 0, 0, 0);
+      } else if constexpr (KIND == K_BF16) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+      } else {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
+      }
+    };
+    // fragment bases per half: loop constants in registers (the 16-bit offset field of ds_read carries buffer and fragment index)
+    const uint8_t* xh[2] = {smem + aoff, smem + (aoff ^ 64)};
+    const uint8_t* wh[2] = {smem + boff, smem + (boff ^ 64)};
+    auto xp = [&](int b, int h) -> const uint8_t* { return xh[h] + b * OP_BYTES; };
+    auto wp = [&](int b, int h) -> const uint8_t* { return wh[h] + b * OP_BYTES; };
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) wq[0][j] = rd(wp(0, 0) + j * FR);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xf[i] = rd(xp(0, 0) + i * FR);
+
+    // pair p, resident in buffer B: [even step: k-step 2p, prefetching k-step 2p+1 from the same buffer] -> own DMA share of pair p+1
+    // landed, own reads of buffer B returned -> barrier -> [odd step: k-step 2p+1, prefetching k-step 2p+2 from the other buffer and
+    // refilling buffer B with pair p+2, one DMA piece behind each token fragment's MFMAs]
+    auto pair = [&](int p, auto btag, bool has_next, bool has_dma) {
+      constexpr int B = decltype(btag)::value;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          mma(acc[j][i], wq[0][j], xf[i]);
+          if (j == 1 % NJ) {
+            if (i < NJ) wq[1][i] = rd(wp(B, 1) + i * FR);
+          }
+          if (j == NJ - 1) xf[i] = rd(xp(B, 1) + i * FR);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (has_next) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        T out[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = (float)acc[j][i][r] * sc[r];  // library/qbytes_mm.py:47-49: fp32(int32) * fp32(scale), rounded to fp32 ...
-          asm volatile("" : "+v"(v));             // ... and only then to the output dtype (no single-rounding v_fma_mixlo_f16)
-          if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[r];
-          out[r] = E::from_f32(v);
-        }
-        const int row = i * 16 + (lane & 15);
-        if constexpr (sizeof(T) == 2) {
-          const int chunk = (jj * 4 + (lane >> 4)) ^ ((row & (LPR - 1)) << 1);  // 8-byte chunks
-          *reinterpret_cast<uint2*>(park + row * ROWB + chunk * 8) = *reinterpret_cast<const uint2*>(out);
-        } else {
-          const int chunk = (jj * 4 + (lane >> 4)) ^ (row & (LPR - 1));  // 16-byte chunks
-          *reinterpret_cast<uint4*>(park + row * ROWB + chunk * 16) = *reinterpret_cast<const uint4*>(out);
+        for (int j = 0; j < NJ; ++j) {
+          mma(acc[j][i], wq[1][j], xf[i]);
+          if (j == 1 % NJ) {
+            if (i < NJ && has_next) wq[0][i] = rd(wp(B ^ 1, 0) + i * FR);
+          }
+          if (j == 2 % NJ) {
+            if (has_dma) issue_piece(p + 2, mdst[B], i);
+          }
+          if (j == NJ - 1 && has_next) xf[i] = rd(xp(B ^ 1, 0) + i * FR);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+    };
+    using b0 = std::integral_constant<int, 0>;
+    using b1 = std::integral_constant<int, 1>;
+    int p = 0;
+    for (; p + 3 < np; p += 2) {  // steady state: both pairs have a successor and a pair p+2 to fetch
+      pair(p, b0{}, true, true);
+      pair(p + 1, b1{}, true, true);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int t = 0; t < 2 * LPR; ++t) {
-      const int row = t * (64 / LPR) + lane / LPR;
-      const int c16 = lane % LPR;
-      uint4 v;
-      if constexpr (sizeof(T) == 2)
-        v = *reinterpret_cast<const uint4*>(park + row * ROWB + (((c16 * 2) ^ ((row & (LPR - 1)) << 1)) * 8));
-      else
-        v = *reinterpret_cast<const uint4*>(park + row * ROWB + ((c16 ^ (row & (LPR - 1))) * 16));
-      const int m = m0 + wm * 128 + row;
-      const int n = n0 + wn * (NJ * 16) + p * FP + c16 * (16 / (int)sizeof(T));
-      if (full) {
-        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // non-temporal: see qmm_mfma_large.hip
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + (size_t)m * N + n));
-      } else if (m < M) {
-        const T* e = reinterpret_cast<const T*>(&v);
-#pragma unroll
-        for (int r = 0; r < 16 / (int)sizeof(T); ++r)
-          if (n + r < N) yg[(size_t)m * N + n + r] = e[r];
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // at most three pairs left (p is even): straight-line, so that the buffer index stays static
+    if (p < np) pair(p, b0{}, p + 1 < np, p + 2 < np);
+    if (p + 1 < np) pair(p + 1, b1{}, p + 2 < np, false);
+    if (p + 2 < np) pair(p + 2, b0{}, false, false);
   }
+
+  epilogue<ODT, KIND, NJ, BM, BN>(a, acc, smem, m0, n0, wm, wn, wave, lane);
+}
+
+template <int ODT, int KIND, bool SMALL>
+static int launch_r128(const Args& a, hipStream_t stream) {
+  constexpr int T = SMALL ? 128 : 256;
+  constexpr int need = 2 * 2 * T * 128;  // two buffers of 128-byte rows: 128 KiB (64 KiB for the 128-tile); the epilogue parks in it
+  const int tiles = ((a.N + T - 1) / T) * ((a.M + T - 1) / T);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_r128_kernel<ODT, KIND, SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, need);
+  hipLaunchKernelGGL((qbytes_native8_r128_kernel<ODT, KIND, SMALL>), dim3(tiles), dim3(SMALL ? 256 : 512), need, stream, a);
+  return launch_status();
 }
 
 template <int ODT, int KIND, bool PAIRED, bool SMALL>
@@ -426,6 +679,9 @@ static int launch(const Args& a, hipStream_t stream) {
   const int paired_env = env_int("QUANTO_HIP_PAIRED", -1);  // experiments
   const bool paired = (paired_env == 1 || (FP8 && paired_env != 0)) && (a.K * ES) % 128 == 0;
   const bool small = small_env >= 0 ? small_env != 0 : (FP8 && paired ? tiles128 <= 512 : tiles256 < 96);
+  // 128-byte rows (full-line vector-L1 fills, one barrier per 128 bytes of K) whenever K allows
+  if ((a.K * ES) % 128 == 0 && env_int("QUANTO_HIP_NATIVE8_ROW128", 1) != 0)
+    return small ? launch_r128<ODT, KIND, true>(a, stream) : launch_r128<ODT, KIND, false>(a, stream);
   if (paired) return small ? launch_cfg<ODT, KIND, true, true>(a, stream) : launch_cfg<ODT, KIND, true, false>(a, stream);
   return small ? launch_cfg<ODT, KIND, false, true>(a, stream) : launch_cfg<ODT, KIND, false, false>(a, stream);
 }

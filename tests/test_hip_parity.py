@@ -601,6 +601,62 @@ def test_qbytes_fp8_fp8_mfma(dt, kind, M, N, K):
     assert_close_to_exact(to_numpy(y), want, dt, "fp8 x fp8 native")
 
 
+@pytest.mark.parametrize("small", ["0", "1"])
+@pytest.mark.parametrize("K", [128, 256, 384, 512, 640, 1152])
+@pytest.mark.parametrize("M,N", [(256, 256), (300, 700), (1, 17), (520, 257)])
+def test_native8_128_byte_rows_bit_exact(monkeypatch, small, K, M, N):
+    """qmm_native8.hip's 128-byte-row kernel (two LDS buffers, one barrier per 128 bytes of K) against the exact integer reference and
+    against the 64-byte-row kernel, on 1..9 K-tiles (every prologue / steady-state / tail combination of the unrolled pair loop),
+    ragged and full tiles, 256- and 128-tiles."""
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    b = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+    s = O.round_to(((rng.random((N, 1)) + 0.5) / 1e4).astype(np.float32), "bf16")
+    ta, tb, ts = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), to_torch(s, "bf16", DEV)
+    monkeypatch.setenv("QUANTO_HIP_NATIVE8_SMALL", small)
+    monkeypatch.setenv("QUANTO_HIP_NATIVE8_ROW128", "1")
+    y = quanto_hip.lib.qbytes_mm(ta, tb, ts, kernel="mfma_native8")
+    np.testing.assert_array_equal(to_numpy(y), O.qbytes_int_mm_ref(a, b, s, "bf16"))
+    monkeypatch.setenv("QUANTO_HIP_NATIVE8_ROW128", "0")
+    assert torch.equal(y, quanto_hip.lib.qbytes_mm(ta, tb, ts, kernel="mfma_native8"))
+
+
+@pytest.mark.parametrize("row128", ["0", "1"])
+@pytest.mark.parametrize("kind", ["e4m3fn", "e5m2"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 700, 384), (520, 257, 640), (1024, 512, 2048)])
+def test_native8_fp8_both_row_widths(monkeypatch, row128, kind, M, N, K):
+    """fp8 x fp8 on the K = 128 MX-format MFMA from 64-byte-row stages and from 128-byte rows: same instruction, same order of the
+    K blocks - each against the float64 oracle, and the two bit-identical."""
+    rng = np.random.default_rng(M + N + K + 11)
+    a = O.fp8_encode(rng.standard_normal((M, K)).astype(np.float32), kind)
+    b = O.fp8_encode(rng.standard_normal((N, K)).astype(np.float32), kind)
+    s = O.round_to(((rng.random((N, 1)) + 0.5) / 1e2).astype(np.float32), "bf16")
+    ta, tb, ts = fp8_tensor(a, kind, DEV), fp8_tensor(b, kind, DEV), to_torch(s, "bf16", DEV)
+    monkeypatch.setenv("QUANTO_HIP_NATIVE8_ROW128", row128)
+    y = quanto_hip.lib.qbytes_mm(ta, tb, ts, kernel="mfma_native8")
+    want = np.matmul(O.fp8_decode(a, kind).astype(np.float64), O.fp8_decode(b, kind).astype(np.float64).T) * s.astype(np.float64).reshape(1, -1)
+    assert_close_to_exact(to_numpy(y), want, "bf16", f"fp8 x fp8, 128-byte rows = {row128}")
+    monkeypatch.setenv("QUANTO_HIP_NATIVE8_ROW128", "0" if row128 == "1" else "1")
+    assert torch.equal(y, quanto_hip.lib.qbytes_mm(ta, tb, ts, kernel="mfma_native8"))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", [(2304, 2048, 256), (2100, 2300, 448), (4200, 1100, 1024)])
+def test_dense_gemm_128_byte_rows(monkeypatch, dt, M, N, K):
+    """The dense 16-bit GEMM behind dequantize + GEMM (int4 prefill) on the 128-byte-row kernel: more than 256 128-tiles so that the
+    weights-direct loop is not taken; whole output against float64 math on the reference's dequantized weight, and the 64-byte-row
+    kernel bit-identical (same MFMA, same K order)."""
+    monkeypatch.setenv("QUANTO_HIP_DENSE_WD", "0")
+    p = make_qbits_problem(M, N, K, dt, group_size=64, seed=M + K)
+    monkeypatch.setenv("QUANTO_HIP_NATIVE8_ROW128", "1")
+    y = _run_qbits(p, "dequant_mfma")
+    assert quanto_hip.lib.last_kernel() == "dequant_mfma"
+    w = O.dequantize_qbits_ref(p["packed"], 4, p["scale"], p["shift"], 0, 64, (N, K), dt).astype(np.float64)
+    assert_close_to_exact(y, np.matmul(p["x"].astype(np.float64), w.T), dt, "dense GEMM, 128-byte rows")
+    monkeypatch.setenv("QUANTO_HIP_NATIVE8_ROW128", "0")
+    np.testing.assert_array_equal(_run_qbits(p, "dequant_mfma"), y)
+
+
 def test_qbytes_mm_reference_test_grid():
     """The parameter grid of the reference's tests/library/test_mm.py:27-49, same assertion (assert_similar)."""
     g = torch.Generator().manual_seed(0)
