@@ -9,14 +9,12 @@ timeout 420 python -m pytest tests/test_hip_parity.py -m gpu -q -p no:cacheprovi
 echo "== A/B sequential"
 timeout 300 python scripts/ab.py --sequential --rounds 7 --workloads w8a8 fp8a8 cfg4_fp8a8 cfg4_w8a8 int4_prefill --env QUANTO_HIP_NATIVE8_ROW128=0,1 2>&1 | grep -v Warning | tee $OUT/ab_row128.jsonl
 echo "== kernel trace"
-for R in 0 1; do
-  (cd /tmp && QUANTO_HIP_NATIVE8_ROW128=$R timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_r$R -o t -- \
-     python $REPO/scripts/ab.py --rounds 3 --workloads w8a8 fp8a8 int4_prefill cfg4_fp8a8 --env QUANTO_HIP_NATIVE8_ROW128=$R > $OUT/trace_r$R.log 2>&1)
-  f=$(find $OUT/trace_r$R -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f" | cut -c1-220 | tee $OUT/kernel_stats_row128_$R.csv
-done
+(cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- \
+   python $REPO/scripts/ab.py --sequential --rounds 3 --workloads w8a8 fp8a8 int4_prefill cfg4_fp8a8 --env QUANTO_HIP_NATIVE8_ROW128=0,1 > $OUT/trace.log 2>&1)
+f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 "$f" | cut -c1-200 | tee $OUT/kernel_stats_row128_ab.csv
 echo "== L1 fill counters"
 for R in 0 1; do
-  for G in "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+  for G in "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE" "FETCH_SIZE"; do
     D=$OUT/pmc_r${R}_$(echo $G | cut -d' ' -f1)
     (cd /tmp && QUANTO_HIP_NATIVE8_ROW128=$R timeout 200 rocprofv3 --pmc $G --output-format csv -d $D -o p -- \
        python $REPO/scripts/ab.py --rounds 2 --steps 4 --ramp-ms 0 --workloads w8a8 fp8a8 int4_prefill --env QUANTO_HIP_NATIVE8_ROW128=$R > $D.log 2>&1)
