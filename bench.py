@@ -114,8 +114,8 @@ WORKLOADS = {
     "int4_decode1_down": ("qbits_i4", 1, 14336, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, decode (M,K,N)=(1,14336,4096) (Llama-3-8B down_proj)"),
     "int4_decode32_up": ("qbits_i4", 32, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,14336)"),
 }
-DEFAULT_SUB = ["northstar", "cfg3", "cfg4", "qkv_fused", "gateup_fused", "int4_decode32", "qkv_fused32", "int8_gateup_fused", "int4_prefill512",
-               "layer_decode_b1", "layer_decode_b32"]
+DEFAULT_SUB = ["northstar", "cfg3", "cfg4", "cfg4_fp8a8", "w8a8", "fp8a8", "int4_prefill", "int4_prefill512", "gateup_fused", "int4_decode32",
+               "qkv_fused32", "layer_decode_b1", "layer_decode_b32"]  # (q/k/v at M = 1 and the int8 gate/up launch of r2-r4 are inside layer_decode_b1 / --sub)
 # printed ONCE per JSON line (r2's line repeated this prose in every sub-result, grew past the driver's 8 KB stdout tail and lost
 # its first two sub-results): what cpu_baseline.kind == "reference" and each cpu_baseline.path code stand for
 CPU_BASELINE_NOTE = {
@@ -240,7 +240,7 @@ def make_step(kind, x, sets, K, N):
     return step
 
 
-REF_ROCM_FOR = ("cfg2", "cfg3", "northstar", "cfg4", "int4_prefill", "int4_prefill512")
+REF_ROCM_FOR = ("cfg2", "cfg3", "northstar", "cfg4", "int4_prefill", "int4_prefill512", "w8a8", "fp8a8", "cfg4_fp8a8", "cfg4_w8a8")
 
 
 def make_ref_rocm_step(kind, x, wset, K, N):
@@ -257,6 +257,12 @@ def make_ref_rocm_step(kind, x, wset, K, N):
             dqt = scale * data
             dqt -= shift
             return torch.matmul(x, dqt.reshape(N, K).t())
+    elif kind == "qbytes_i8i8":  # library/qbytes_mm.py:36-50, reached from :73-87 for int8 activations: hipBLASLt int8 GEMM + fp32 rescale
+        w, scale = wset
+
+        def step():
+            out = torch._int_mm(x, w.t())
+            return (out.to(torch.float32) * scale.t()).to(scale.dtype)
     else:
         w, scale = wset
 
@@ -399,12 +405,6 @@ def run_workload(name, args, device, rank, world, dist, steps, with_cpu):
     roof["kernel_us"] = roof["kernel_us_min"] = None  # kernel-only duration: filled from the rocprofv3 kernel-trace child pass
     roof["algorithmic_bytes"] = nbytes
     roof["algorithmic_flops"] = flops
-    pmc = os.path.join(ROOT, "profiles", f"pmc_{name}.json")
-    if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (profiles/README.md)
-        rec = json.load(open(pmc))
-        roof["traffic"] = rec.get("hbm_bytes_per_launch")
-        roof["traffic_stale"] = True  # replaced by this run's own counter passes when rocprofv3 is usable (apply_profile)
-        roof["traffic_source"] = f"profiles/pmc_{name}.json ({rec.get('round', 'r01')} builder-run rocprofv3 --pmc passes, not this run)"
     out = {
         "metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -417,10 +417,14 @@ def run_workload(name, args, device, rank, world, dist, steps, with_cpu):
         "roofline": roof,
     }
     if name in REF_ROCM_FOR and not args.no_ref_rocm:
-        ref_step = make_ref_rocm_step(kind, x, sets[0], K, N)
-        with torch.no_grad():
-            r_elapsed, _ = timed_replay(ref_step, 10 if M > 64 else 20, args, None, device, warmup=2)
-        out["ref_rocm_us"] = round(r_elapsed * 1e6 / (10 if M > 64 else 20), 2)
+        try:
+            ref_step = make_ref_rocm_step(kind, x, sets[0], K, N)
+            with torch.no_grad():
+                r_elapsed, _ = timed_replay(ref_step, 10 if M > 64 else 20, args, None, device, warmup=2)
+            out["ref_rocm_us"] = round(r_elapsed * 1e6 / (10 if M > 64 else 20), 2)
+        except Exception as e:  # an ATen op the ROCm build lacks (torch._int_mm): say so instead of dropping the record
+            out["ref_rocm_us"] = None
+            out["ref_rocm_error"] = repr(e)[:120]
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline(kind, M, K, N, x, sets[0], args.cpu_budget)
     del sets
@@ -585,34 +589,49 @@ def run_layer_decode(name, args, device, rank, world, dist, steps):
 QCONV = {"B": 8, "C": 128, "H": 28, "W": 28, "OC": 128, "k": 3, "stride": 1, "pad": 1}
 
 
-def run_qconv2d(args, device, steps=50):
-    """One ResNet-style 3x3 layer, bf16 activations: ``QConv2d`` with qint8 and qint4 weights through this library (quanto::qbytes_conv2d /
-    quanto::qbits_conv2d: im2col gathered inside the kernel, K split + deterministic reduce) and what the reference computes for the same
-    module on a ROCm device (nn/qconv2d.py:54-55 -> qfallback: dequantize the weight, aten convolution = MIOpen).  hipGraph-timed like every
-    other record; the weight is small (147 KB / 74 KB), so nothing is rotated."""
+def build_qconv(wq, device):
+    """The frozen QConv2d of the record (weights ``wq``) on the device and its input."""
     import optimum_quanto_amd as Q
-    from optimum_quanto_amd.library.hip import quanto_hip
 
     c = QCONV
     torch.manual_seed(0)
     x = torch.randn(c["B"], c["C"], c["H"], c["W"], device=device).to(torch.bfloat16)
+    conv = torch.nn.Conv2d(c["C"], c["OC"], c["k"], stride=c["stride"], padding=c["pad"]).to(torch.bfloat16)
+    q = Q.QConv2d.from_module(conv, weights=getattr(Q, wq))
+    Q.freeze(q)
+    return q.to(device), x
+
+
+def run_qconv2d(args, device, steps=50):
+    """One ResNet-style 3x3 layer, bf16 activations: ``QConv2d`` with qint8 and qint4 weights through this library (quanto::qbytes_conv2d /
+    quanto::qbits_conv2d: im2col gathered inside the kernel, K split + deterministic reduce) and what the reference computes for the same
+    module on a ROCm device (nn/qconv2d.py:54-55 -> qfallback: dequantize the weight, aten convolution = MIOpen).  hipGraph-timed like every
+    other record; the weight is small (147 KB / 74 KB), so nothing is rotated.  Algorithmic bytes: input + weight + scales + output, each once."""
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    c = QCONV
     OH = (c["H"] + 2 * c["pad"] - c["k"]) // c["stride"] + 1
     M, K, N = c["B"] * OH * OH, c["C"] * c["k"] * c["k"], c["OC"]
-    out = {"name": "qconv2d_3x3", "shape": f"({c['B']},{c['C']},{c['H']},{c['W']})->{c['OC']} 3x3 pad 1", "M": M, "K": K, "N": N,
-           "alg_flops": 2 * M * K * N, "bound": "gather issue (DESIGN 8)", "steps": steps}
+    flops = 2 * M * K * N
+    io_bytes = c["B"] * c["C"] * c["H"] * c["W"] * 2 + M * N * 2
+    out = {"name": CONV_NAME, "shape": f"({c['B']},{c['C']},{c['H']},{c['W']})->{c['OC']} 3x3 pad 1", "M": M, "K": K, "N": N, "alg_flops": flops,
+           "steps": steps, "kernel_us": None, "kernel_us_min": None, "traffic": None}
     with torch.no_grad():
         for wq in ("qint8", "qint4"):
-            conv = torch.nn.Conv2d(c["C"], c["OC"], c["k"], stride=c["stride"], padding=c["pad"]).to(torch.bfloat16)
-            q = Q.QConv2d.from_module(conv, weights=getattr(Q, wq))
-            Q.freeze(q)
-            q = q.to(device)
+            q, x = build_qconv(wq, device)
             w, bias = q.weight, q.bias
             el, _ = timed_replay(lambda: q(x), steps, args, None, device, warmup=3)
-            out[f"{wq[1:]}_us"] = round(el * 1e6 / steps, 2)
+            us = el * 1e6 / steps
+            nbytes = io_bytes + (N * K + N * 2 if wq == "qint8" else N * K // 2 + 2 * (N * (K // w._group_size) * 2))
+            out[f"{wq[1:]}_us"] = round(us, 2)
             out[f"{wq[1:]}_kernel"] = quanto_hip.lib.last_kernel()
+            out[f"{wq[1:]}_alg_bytes"] = nbytes
+            out[f"{wq[1:]}_frac_mfma"] = round(flops / us / 1e6 / MFMA_PEAK_TFLOPS, 4)
+            out[f"{wq[1:]}_frac_hbm"] = round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)
             el, _ = timed_replay(lambda: torch.nn.functional.conv2d(x, w.dequantize(), bias, c["stride"], c["pad"]), steps, args, None, device, warmup=3)
             out[f"ref_rocm_{wq[1:]}_us"] = round(el * 1e6 / steps, 2)
-    out["ref_rocm"] = "reference behaviour on the device: dequantize + MIOpen convolution"
+    out["bound"] = "gather instruction issue (DESIGN 4.8): both roofline fractions given"
+    out["ref_rocm"] = "dequantize + MIOpen conv; kernel_us / traffic: the int8 launch"
     return out
 
 
@@ -664,42 +683,117 @@ def run_cfg5(args, device, batches=(1, 32), prompt=512, new=512):
                 out[f"b{b}_ms_per_token"] = round(ms / new, 3)
             except Exception as e:
                 out[f"b{b}_error"] = repr(e)[:160]
+        # the binding's own share of a decode step: host time per eager QLinear.forward at the decode shape (2000 back-to-back calls: the
+        # loop is host-bound, so wall time / calls = host cost per call), split by layer of the Python stack (scripts/host_overhead.py)
+        try:
+            out["host_us_per_call"] = host_cost_per_call(model, device)
+        except Exception as e:
+            out["host_us_per_call_error"] = repr(e)[:120]
     del model
     torch.cuda.empty_cache()
     return out
 
 
+def host_cost_per_call(model, device, calls=2000):
+    """us of host time per call at M = 1 for one of the model's int4 QLinears (o_proj): the module, F.linear on the quantized weight
+    (__torch_function__), the torch.ops.quanto op, the ctypes binding, and the raw C entry with pre-marshalled arguments."""
+    import ctypes
+
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    lin = model.model.layers[0].self_attn.o_proj
+    w = lin.weight
+    x = torch.randn(1, 1, 4096, dtype=torch.bfloat16, device=device)
+    y = torch.empty((1, 4096), dtype=torch.bfloat16, device=device)
+    c = quanto_hip.lib._c
+    raw = (x.data_ptr(), w._data._data.data_ptr(), w._scale.data_ptr(), w._shift.data_ptr(), 0, y.data_ptr(), 1, 4096, 4096, 4, 128, 2, 2, 2, 0, 0,
+           ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+    legs = {"module": lambda: lin(x), "F_linear": lambda: torch.nn.functional.linear(x, w),
+            "op": lambda: torch.ops.quanto.qbits_mm(x, w._data._data, w._scale, w._shift, None, 4, 128, 4096, 4096),
+            "binding": lambda: quanto_hip.lib.qbits_mm(x, w._data._data, w._scale, w._shift, None, 4, 128, 4096, 4096),
+            "c_entry": lambda: c.quanto_hip_qbits_mm(*raw)}
+    res = {}
+    for k, fn in legs.items():
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            fn()
+        torch.cuda.synchronize()
+        res[k] = round((time.perf_counter() - t0) / calls * 1e6, 1)
+    return res
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # rocprofv3 child passes: kernel-only durations and fabric traffic measured by THIS run (not copied from profiles/)
 # ------------------------------------------------------------------------------------------------------------------------
-MARKER = "unpack_scalar_kernel"  # one 3-byte quanto::unpack launch (a kernel no bench workload uses) separates the workloads in a trace
+MARKER = "unpack_scalar_kernel"  # one 3-byte quanto::unpack launch (a kernel no bench workload uses) separates the segments of a trace
 TRACE_STEPS = 12
+CONV_NAME = "qconv2d_3x3"
+
+
+def _child_step(name, device):
+    """(step, keep-alive) of a workload inside a rocprofv3 child process - the very step the timed region replays."""
+    if name in LAYER_WORKLOADS:
+        xs, sets = build_layer(LAYER_WORKLOADS[name], device, seed=4321)
+        return make_layer_step(xs, sets), sets
+    if name == CONV_NAME:
+        q, x = build_qconv("qint8", device)
+        return (lambda: q(x)), q
+    kind, M, K, N, _ = WORKLOADS[name]
+    Nt = sum(N) if isinstance(N, tuple) else N
+    wb = Nt * K // 2 if kind.startswith("qbits") else Nt * K
+    n_weights = max(1, -(-(512 << 20) // wb)) if M <= 64 else 1
+    x, sets = build_inputs(kind, M, K, N, device, min(n_weights, 3 + TRACE_STEPS), seed=1234)
+    return make_step(kind, x, sets, K, N), sets
 
 
 def trace_child(names, args, device):
-    """``--trace-child``: run under rocprofv3.  Every workload: marker launch, 3 + TRACE_STEPS eager steps, synchronize."""
+    """``--trace-child``: run under rocprofv3.  Two segments per workload, each opened by a marker launch:
+      * ``graph`` mode (kernel trace): [capture TRACE_STEPS steps in a hipGraph, replay it for the clock ramp] [ONE more replay] - the second
+        segment is the steady state the timed region of the parent measures, so its kernel durations can be laid beside ``us_per_step``
+        (r4 traced cold, eager launches: a kernel that took LONGER than the step containing it);
+      * ``eager`` mode (counter passes, where rocprofv3 serialises the dispatches anyway): [3 warm-up steps] [TRACE_STEPS steps]."""
     from optimum_quanto_amd.library.hip import quanto_hip
 
     lib = quanto_hip.lib
     tag = torch.zeros(3, dtype=torch.uint8, device=device)  # 3 bytes: the scalar unpack kernel (the vectorised one needs multiples of 16)
+    graph_mode = args.trace_mode == "graph"
     for name in names:
-        if name in LAYER_WORKLOADS:
-            xs, sets = build_layer(LAYER_WORKLOADS[name], device, seed=4321)
-            step = make_layer_step(xs, sets)
-        else:
-            kind, M, K, N, _ = WORKLOADS[name]
-            Nt = sum(N) if isinstance(N, tuple) else N
-            wb = Nt * K // 2 if kind.startswith("qbits") else Nt * K
-            n_weights = max(1, -(-(512 << 20) // wb)) if M <= 64 else 1
-            x, sets = build_inputs(kind, M, K, N, device, min(n_weights, 3 + TRACE_STEPS), seed=1234)
-            step = make_step(kind, x, sets, K, N)
-        torch.cuda.synchronize()
-        lib.unpack(tag, 4)
+        step, keep = _child_step(name, device)
         with torch.no_grad():
-            for _ in range(3 + TRACE_STEPS):
-                step()
-        torch.cuda.synchronize()
-        del sets, step
+            step()
+            torch.cuda.synchronize()
+            lib.unpack(tag, 4)
+            if graph_mode:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        for _ in range(TRACE_STEPS):
+                            step()
+                torch.cuda.current_stream().wait_stream(side)
+                compute_bound = name == CONV_NAME or (name in WORKLOADS and WORKLOADS[name][1] > 64)
+                t0, n = time.perf_counter(), 0
+                while (time.perf_counter() - t0) * 1e3 < (120.0 if compute_bound else 15.0) or n < 2:
+                    g.replay()
+                    torch.cuda.synchronize()
+                    n += 1
+                lib.unpack(tag, 4)
+                g.replay()
+                torch.cuda.synchronize()
+                del g
+            else:
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                lib.unpack(tag, 4)
+                for _ in range(TRACE_STEPS):
+                    step()
+                torch.cuda.synchronize()
+        del keep, step
         torch.cuda.empty_cache()
     lib.unpack(tag, 4)
     torch.cuda.synchronize()
@@ -719,7 +813,8 @@ def _rocprof_pass(names, mode, timeout_s):
         return None
     out_dir = tempfile.mkdtemp(prefix="qh_bench_prof_", dir="/tmp")
     flags = ["--kernel-trace"] if mode == "trace" else ["--pmc", mode]
-    cmd = [exe, *flags, "--output-format", "csv", "-d", out_dir, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--trace-child", *names]
+    cmd = [exe, *flags, "--output-format", "csv", "-d", out_dir, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--trace-mode",
+           "graph" if mode == "trace" else "eager", "--trace-child", *names]
     env = dict(os.environ, TMPDIR="/tmp", QH_BENCH_CHILD="1")
     try:
         subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, capture_output=True)
@@ -727,6 +822,8 @@ def _rocprof_pass(names, mode, timeout_s):
         files = glob.glob(os.path.join(out_dir, "**", pat), recursive=True)
         if not files:
             return None
+        if mode == "trace" and os.environ.get("QH_BENCH_KEEP_TRACE"):  # the visit scripts keep the trace the line was computed from
+            shutil.copy(files[0], os.environ["QH_BENCH_KEEP_TRACE"])
         rows = []
         for r in csv.DictReader(open(files[0])):
             val = float(r["Counter_Value"]) if mode != "trace" else None
@@ -741,7 +838,8 @@ def _rocprof_pass(names, mode, timeout_s):
 
 
 def _segments(rows, names):
-    """Split the dispatch list at the marker launches: segment i belongs to names[i]; only the library's kernels (qh::) are kept."""
+    """Split the dispatch list at the marker launches.  Every workload opens TWO segments (warm-up / ramp, then the measured one): the
+    measured segment of names[i] is segment 2 i + 1; only the library's kernels (qh::) are kept."""
     segs, cur = [], None
     for k, a, b, v in rows:
         if MARKER in k:
@@ -750,12 +848,12 @@ def _segments(rows, names):
             cur = []
         elif cur is not None and "qh::" in k:
             cur.append((k, a, b, v))
-    return dict(zip(names, segs)) if len(segs) == len(names) else None
+    return dict(zip(names, segs[1::2])) if len(segs) == 2 * len(names) else None
 
 
-def collect_profiles(names, timeout_s=240):
-    """kernel-only us per step (average and sum-of-minima over the kernels a step launches) and fabric bytes per step for every
-    workload in ``names``; {} when rocprofv3 cannot be used here (the caller then keeps the committed figures, marked stale)."""
+def collect_profiles(names, timeout_s=300):
+    """kernel-only us per step (average and sum-of-minima over the kernels a step launches, from ONE steady-state graph replay) and fabric
+    bytes per step for every workload in ``names``; {} when rocprofv3 cannot be used here."""
     if os.environ.get("QH_BENCH_CHILD"):
         return {}
     res = {}
@@ -763,11 +861,10 @@ def collect_profiles(names, timeout_s=240):
     segs = _segments(trace, names) if trace else None
     if segs:
         for n, seg in segs.items():
-            per_step = len(seg) // (3 + TRACE_STEPS)
-            if per_step == 0:
+            per_step = len(seg) // TRACE_STEPS
+            if per_step == 0 or len(seg) != per_step * TRACE_STEPS:
                 continue
-            timed = seg[3 * per_step:(3 + TRACE_STEPS) * per_step]
-            by_slot = [[(b - a) / 1e3 for (_, a, b, _) in timed[j::per_step]] for j in range(per_step)]  # slot j of a step over the steps
+            by_slot = [[(b - a) / 1e3 for (_, a, b, _) in seg[j::per_step]] for j in range(per_step)]  # slot j of a step over the steps
             res[n] = {"kernel_us": round(sum(sum(v) / len(v) for v in by_slot), 3), "kernel_us_min": round(sum(min(v) for v in by_slot), 3),
                       "kernels_per_step": per_step}
     traffic = {}
@@ -777,10 +874,8 @@ def collect_profiles(names, timeout_s=240):
         if not segs:
             return res
         for n, seg in segs.items():
-            per_step = len(seg) // (3 + TRACE_STEPS)
-            if per_step:
-                timed = seg[3 * per_step:(3 + TRACE_STEPS) * per_step]
-                traffic.setdefault(n, {})[counter] = sum(v for *_, v in timed) / TRACE_STEPS  # KB per step
+            if len(seg) >= TRACE_STEPS:
+                traffic.setdefault(n, {})[counter] = sum(v for *_, v in seg) / TRACE_STEPS  # KB per step
     for n, t in traffic.items():
         if len(t) == 2:
             # gfx950: FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes -> x 2 (MI355X_MICROARCH.md, HBM section)
@@ -798,25 +893,22 @@ def apply_profile(rec, prof, compacted):
             roof[k] = prof[k]
     if "traffic" in prof:
         roof["traffic"] = prof["traffic"]
-        roof.pop("traffic_stale", None)
-        if not compacted:
-            roof["traffic_source"] = "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of bench.py (eager, same inputs), FETCH x2 (gfx950)"
 
 
 def compact(r):
-    """A sub-result in ~300 bytes: everything the reader needs to recompute the roofline fraction, nothing repeated."""
+    """A sub-result in ~300 bytes: what the reader needs to recompute the roofline fraction (frac = alg_flops or alg_bytes / us_per_step /
+    peak; alg_flops = 2 M sum(N) K), nothing repeated.  ``kernel_us`` (steady-state graph replay under rocprofv3) <= ``event_us`` (device
+    events around the timed replay) <= ``us_per_step`` (host clock around barrier + synchronize: the time ``value`` uses)."""
     roof, cfg = r["roofline"], r["config"]
     out = {"name": cfg["name"], "M": cfg["M"], "K": cfg["K"], "N": cfg["N"], "value": r["value"], "unit": r["unit"],
-           "us_per_step": round(r["ms_per_step"] * 1e3, 3), "kernel": roof["kernel"], "bound": roof["bound"],
-           "frac": roof["frac"], "alg_bytes": int(roof["algorithmic_bytes"]), "alg_flops": int(roof["algorithmic_flops"]),
-           "traffic": roof["traffic"], "rot": cfg["weight_buffers_rotated"], "event_us": roof["event_us"], "kernel_us": None, "kernel_us_min": None}
-    if roof.get("traffic_stale"):
-        out["traffic_stale"] = True
+           "us_per_step": round(r["ms_per_step"] * 1e3, 3), "event_us": roof["event_us"], "kernel_us": None, "kernel_us_min": None,
+           "kernel": roof["kernel"], "bound": roof["bound"], "frac": roof["frac"], "alg_bytes": int(roof["algorithmic_bytes"]),
+           "traffic": roof["traffic"], "rot": cfg["weight_buffers_rotated"]}
     if "ref_rocm_us" in r:
         out["ref_rocm_us"] = r["ref_rocm_us"]
     if "cpu_baseline" in r:
         c = r["cpu_baseline"]
-        out["cpu"] = {"v": c["value"], "unit": c["unit"], "s": c["seconds_per_call"], "iqr_s": c["iqr_s"], "path": c["path"]}
+        out["cpu"] = {"v": c["value"], "unit": c["unit"], "s": c["seconds_per_call"], "path": c["path"]}
         if "tinygemm" in c:
             out["cpu"]["tinygemm_GBs"] = c["tinygemm"]["value"]
     return out
@@ -855,6 +947,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the rocprofv3 child passes (kernel_us, traffic) of the default run")
     ap.add_argument("--profile", action="store_true", help="run the rocprofv3 child passes for a non-default selection of workloads too")
     ap.add_argument("--trace-child", nargs="+", default=None, help=argparse.SUPPRESS)  # the child run of collect_profiles
+    ap.add_argument("--trace-mode", default="graph", choices=["graph", "eager"], help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus is None:  # an external launcher's WORLD_SIZE is enough (torchrun --nproc-per-node 8 bench.py --shard)
@@ -921,37 +1014,40 @@ def main():
                 sub_results.append({"name": "cfg4_sharded", "scaling": "strong", "n_gpus": world, "value": r["value"], "unit": r["unit"],
                                     "compute_only_us": r["compute_only_us"], "with_all_gather_us": r["with_all_gather_us"],
                                     "compute_only_tflops": r["compute_only_tflops"], "parallelism": r["config"]["parallelism"]})
+        conv_rec = None
+        if world == 1 and rank == 0 and default_run and out is not None:
+            try:
+                conv_rec = run_qconv2d(args, device)
+            except Exception as e:
+                conv_rec = {"name": CONV_NAME, "error": repr(e)[:200]}
+            sub_results.append(conv_rec)
         if world == 1 and rank == 0 and (default_run or args.profile) and not args.no_profile and out is not None:
             # this run's own kernel-only durations and counter traffic (child processes under rocprofv3; nothing here is timed)
             names = [args.workload] + [sr["name"] for sr in sub_results if sr["name"] in WORKLOADS or sr["name"] in LAYER_WORKLOADS]
+            if conv_rec is not None and "error" not in conv_rec:
+                names.append(CONV_NAME)
             t_prof = time.perf_counter()
             prof = collect_profiles(names)
             apply_profile(out, prof.get(args.workload), compacted=False)
             for sr in sub_results:
                 apply_profile(sr, prof.get(sr["name"]), compacted=True)
             out["profile_passes"] = {"ok": bool(prof), "seconds": round(time.perf_counter() - t_prof, 1),
-                                     "what": "rocprofv3 --kernel-trace, --pmc FETCH_SIZE, --pmc WRITE_SIZE child runs of this file"}
-        if world == 1 and rank == 0 and default_run and out is not None:
-            try:
-                sub_results.append(run_qconv2d(args, device))
-            except Exception as e:
-                sub_results.append({"name": "qconv2d_3x3", "error": repr(e)[:200]})
+                                     "what": "rocprofv3 child runs of this file: --kernel-trace of one steady-state hipGraph replay (kernel_us), --pmc FETCH_SIZE / WRITE_SIZE (traffic, FETCH x2: gfx950)"}
         if world == 1 and rank == 0 and default_run and not args.no_cfg5 and out is not None:
             try:
-                sub_results.append(run_cfg5(args, device))
+                rec = run_cfg5(args, device)
+                # the library's kernels in one decoded token = 32 layers x the four launches of layer_decode_b1 / _b32 (same shapes, same kernels)
+                for b, lname in ((1, "layer_decode_b1"), (32, "layer_decode_b32")):
+                    lay = next((sr for sr in sub_results if sr.get("name") == lname), None)
+                    if lay is not None and lay.get("kernel_us") is not None:
+                        rec[f"b{b}_qh_kernel_ms_per_token"] = round(32 * lay["kernel_us"] / 1e3, 3)
+                sub_results.append(rec)
             except Exception as e:  # transformers missing / out of memory: the GEMM records stand on their own
                 sub_results.append({"name": "cfg5", "error": repr(e)[:200]})
         if out is not None and sub_results:
             out["sub_results"] = sub_results
-            if any(sr["name"] in LAYER_WORKLOADS for sr in sub_results):
-                out["layer_decode_note"] = ("one Llama-3-8B layer's int4 QLinears as 4 launches (q/k/v fused, o, gate/up fused, down), 5 layers' weights "
-                                            "rotated (HBM); cache_resident_*: 2 layers rotated = Infinity-Cache hits, the bound for a weight prefetcher")
         if out is not None and "cpu_baseline" in out:
-            out["cpu_baseline"]["how"] = CPU_BASELINE_NOTE["reference"]
-            used = {out["cpu_baseline"]["path"]} | {sr["cpu"]["path"] for sr in sub_results if "cpu" in sr}
-            if any("tinygemm_GBs" in sr.get("cpu", {}) for sr in sub_results):
-                used.add("tinygemm")
-            out["cpu_paths"] = {k: CPU_BASELINE_NOTE[k] for k in sorted(used)}
+            out["cpu_baseline"]["how"] = "the reference's CPU QLinear path (its ATen kernels in its order, oracle/reference_cpu_path.py; path codes: README.md, Benchmark)"
     if rank == 0 and out is not None:
         print(json.dumps(out, separators=(",", ":")), flush=True)
     if dist is not None:

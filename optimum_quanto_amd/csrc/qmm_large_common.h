@@ -1,4 +1,4 @@
-// Shared pieces of the large-tile MFMA GEMMs (qmm_mfma_large.hip: 16x16x32 MFMA; qmm_mfma_large32.hip: 32x32x16 MFMA).
+// Shared pieces of the large-tile MFMA GEMMs (qmm_mfma_large.hip: 16x16x32 MFMA; the 32x32x16 experiment of r2 is kept as scripts/probes/qmm_mfma_large32.hip).
 #pragma once
 #include "qh_common.h"
 

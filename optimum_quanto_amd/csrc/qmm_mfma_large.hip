@@ -17,7 +17,7 @@
 //     tile are fetched from LDS as soon as their register is dead; activation fragments stream two steps ahead.
 //   ONE workgroup barrier per K-tile (at the tile boundary): before it every wave waits for its own DMA share of tile
 //   kt+1 (issued a full tile earlier); after it the stage of tile kt-1 is refilled with tile kt+2.
-// LDS image, swizzles, XCD-aware tile order and the D[n][m] accumulator orientation are v2's (qmm_mfma_v2.hip).
+// LDS image, swizzles, XCD-aware tile order and the D[n][m] accumulator orientation are those of the 128x128 kernel (qmm_mfma.hip).
 #include <cstdlib>
 #include <type_traits>
 
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   QH_LT_STAMP(6);
 }
 
-enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2, CFG_256_1X8 = 3, CFG_256_MFMA32 = 4 /* qmm_mfma_large32.hip */ };
+enum { CFG_256_8W = 0, CFG_256_4W = 1, CFG_128_4W = 2, CFG_256_1X8 = 3 };
 
 template <int DT, int FMT, int BM, int BN, int WM, int WN, int WD = 0>
 static int launch_cfg(const Args& a, hipStream_t stream) {
@@ -553,8 +553,6 @@ static int launch(const Args& a, int cfg, hipStream_t stream) {
 }
 
 }  // namespace lt
-
-int qbytes_mm_mfma_large32(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, hipStream_t);
 
 bool qbytes_mfma_large_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
   const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2 || b_dtype == QUANTO_HIP_F8_E4M3FNUZ;
@@ -618,7 +616,6 @@ int qbytes_mm_mfma_large(const void* x, const void* w, const void* s, const void
   const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
   const int cfg = forced >= 0 ? forced : (tiles128 > 512 ? lt::CFG_256_8W : lt::CFG_128_4W);
   if (cfg != lt::CFG_128_4W) split = 1;  // the workspace is sized for 128-tiles
-  if (cfg == lt::CFG_256_MFMA32 && b_dtype != QUANTO_HIP_F8_E4M3FNUZ) return qbytes_mm_mfma_large32(x, w, s, bias, y, M, N, K, b_dtype, out_dtype, stream);
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
   lt::Args a{x, reinterpret_cast<const uint8_t*>(w), s, bias, y, (int)M, (int)N, (int)K, 1, split, reinterpret_cast<int*>(workspace),
              split > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + large_counter_bytes(M, N)) : nullptr};

@@ -60,7 +60,23 @@ struct Args {
   const void* bias;   // [N] or null
   void* y;            // [M, N]
   int M, N, K;
+  int gm;             // tile raster: consecutive workgroup ids walk down gm tile rows before moving to the next tile column (1 = row-major)
 };
+
+// Tile raster.  The XCD remap in the kernels hands every XCD (its own 4 MiB L2, 32 CUs) one contiguous range of tile indices; all of an
+// XCD's workgroups walk K in step, so its L2 fetches every operand line once per distinct tile row / tile column in that range.  Row-major
+// indices make the range 2 tile rows x 16 tile columns at 4096^3 (18 row-panels of traffic per XCD, 72 % L2 hits), and ONE row x 32 columns for
+// the 128-tiles of (512,8192,8192) (33 panels); walking `gm` tile rows first turns it into a gm x (32 / gm) block: 4 x 8 = 12 panels, 81 % hits.
+// The vector L1 keeps ~57 of its 64 miss slots busy in these kernels (requests x latency / cycles, profiles/r05_native8_row128.md), so the
+// fill rate is slots x 128 B / latency and the L2 hit rate sets the latency.
+__device__ __forceinline__ void tile_of(int bid, int tiles_m, int tiles_n, int gm, int& tm, int& tn) {
+  const int per_group = gm * tiles_n;
+  const int grp = bid / per_group, first = grp * gm;
+  const int rows = tiles_m - first < gm ? tiles_m - first : gm;
+  const int in = bid - grp * per_group;
+  tn = in / rows;
+  tm = first + (in - tn * rows);
+}
 
 // ---- epilogue: (int32 | fp32) accumulator * scale[n] (+ bias), parked per wave in LDS, stored as full 128-byte lines ----
 // (shared by the 64-byte-row and the 128-byte-row kernels; every wave must be done with the operand stages: the barrier below)
@@ -145,8 +161,6 @@ __device__ __forceinline__ void epilogue(const Args& a, typename Acc<KIND>::V (&
 // occupy the chip; otherwise 256x256 with eight waves of 128 x 64.
 template <int ODT, int KIND, bool PAIRED = false, bool SMALL = false>
 __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(const Args a) {
-  using E = Elem<ODT>;
-  using T = typename E::T;
   using AV = typename Acc<KIND>::V;
   constexpr int BM = SMALL ? 128 : 256, BN = BM;
   constexpr int NWAVES = SMALL ? 4 : 8;
@@ -168,7 +182,8 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  int tm, tn;
+  tile_of(bid, tiles_m, tiles_n, a.gm, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- DMA: 2 + 2 pieces of 1 KiB per wave and K-tile; piece j of an operand covers tile rows (j*8+wave)*16 .. +15 -------
@@ -429,7 +444,10 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
 // =============================================================================================================================
 __device__ __forceinline__ int swz128(int row) { return (row >> 1) & 7; }
 
-template <int ODT, int KIND, bool SMALL = false>
+// V: scheduling experiments (QUANTO_HIP_R128_VARIANT; int8 / 16-bit 256-tiles only).  bit 0: the eight DMA pieces of a pair behind the FIRST
+// four token fragments of the odd step (two per fragment) instead of one behind each of the eight; bit 1: no lgkmcnt(0) in front of the
+// barrier (timing only: the write-after-read margin is then a matter of luck).
+template <int ODT, int KIND, bool SMALL = false, int V = 0>
 __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kernel(const Args a) {
   using AV = typename Acc<KIND>::V;
   constexpr bool MX = KIND == K_F8E4M3 || KIND == K_F8E5M2;
@@ -458,7 +476,8 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  int tm, tn;
+  tile_of(bid, tiles_m, tiles_n, a.gm, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- DMA: 4 + 4 pieces of 1 KiB per wave and pair; piece j of an operand covers tile rows (j * NWAVES + wave) * 8 .. + 7 ----
@@ -608,7 +627,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
       }
       if (has_next) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!(V & 2)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
@@ -621,7 +640,14 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
             if (i < NJ && has_next) wq[0][i] = rd(wp(B ^ 1, 0) + i * FR);
           }
           if (j == 2 % NJ) {
-            if (has_dma) issue_piece(p + 2, mdst[B], i);
+            if constexpr (V & 1) {
+              if (has_dma && i < 4) {
+                issue_piece(p + 2, mdst[B], 2 * i);
+                issue_piece(p + 2, mdst[B], 2 * i + 1);
+              }
+            } else {
+              if (has_dma) issue_piece(p + 2, mdst[B], i);
+            }
           }
           if (j == NJ - 1 && has_next) xf[i] = rd(xp(B ^ 1, 0) + i * FR);
           __builtin_amdgcn_sched_barrier(0);
@@ -644,14 +670,25 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
   epilogue<ODT, KIND, NJ, BM, BN>(a, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
-template <int ODT, int KIND, bool SMALL>
+template <int ODT, int KIND, bool SMALL, int V = 0>
 static int launch_r128(const Args& a, hipStream_t stream) {
   constexpr int T = SMALL ? 128 : 256;
   constexpr int need = 2 * 2 * T * 128;  // two buffers of 128-byte rows: 128 KiB (64 KiB for the 128-tile); the epilogue parks in it
   const int tiles = ((a.N + T - 1) / T) * ((a.M + T - 1) / T);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_r128_kernel<ODT, KIND, SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, need);
-  hipLaunchKernelGGL((qbytes_native8_r128_kernel<ODT, KIND, SMALL>), dim3(tiles), dim3(SMALL ? 256 : 512), need, stream, a);
+  if constexpr (V == 0 && !SMALL && ODT == QUANTO_HIP_BF16 && (KIND == K_I8 || KIND == K_BF16)) {
+    const int v = env_int("QUANTO_HIP_R128_VARIANT", 0);  // experiments
+    if (v == 1) return launch_r128<ODT, KIND, SMALL, 1>(a, stream);
+    if (v == 2) return launch_r128<ODT, KIND, SMALL, 2>(a, stream);
+    if (v == 3) return launch_r128<ODT, KIND, SMALL, 3>(a, stream);
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_r128_kernel<ODT, KIND, SMALL, V>), hipFuncAttributeMaxDynamicSharedMemorySize, need);
+  hipLaunchKernelGGL((qbytes_native8_r128_kernel<ODT, KIND, SMALL, V>), dim3(tiles), dim3(SMALL ? 256 : 512), need, stream, a);
   return launch_status();
+}
+
+static int raster_group() {
+  const int g = env_int("QUANTO_HIP_NATIVE8_GROUP_M", 4);  // experiments: 1 = row-major
+  return g < 1 ? 1 : g;
 }
 
 template <int ODT, int KIND, bool PAIRED, bool SMALL>
@@ -698,7 +735,7 @@ bool dense_mm_large_supported(int64_t M, int64_t N, int64_t K, int dtype) {
 int dense_mm_large(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int dtype, hipStream_t stream) {
   if (!dense_mm_large_supported(M, N, K, dtype)) return QUANTO_HIP_ENOTSUP;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
-  n8::Args args{reinterpret_cast<const uint8_t*>(x), reinterpret_cast<const uint8_t*>(w), nullptr, bias, y, (int)M, (int)N, (int)K};
+  n8::Args args{reinterpret_cast<const uint8_t*>(x), reinterpret_cast<const uint8_t*>(w), nullptr, bias, y, (int)M, (int)N, (int)K, n8::raster_group()};
   if (dtype == QUANTO_HIP_BF16) return n8::launch<QUANTO_HIP_BF16, n8::K_BF16>(args, stream);
   return n8::launch<QUANTO_HIP_F16, n8::K_F16>(args, stream);
 }
@@ -716,7 +753,7 @@ int qbytes_mm_native8(const void* a, const void* b, const void* s, const void* b
                       int b_dtype, int out_dtype, hipStream_t stream) {
   if (!qbytes_native8_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
   if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16) return QUANTO_HIP_EALIGN;
-  n8::Args args{reinterpret_cast<const uint8_t*>(a), reinterpret_cast<const uint8_t*>(b), s, bias, y, (int)M, (int)N, (int)K};
+  n8::Args args{reinterpret_cast<const uint8_t*>(a), reinterpret_cast<const uint8_t*>(b), s, bias, y, (int)M, (int)N, (int)K, n8::raster_group()};
 #define QH_KIND(ODT)                                                                  \
   if (a_dtype == QUANTO_HIP_I8) return n8::launch<ODT, n8::K_I8>(args, stream);       \
   if (a_dtype == QUANTO_HIP_F8_E4M3FN) return n8::launch<ODT, n8::K_F8E4M3>(args, stream); \

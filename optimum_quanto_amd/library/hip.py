@@ -20,6 +20,7 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # quanto_hip_dtype (include/quanto_hip.h)
 F32, F16, BF16, I8, U8, F8_E4M3FN, F8_E5M2, F8_E4M3FNUZ = range(8)
 WS_COUNTER_BYTES = 4096  # QUANTO_HIP_WS_COUNTER_BYTES
+_EXPERIMENT = os.environ.get("QUANTO_HIP_EXPERIMENT", "0") not in ("", "0")  # the library's knobs are live: plans are not cached
 KERNEL_AUTO, KERNEL_NAIVE, KERNEL_GEMV, KERNEL_MFMA, KERNEL_MFMA_LARGE, KERNEL_SKINNY, KERNEL_NATIVE8, KERNEL_DEQUANT_MFMA, KERNEL_MFMA_FUSED4, KERNEL_MMV, KERNEL_MFMA_LARGE4 = range(11)
 KERNELS = {"auto": KERNEL_AUTO, "naive": KERNEL_NAIVE, "gemv": KERNEL_GEMV, "mfma": KERNEL_MFMA, "mfma_large": KERNEL_MFMA_LARGE, "skinny": KERNEL_SKINNY,
            "mfma_native8": KERNEL_NATIVE8, "dequant_mfma": KERNEL_DEQUANT_MFMA, "mfma_fused4": KERNEL_MFMA_FUSED4, "mmv": KERNEL_MMV, "mfma_large4": KERNEL_MFMA_LARGE4}
@@ -48,7 +49,38 @@ def _dt(t: torch.Tensor) -> int:
 
 
 def _ptr(t):
-    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+    """Device address as a plain int (ctypes converts it through the entry's argtypes; building a c_void_p object per argument costs more
+    than the rest of the marshalling)."""
+    return 0 if t is None else t.data_ptr()
+
+
+try:  # the stream handle without constructing a torch.cuda.Stream per call (what torch's own inductor / triton launchers use)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+    _current_device = torch._C._cuda_getDevice
+except AttributeError:  # pragma: no cover - other torch builds
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+
+    def _current_device():
+        return torch.cuda.current_device()
+
+
+class _DeviceGuard:
+    """``with torch.cuda.device(d)`` only when ``d`` is not already current: the context manager costs ~3 us per call, the check 0.2."""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, device: torch.device):
+        self.ctx = None if device.index is None or device.index == _current_device() else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 class _Bindings:
@@ -124,7 +156,7 @@ class _Bindings:
 
     @staticmethod
     def _stream(t: torch.Tensor):
-        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        return ctypes.c_void_p(_raw_stream(t.device.index if t.device.index is not None else _current_device()))
 
     @staticmethod
     def _require_cuda(*tensors):
@@ -257,11 +289,26 @@ class _Bindings:
             return None, 0
         return self._scratch(x.device, nbytes, self._stream(x).value), nbytes
 
-    def qbytes_conv2d_supported(self, x, w) -> bool:
-        """What the kernel takes: NCHW 16-bit activations, an 8-bit OCP weight, cin * KH * KW a multiple of the K-tile (64), windows of up to 64 taps."""
+    @classmethod
+    def conv2d_geometry_ok(cls, x_shape, w_shape, stride, padding, dilation) -> bool:
+        """Python mirror of ``conv::geometry_ok`` (csrc/qconv_mfma.hip): what the implicit-GEMM kernels index with 31-bit offsets and one grid
+        dimension.  Beyond these limits the C entry returns ENOTSUP; the callers ask here first and keep the im2col / reference path instead."""
+        B, C, H, W = x_shape
+        OC, _, KH, KW = w_shape
+        if min(stride) <= 0 or min(dilation) <= 0 or min(padding) < 0:
+            return False
+        OH = cls.conv2d_out_size(H, KH, stride[0], padding[0], dilation[0])
+        OW = cls.conv2d_out_size(W, KW, stride[1], padding[1], dilation[1])
+        K = C * KH * KW
+        return (B >= 1 and OH >= 1 and OW >= 1 and K % 64 == 0 and KH * KW <= 64 and B * C * H * W < (1 << 30) and B * OC * OH * OW < (1 << 31)
+                and OC * K < (1 << 31) and (B * OH * OW + 127) // 128 <= 65535)
+
+    def qbytes_conv2d_supported(self, x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)) -> bool:
+        """What the kernel takes: NCHW 16-bit activations, an 8-bit OCP weight whose rows start on 16-byte boundaries, and a geometry within
+        ``conv2d_geometry_ok`` (C * KH * KW a multiple of the K-tile, windows of up to 64 taps, 31-bit offsets)."""
         return (x.is_cuda and x.dim() == 4 and w.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and
-                w.dtype in (torch.int8, torch.float8_e4m3fn, torch.float8_e5m2) and (w.shape[1] * w.shape[2] * w.shape[3]) % 64 == 0 and
-                w.shape[2] * w.shape[3] <= 64)
+                w.dtype in (torch.int8, torch.float8_e4m3fn, torch.float8_e5m2) and (not w.is_contiguous() or w.data_ptr() % 16 == 0) and
+                self.conv2d_geometry_ok(tuple(x.shape), tuple(w.shape), stride, padding, dilation))
 
     def qbytes_conv2d(self, x, w, scales, bias, stride, padding, dilation):
         """Dense convolution with an 8-bit weight [OC, C, KH, KW] and per-channel scales: im2col happens inside the kernel's staging loads."""
@@ -286,13 +333,14 @@ class _Bindings:
         return y
 
     # -- quanto::qbits_conv2d (implicit GEMM, int4 dequantized while staged) -----------------------------------
-    def qbits_conv2d_supported(self, x, weight_size, bits: int, group_size) -> bool:
-        """NCHW 16-bit activations, generic packed int4 weight [OC, C, KH, KW] with OC even, C * KH * KW a multiple of 64 and groups of a
-        multiple of 8 (or per-channel scales), windows of up to 64 taps."""
+    def qbits_conv2d_supported(self, x, weight_size, bits: int, group_size, stride=(1, 1), padding=(0, 0), dilation=(1, 1)) -> bool:
+        """NCHW 16-bit activations, generic packed int4 weight [OC, C, KH, KW] with OC even and groups of a multiple of 8 (or per-channel scales),
+        geometry within ``conv2d_geometry_ok``."""
         oc, c, kh, kw = weight_size
         k = c * kh * kw
-        return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and bits == 4 and oc % 2 == 0 and k % 64 == 0 and
-                kh * kw <= 64 and (not group_size or (group_size % 8 == 0 and k % group_size == 0)))
+        return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and bits == 4 and oc % 2 == 0 and
+                (not group_size or (group_size % 8 == 0 and k % group_size == 0)) and oc * (k // (group_size or k)) < (1 << 31) and
+                self.conv2d_geometry_ok(tuple(x.shape), tuple(weight_size), stride, padding, dilation))
 
     def qbits_conv2d(self, x, packed, scale, shift, bias, bits: int, group_size, weight_size, stride, padding, dilation):
         """Dense convolution with a generic packed int4 weight (its [OC, C, KH, KW] shape in ``weight_size``): im2col inside the staging loads,
@@ -344,38 +392,67 @@ class _Bindings:
         return out
 
     # -- quanto::qbits_mm ---------------------------------------------------------------------------
+    def _plan(self, which: str, key, call):
+        """(kernel, workspace bytes) of a call shape, asked from the library once per (shape, format, dtype, forced kernel) and kept: the
+        choice is a pure function of those (csrc/c_api.hip: pick_q*_kernel; with QUANTO_HIP_EXPERIMENT the knobs may change between calls, so
+        nothing is kept then)."""
+        cache = self.__dict__.setdefault("_plans", {})
+        hit = cache.get((which, key))
+        if hit is not None:
+            return hit
+        k_out, ws_out = ctypes.c_int(0), ctypes.c_int64(0)
+        st = call(ctypes.byref(k_out), ctypes.byref(ws_out))
+        if st != 0:
+            self._check(st, which + "_plan")
+        plan = (k_out.value, ws_out.value)
+        if not _EXPERIMENT:
+            if len(cache) > 4096:
+                cache.clear()
+            cache[(which, key)] = plan
+        return plan
+
     def qbits_mm(self, x, packed, scale, shift, bias, bits: int, group_size, out_features: int, in_features: int,
                  kernel: str = "auto"):
-        self._require_cuda(x, packed, scale, shift, bias)
-        if x.dtype != scale.dtype:
-            x = x.to(scale.dtype)
-        lead = x.shape[:-1]
-        x2 = x.reshape(-1, in_features).contiguous()
-        packed, scale, shift = packed.contiguous(), scale.contiguous(), shift.contiguous()
-        if bias is not None:
-            bias = bias.to(scale.dtype).contiguous()
+        if not (x.is_cuda and packed.is_cuda and scale.is_cuda and shift.is_cuda and (bias is None or bias.is_cuda)):
+            raise QuantoHipError("quanto_hip kernels only accept tensors on a ROCm device")
+        sdt = scale.dtype
+        if x.dtype != sdt:
+            x = x.to(sdt)
+        x2 = x if x.dim() == 2 and x.is_contiguous() else x.reshape(-1, in_features).contiguous()
+        if not packed.is_contiguous():
+            packed = packed.contiguous()
+        if not scale.is_contiguous():
+            scale = scale.contiguous()
+        if not shift.is_contiguous():
+            shift = shift.contiguous()
+        if bias is not None and (bias.dtype != sdt or not bias.is_contiguous()):
+            bias = bias.to(sdt).contiguous()
         M = x2.shape[0]
-        y = torch.empty((M, out_features), dtype=scale.dtype, device=x.device)
-        k_out, ws_out = ctypes.c_int(0), ctypes.c_int64(0)
-        with torch.cuda.device(x.device):
-            st = self._c.quanto_hip_qbits_mm_plan(M, out_features, in_features, bits, group_size or 0, _dt(scale), KERNELS[kernel],
-                                                  ctypes.byref(k_out), ctypes.byref(ws_out))
-            if st != 0:
-                self._check(st, "qbits_mm_plan")
-            k, ws_bytes = k_out.value, ws_out.value
-            if kernel == "auto" and (x2.data_ptr() | packed.data_ptr()) % 16:
-                k, ws_bytes = KERNEL_NAIVE, 0  # misaligned view: the kernel without an alignment requirement (what AUTO does in C)
+        gs = group_size or 0
+        dt, zdt = _DTYPES.get(sdt), _DTYPES.get(shift.dtype)
+        if dt is None or zdt is None:
+            raise QuantoHipError(f"quanto_hip: unsupported dtype {sdt if dt is None else shift.dtype}")
+        y = torch.empty((M, out_features), dtype=sdt, device=x.device)
+        c = self._c
+        k, ws_bytes = self._plan("qbits_mm", (M, out_features, in_features, bits, gs, dt, kernel),
+                                 lambda ko, wo: c.quanto_hip_qbits_mm_plan(M, out_features, in_features, bits, gs, dt, KERNELS[kernel], ko, wo))
+        xp, pp = x2.data_ptr(), packed.data_ptr()
+        if kernel == "auto" and (xp | pp) % 16:
+            k, ws_bytes = KERNEL_NAIVE, 0  # misaligned view: the kernel without an alignment requirement (what AUTO does in C)
+        index = x.device.index
+        with _DeviceGuard(x.device):
+            stream = _raw_stream(index if index is not None else _current_device())
             if ws_bytes == 0:
-                ws = None
+                wp = 0
             elif k in (KERNEL_SKINNY, KERNEL_MFMA_FUSED4):
-                ws = self._zeroed_workspace(x.device, ws_bytes, self._stream(x).value)  # split-K arrival counters: zero on entry, left zero by the kernel
+                wp = self._zeroed_workspace(x.device, ws_bytes, stream).data_ptr()  # split-K arrival counters: zero on entry, left zero by the kernel
             else:
-                ws = self._scratch(x.device, ws_bytes, self._stream(x).value)
-            st = self._c.quanto_hip_qbits_mm(
-                _ptr(x2), _ptr(packed), _ptr(scale), _ptr(shift), _ptr(bias), _ptr(y), M, out_features, in_features,
-                bits, group_size or 0, _dt(scale), _dt(shift), k, _ptr(ws), ws_bytes, self._stream(x))
-        self._check(st, "qbits_mm")
-        return y.reshape(*lead, out_features)
+                wp = self._scratch(x.device, ws_bytes, stream).data_ptr()
+            st = c.quanto_hip_qbits_mm(xp, pp, scale.data_ptr(), shift.data_ptr(), 0 if bias is None else bias.data_ptr(), y.data_ptr(), M,
+                                       out_features, in_features, bits, gs, dt, zdt, k, wp, ws_bytes, stream)
+        if st != 0:
+            self._check(st, "qbits_mm")
+        return y if x.dim() == 2 else y.reshape(*x.shape[:-1], out_features)
 
     # -- quanto::qbits_mm_multi ---------------------------------------------------------------------
     MAX_MULTI = 4  # QUANTO_HIP_MAX_MULTI
@@ -466,34 +543,40 @@ class _Bindings:
 
     # -- quanto::qbytes_mm --------------------------------------------------------------------------
     def qbytes_mm(self, a, b, scales, bias=None, kernel: str = "auto"):
-        self._require_cuda(a, b, scales, bias)
+        if not (a.is_cuda and b.is_cuda and scales.is_cuda and (bias is None or bias.is_cuda)):
+            raise QuantoHipError("quanto_hip kernels only accept tensors on a ROCm device")
         N, K = b.shape
         if scales.numel() != N:
             raise QuantoHipError(f"qbytes_mm expects one scale per output feature ({N}), got {tuple(scales.shape)}")
-        lead = a.shape[:-1]
-        if a.dtype.is_floating_point and a.dtype.itemsize > 1 and a.dtype != scales.dtype:
-            a = a.to(scales.dtype)  # library/qbytes_mm.py:26
-        a2 = a.reshape(-1, K).contiguous()
-        b, s = b.contiguous(), scales.reshape(-1).contiguous()
-        if bias is not None:
-            bias = bias.to(scales.dtype).contiguous()
+        sdt = scales.dtype
+        if a.dtype.is_floating_point and a.dtype.itemsize > 1 and a.dtype != sdt:
+            a = a.to(sdt)  # library/qbytes_mm.py:26
+        a2 = a if a.dim() == 2 and a.is_contiguous() else a.reshape(-1, K).contiguous()
+        if not b.is_contiguous():
+            b = b.contiguous()
+        s = scales if scales.dim() == 1 and scales.is_contiguous() else scales.reshape(-1).contiguous()
+        if bias is not None and (bias.dtype != sdt or not bias.is_contiguous()):
+            bias = bias.to(sdt).contiguous()
         M = a2.shape[0]
-        y = torch.empty((M, N), dtype=scales.dtype, device=a.device)
-        k_out, ws_out = ctypes.c_int(0), ctypes.c_int64(0)
-        with torch.cuda.device(a.device):
-            st = self._c.quanto_hip_qbytes_mm_plan(M, N, K, _dt(a2), _dt(b), _dt(s), KERNELS[kernel], ctypes.byref(k_out), ctypes.byref(ws_out))
-            if st != 0:
-                self._check(st, "qbytes_mm_plan")
-            k, ws_bytes = k_out.value, ws_out.value
-            if kernel == "auto" and (a2.data_ptr() | b.data_ptr()) % 16:
-                k, ws_bytes = KERNEL_NAIVE, 0  # misaligned view: the kernel without an alignment requirement (what AUTO does in C)
-            ws = None
-            if ws_bytes > 0:
-                ws = self._zeroed_workspace(a.device, ws_bytes, self._stream(a).value)  # split-K arrival counters: zero on entry, left zero
-            st = self._c.quanto_hip_qbytes_mm_ws(_ptr(a2), _ptr(b), _ptr(s), _ptr(bias), _ptr(y), M, N, K, _dt(a2), _dt(b),
-                                                 _dt(s), k, _ptr(ws), max(ws_bytes, 0), self._stream(a))
-        self._check(st, "qbytes_mm")
-        return y.reshape(*lead, N)
+        adt, bdt, odt = _DTYPES.get(a2.dtype), _DTYPES.get(b.dtype), _DTYPES.get(sdt)
+        if adt is None or bdt is None or odt is None:
+            raise QuantoHipError(f"quanto_hip: unsupported dtype in qbytes_mm({a2.dtype}, {b.dtype}, {sdt})")
+        y = torch.empty((M, N), dtype=sdt, device=a.device)
+        c = self._c
+        k, ws_bytes = self._plan("qbytes_mm", (M, N, K, adt, bdt, odt, kernel),
+                                 lambda ko, wo: c.quanto_hip_qbytes_mm_plan(M, N, K, adt, bdt, odt, KERNELS[kernel], ko, wo))
+        ap, bp = a2.data_ptr(), b.data_ptr()
+        if kernel == "auto" and (ap | bp) % 16:
+            k, ws_bytes = KERNEL_NAIVE, 0  # misaligned view: the kernel without an alignment requirement (what AUTO does in C)
+        index = a.device.index
+        with _DeviceGuard(a.device):
+            stream = _raw_stream(index if index is not None else _current_device())
+            wp = self._zeroed_workspace(a.device, ws_bytes, stream).data_ptr() if ws_bytes > 0 else 0  # split-K arrival counters: zero on entry, left zero
+            st = c.quanto_hip_qbytes_mm_ws(ap, bp, s.data_ptr(), 0 if bias is None else bias.data_ptr(), y.data_ptr(), M, N, K, adt, bdt, odt, k, wp,
+                                           max(ws_bytes, 0), stream)
+        if st != 0:
+            self._check(st, "qbytes_mm")
+        return y if a.dim() == 2 else y.reshape(*a.shape[:-1], N)
 
 
 class QuantoHipExtension(NativeLibrary):
@@ -505,7 +588,7 @@ class QuantoHipExtension(NativeLibrary):
             "quanto_hip",
             root_dir=csrc,
             lib_path=os.path.join(_PKG_DIR, "lib", "libquanto_hip.so"),
-            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qconv_mfma.hip", "qmm_mfma_large.hip", "qmm_mfma_large32.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbits_mfma_large.hip", "qbytes_skinny.hip", "qmm_native8.hip", "quantize.hip",
+            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qconv_mfma.hip", "qmm_mfma_large.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbits_mfma_large.hip", "qbytes_skinny.hip", "qmm_native8.hip", "quantize.hip",
                      "qh_common.h", os.path.join("..", "..", "include", "quanto_hip.h")],
         )
         self._bindings = None

@@ -20,13 +20,14 @@ def _set_module_by_name(parent: torch.nn.Module, name: str, child: torch.nn.Modu
 def _quantize_submodule(model, name, module, weights=None, activations=None, optimizer=None):
     qmodule = quantize_module(module, weights=weights, activations=activations, optimizer=optimizer)
     if qmodule is None:
-        return
+        return False
     _set_module_by_name(model, name, qmodule)
     qmodule.name = name
     for pname, param in module.named_parameters():
         # the quantized module aliases the parameters: release the originals
         setattr(module, pname, None)
         del param
+    return True
 
 
 def _as_patterns(p: Optional[Union[str, List[str]]]):
@@ -64,13 +65,16 @@ def requantize(model: torch.nn.Module, state_dict: Dict[str, Any], quantization_
         device = next(model.parameters()).device
         if device.type == "meta":
             device = torch.device("cpu")
+    not_rebuilt = []
     for name, module in list(model.named_modules()):
         qconfig = quantization_map.get(name)
         if qconfig is None:
             continue
         weights = None if qconfig["weights"] == "none" else qconfig["weights"]
         activations = None if qconfig["activations"] == "none" else qconfig["activations"]
-        _quantize_submodule(model, name, module, weights=weights, activations=activations)
+        if not _quantize_submodule(model, name, module, weights=weights, activations=activations):
+            not_rebuilt.append(f"{name} ({type(module).__name__})")
+    missing = sorted(set(quantization_map) - {n for n, _ in model.named_modules()})
     # Materialise what is still on the meta device, then load.  The float ``weight`` of a module whose quantized weight is in the
     # state dict is never materialised (the reference stages everything on the CPU, quantize.py:123-137; on the device that would
     # cost the full float model next to the quantized one): it stays on meta until ``load_state_dict(assign=True)`` replaces it.
@@ -95,7 +99,21 @@ def requantize(model: torch.nn.Module, state_dict: Dict[str, Any], quantization_
     # ... including a quantized module's weight: its scale (and float shift) follow the dtype the module was built in, so that a
     # checkpoint saved in another float dtype does not leave bias / activations in one dtype and the weight's scale in another
     qdtype = {name: m.weight.dtype for name, m in model.named_modules() if isinstance(m, QModuleMixin) and m.weight is not None}
-    model.load_state_dict(state_dict, strict=False, assign=True)
+    loaded = model.load_state_dict(state_dict, strict=False, assign=True)
+    # A checkpoint written by the reference may quantize module types this package has no counterpart for (the reference's QLayerNorm,
+    # nn/qlayernorm.py): loading it silently would compute something else than what was saved - say so, loudly.
+    if not_rebuilt or missing or loaded.unexpected_keys:
+        import warnings
+
+        parts = []
+        if not_rebuilt:
+            parts.append("no quantized counterpart for " + ", ".join(not_rebuilt[:4]) + (f" and {len(not_rebuilt) - 4} more" if len(not_rebuilt) > 4 else "")
+                         + " (kept as float modules: their input / output scales are dropped)")
+        if missing:
+            parts.append("quantization_map names modules the model does not have: " + ", ".join(missing[:4]))
+        if loaded.unexpected_keys:
+            parts.append(f"{len(loaded.unexpected_keys)} state-dict entries were not used, e.g. " + ", ".join(list(loaded.unexpected_keys)[:4]))
+        warnings.warn("requantize: the rebuilt model differs from the checkpoint - " + "; ".join(parts), UserWarning)
     for k, v in list(model.named_parameters()) + list(model.named_buffers()):
         if k in want and type(v.data) is torch.Tensor and v.is_floating_point() and v.dtype != want[k]:
             v.data = v.data.to(want[k])

@@ -28,9 +28,32 @@ from .packing import PackedTensor
 __all__ = ["WeightQBytesTensor", "WeightQBitsTensor", "quantize_weight"]
 
 
+class _NoCtx:
+    """Stands in for the autograd context when a linear function's ``forward`` is called directly (nothing is saved: no backward will run)."""
+
+    @staticmethod
+    def save_for_backward(*tensors):
+        pass
+
+
+_NO_CTX = _NoCtx()
+
+
+def _wants_grad(input, weight, bias) -> bool:
+    return torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad))
+
+
+def _pair(v):
+    """``int`` or 1- / 2-element sequence -> [h, w] (torch accepts ``stride=(2,)`` for a 2-D convolution)."""
+    if isinstance(v, int):
+        return [v, v]
+    v = [int(e) for e in v]
+    return v * 2 if len(v) == 1 else v
+
+
 def conv2d_patches(input, kernel_size, stride, padding, dilation):
     """im2col: NCHW ``input`` -> ([B*L, C*kh*kw] rows in the weight's (c, i, j) order, output height, output width)."""
-    pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+    pair = lambda v: tuple(_pair(v))  # noqa: E731
     (kh, kw), stride, padding, dilation = pair(kernel_size), pair(stride), pair(padding), pair(dilation)
     b, c, h, w = input.shape
     oh = (h + 2 * padding[0] - dilation[0] * (kh - 1) - 1) // stride[0] + 1
@@ -53,9 +76,10 @@ def _implicit_conv2d(input, weight, scale, bias, stride, padding, dilation, grou
         return None
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (input, weight, bias)):
         return None
-    if weight.dim() != 4 or input.shape[1] != weight.shape[1] or not quanto_hip.lib.qbytes_conv2d_supported(input, weight._data):
+    stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    if weight.dim() != 4 or input.shape[1] != weight.shape[1] or not quanto_hip.lib.qbytes_conv2d_supported(input, weight._data, stride, padding, dilation):
         return None
-    pair = lambda v: [v, v] if isinstance(v, int) else list(v)  # noqa: E731
+    pair = _pair
     if tuple(weight.shape[2:]) == (1, 1) and pair(stride) == [1, 1] and pair(padding) == [0, 0] and weight.shape[1] < 128:
         # pointwise with ONE K-tile: the "patches" are a permuted view of the input, one copy + the tuned GEMM kernels is ahead ((8,64,56,56) -> 256:
         # 21.5 vs 25.0 us); from two K-tiles on the convolution kernel is ((8,256,56,56) -> 64: 14.9 vs 37.6, (8,512,28,28) -> 128: 19.4 vs 29.2)
@@ -75,9 +99,12 @@ def _implicit_conv2d_qbits(input, weight, bias, stride, padding, dilation, group
     packed = weight._data
     if weight.dim() != 4 or input.shape[1] != weight.shape[1] or input.dtype != weight._scale.dtype:
         return None
-    if not quanto_hip.lib.qbits_conv2d_supported(input, tuple(weight.shape), packed.bits, weight._group_size):
+    stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    if not quanto_hip.lib.qbits_conv2d_supported(input, tuple(weight.shape), packed.bits, weight._group_size, stride, padding, dilation):
         return None
-    pair = lambda v: [v, v] if isinstance(v, int) else list(v)  # noqa: E731
+    if packed._data.data_ptr() % 8:
+        return None  # a view the kernel's 8-byte weight loads cannot take: the im2col / reference path copes
+    pair = _pair
     if tuple(weight.shape[2:]) == (1, 1) and pair(stride) == [1, 1] and pair(padding) == [0, 0] and weight.shape[1] < 128:
         return None  # pointwise with one K-tile: a permuted view of the input + the tuned GEMM kernels (see _implicit_conv2d)
     return torch.ops.quanto.qbits_conv2d(input, packed._data, weight._scale, weight._shift, bias, packed.bits, weight._group_size,
@@ -209,6 +236,8 @@ class WeightQBytesTensor(QBytesTensor):
         kwargs = kwargs or {}
         if func is torch.nn.functional.linear:
             def qlinear(input, other, bias=None):
+                if not _wants_grad(input, other, bias):  # inference: the op itself, no autograd.Function node around it (~3 us per call)
+                    return WeightQBytesLinearFunction.forward(_NO_CTX, input, other, bias)
                 return WeightQBytesLinearFunction.apply(input, other, bias)
 
             return qlinear(*args, **kwargs)
@@ -401,6 +430,8 @@ class WeightQBitsTensor(QBitsTensor):
         if func is torch.nn.functional.linear:
             def qlinear(input, other, bias=None):
                 if _fusable(other):
+                    if not _wants_grad(input, other, bias):  # inference: see WeightQBytesTensor
+                        return WeightQBitsLinearFunction.forward(_NO_CTX, input, other, bias)
                     return WeightQBitsLinearFunction.apply(input, other, bias)
                 return QuantizedLinearFunction.apply(input, other, bias)
 

@@ -1,3 +1,6 @@
+// NOT part of libquanto_hip.so since r5 (the r2 experiment behind DESIGN 4.3a: same tile on v_mfma_f32_32x32x16, 7.5 % slower at the part's power limit).
+// Kept as a probe: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I optimum_quanto_amd/csrc -c scripts/probes/qmm_mfma_large32.hip
+//
 // qbytes_mm MFMA GEMM on v_mfma_f32_32x32x16_{bf16,f16}: 256x256x64 tile, eight waves as 2 (tokens) x 4 (features), each
 // owning 128 tokens x 64 features = 2 x 4 accumulator blocks of 32 x 32 (128 accumulator registers).
 //

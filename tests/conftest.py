@@ -15,6 +15,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: timing assertion on a real MI355X (run with -m perf; kept out of the -m gpu parity run)")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -24,6 +24,14 @@ def test_gpus_2_spawns_two_ranks_over_gloo():
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["data"] == "stub"
 
 
+def test_gpus_8_stub_spawns_eight_ranks():
+    """What the driver does on an 8-GPU node, without the GPUs: eight ranks over gloo, barrier + max-over-ranks timing, ONE line from rank 0."""
+    r = _run("--gpus", "8", "--stub", "--steps", "2", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 8
+
+
 def test_gpus_2_without_a_device_reaches_the_process_group_then_fails_loudly():
     r = _run("--gpus", "2", "--steps", "1", "--warmup", "0")
     if r.returncode == 0:  # a box with two GPUs: the real thing ran
@@ -45,7 +53,7 @@ def test_default_line_fits_the_driver_tail():
         flops, nbytes = bench.algorithmic_work(kind, M, K, N)
         roof = {"bound": "hbm", "achieved": 1234.5, "peak": 8000.0, "unit": "GB/s", "frac": 0.1543, "traffic": 123456789, "kernel": "skinny_multi",
                 "launch_us": 12.345, "event_us": 12.123, "kernel_us": 10.123, "kernel_us_min": 9.876, "algorithmic_bytes": nbytes,
-                "algorithmic_flops": flops, "traffic_source": "x" * 150}
+                "algorithmic_flops": flops}
         cpu = {"kind": "reference", "cores": 128, "path": "int4_generic", "value": 1.23456, "unit": "GB/s", "sample": "full call, 50 timed calls after 3 warm-up",
                "seconds_per_call": 0.123456, "iqr_s": 0.012345, "calls_timed": 50,
                "tinygemm": {"seconds_per_call": 0.000123, "iqr_s": 1e-6, "calls": 200, "value": 123.456, "unit": "GB/s"}}
@@ -61,23 +69,27 @@ def test_default_line_fits_the_driver_tail():
                 "cache_resident_us_per_layer": 123.456, "cache_resident_GBs": 12345.6}
 
     out = fake("cfg2")
-    out["cpu_baseline"]["how"] = bench.CPU_BASELINE_NOTE["reference"]
+    out["cpu_baseline"]["how"] = "x" * 160
     out["sub_results"] = [fake_layer(n) if n in bench.LAYER_WORKLOADS else bench.compact(fake(n)) for n in bench.DEFAULT_SUB]
     for sr in out["sub_results"]:
         bench.apply_profile(sr, {"kernel_us": 12.345, "kernel_us_min": 11.234, "traffic": 123456789}, compacted=True)
+    out["sub_results"].append({"name": "qconv2d_3x3", "shape": "(8,128,28,28)->128 3x3 pad 1", "M": 6272, "K": 1152, "N": 128, "alg_flops": 1849688064, "steps": 50,
+                               "kernel_us": 12.345, "kernel_us_min": 12.345, "traffic": 123456789, "int8_us": 12.34, "int8_kernel": "conv2d_mfma",
+                               "int8_alg_bytes": 3358976, "int8_frac_mfma": 0.0299, "int8_frac_hbm": 0.0123, "ref_rocm_int8_us": 12.34, "int4_us": 12.34,
+                               "int4_kernel": "conv2d_mfma_int4", "int4_alg_bytes": 3358976, "int4_frac_mfma": 0.0299, "int4_frac_hbm": 0.0123,
+                               "ref_rocm_int4_us": 12.34, "bound": "x" * 75, "ref_rocm": "x" * 65})
     out["sub_results"].append({"name": "cfg5", "model": "Llama-3-8B random-init bf16, qint4 g128, lm_head excluded", "prompt": 512,
                                "new_tokens": 512, "method": "generate(), greedy, eos off, prefill included (latency.py:24-105)",
                                "fused_groups": 64, "build_s": 12.3, "int4_bytes_per_token": 3706716160, "b1_tok_s": 123.4, "b1_ms_per_token": 12.345,
-                               "b32_tok_s": 1234.5, "b32_ms_per_token": 12.345})
-    out["profile_passes"] = {"ok": True, "seconds": 123.4, "what": "rocprofv3 --kernel-trace, --pmc FETCH_SIZE, --pmc WRITE_SIZE child runs of this file"}
-    out["cpu_paths"] = dict(bench.CPU_BASELINE_NOTE)
-    out["layer_decode_note"] = "x" * 230
+                               "b32_tok_s": 1234.5, "b32_ms_per_token": 12.345, "b1_qh_kernel_ms_per_token": 1.234, "b32_qh_kernel_ms_per_token": 1.234,
+                               "host_us_per_call": {"module": 12.3, "F_linear": 12.3, "op": 12.3, "binding": 12.3, "c_entry": 12.3}})
+    out["profile_passes"] = {"ok": True, "seconds": 123.4, "what": "x" * 190}
     line = json.dumps(out, separators=(",", ":"))
-    assert len(line) < 7600, len(line)  # the driver keeps an 8 KB stdout tail
-    for sr in out["sub_results"]:  # enough to recompute every fraction from the line alone
+    assert len(line) < 7900, len(line)  # the driver keeps an 8 KB stdout tail
+    for sr in out["sub_results"]:  # enough to recompute every fraction from the line alone (alg_flops = 2 M sum(N) K)
         if sr["name"] in bench.WORKLOADS:
-            assert {"name", "us_per_step", "event_us", "kernel_us", "frac", "alg_bytes", "alg_flops", "kernel", "traffic", "cpu"} <= set(sr)
-    assert {"northstar", "cfg3", "cfg4", "layer_decode_b1", "layer_decode_b32", "cfg5"} <= {sr["name"] for sr in out["sub_results"]}
+            assert {"name", "M", "K", "N", "us_per_step", "event_us", "kernel_us", "frac", "alg_bytes", "kernel", "traffic", "cpu"} <= set(sr)
+    assert {"northstar", "cfg3", "cfg4", "cfg4_fp8a8", "w8a8", "fp8a8", "int4_prefill", "layer_decode_b1", "layer_decode_b32", "cfg5"} <= {sr["name"] for sr in out["sub_results"]}
 
 
 def test_world_size_from_the_launcher_is_enough():

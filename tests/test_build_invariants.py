@@ -1,0 +1,31 @@
+"""Build-time invariants of libquanto_hip.so that no run-time test would notice except by luck.
+
+``profiles/r05_packed_fp32_op_sel_next_to_mfma.md``: on gfx950 a ``v_pk_{add,mul}_f32`` whose ``op_sel`` takes the HIGH half of a 64-bit source
+returns a wrong value in lanes 48-63 once in 10^3..10^7 executions while MFMAs are in flight on the SIMD (stand-alone reproducer:
+``scripts/probes/pk_f32_opsel_probe.hip``).  hipcc's SLP vectorizer produces exactly that form from adjacent scalar fp32 math, so the kernels that do
+fp32 conversion math between MFMAs are compiled with ``-fno-slp-vectorize`` (csrc/Makefile) and written on scalars.  This test fails when a
+toolchain or a source edit brings packed fp32 instructions with ``op_sel`` back into those translation units."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "optimum_quanto_amd", "csrc")
+HAVE_HIPCC = shutil.which("hipcc") is not None or os.path.exists("/opt/rocm/bin/hipcc")
+
+
+@pytest.mark.skipif(not HAVE_HIPCC, reason="needs hipcc")
+@pytest.mark.parametrize("unit", ["qbits_mfma_large", "qconv_mfma", "qmm_mfma"])
+def test_no_packed_fp32_with_op_sel_next_to_mfmas(unit):
+    listing = os.path.join(CSRC, "build", unit + ".s")
+    proc = subprocess.run(["make", "-C", CSRC, f"build/{unit}.s"], capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    text = open(listing).read()
+    assert "v_mfma_f32_16x16x32" in text  # the listing is the device code of an MFMA kernel
+    packed = [ln.strip() for ln in text.splitlines() if re.search(r"\bv_pk_(add|mul|fma)_f32\b", ln)]
+    risky = [ln for ln in packed if "op_sel" in ln]
+    assert not risky, f"{unit}: {len(risky)} packed fp32 instructions with op_sel, e.g. {risky[:3]}"
+    assert not packed, f"{unit}: hipcc re-packed scalar fp32 math ({len(packed)} v_pk_*_f32): is -fno-slp-vectorize still applied?"

@@ -31,6 +31,9 @@ def test_quantize_generate_save_reload(tmp_path):
         out = qmodel.generate(input_ids=ids, max_new_tokens=4, do_sample=False)
     assert out.shape == (2, 12)
     qmodel.save_pretrained(tmp_path)
+    import json
+    cfg = json.load(open(tmp_path / "config.json"))  # the compute dtype travels in config.json under the name this transformers serialises
+    assert "float32" in (str(cfg.get("dtype")), str(cfg.get("torch_dtype")))
     again = Q.QuantizedModelForCausalLM.from_pretrained(tmp_path)
     assert isinstance(again.model.layers[0].self_attn.q_proj.weight, Q.WeightQBitsTensor)
     with torch.no_grad():

@@ -331,6 +331,49 @@ def test_qlinear_quantize_freeze_state_dict_roundtrip():
     assert out.dtype == torch.bfloat16 and (out.float() - y).abs().max() < 0.05 * y.abs().max()
 
 
+def test_requantize_says_what_it_could_not_rebuild():
+    """A reference checkpoint may quantize module types this package has no counterpart for (the reference's QLayerNorm) and carry
+    their input / output scales: requantize must not drop them silently."""
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(64, 32), torch.nn.LayerNorm(32))
+    Q.quantize(model, weights=Q.qint8, exclude="1")
+    Q.freeze(model)
+    sd, qmap = model.state_dict(), Q.quantization_map(model)
+    qmap["1"] = {"weights": "none", "activations": "qint8"}  # what the reference writes for a quantized LayerNorm ...
+    sd["1.input_scale"], sd["1.output_scale"] = torch.ones(()), torch.ones(())  # ... with its calibrated scales
+    qmap["ghost"] = {"weights": "qint8", "activations": "none"}
+    fresh = torch.nn.Sequential(torch.nn.Linear(64, 32), torch.nn.LayerNorm(32))
+    with pytest.warns(UserWarning) as rec:
+        Q.requantize(fresh, sd, qmap)
+    text = " ".join(str(w.message) for w in rec)
+    assert "1 (LayerNorm)" in text and "ghost" in text and "1.input_scale" in text
+    assert isinstance(fresh[0], Q.QLinear) and torch.equal(fresh[0].weight._data, model[0].weight._data)
+
+
+def test_conv2d_geometry_gate_mirrors_the_kernel_limits():
+    """library/hip.py asks conv2d_geometry_ok before routing a QConv2d to the implicit-GEMM kernels; the limits are the kernel's
+    (31-bit offsets, one grid dimension of 65535 tiles of 128 pixels): beyond them the call keeps the im2col / reference path
+    instead of surfacing ENOTSUP as an error."""
+    from optimum_quanto_amd.library.hip import _Bindings
+
+    ok = _Bindings.conv2d_geometry_ok
+    one = ((1, 1), (0, 0), (1, 1))
+    assert ok((8, 128, 28, 28), (128, 128, 3, 3), (1, 1), (1, 1), (1, 1))
+    assert not ok((8, 3, 224, 224), (64, 3, 7, 7), (2, 2), (3, 3), (1, 1))      # K = 147: not a multiple of the K-tile
+    assert not ok((1, 64, 32, 32), (64, 64, 9, 9), *one)                        # 81 taps
+    assert ok((8, 64, 1024, 1023), (64, 64, 1, 1), *one)                        # 65472 tiles of 128 pixels ...
+    assert not ok((8, 64, 1024, 1024), (64, 64, 1, 1), *one)                    # ... 65536: grid.y
+    assert not ok((16, 64, 1024, 1024), (64, 64, 1, 1), (8, 8), (0, 0), (1, 1))  # 2^30 input elements
+    assert not ok((1, 64, 8, 8), (64, 64, 3, 3), (0, 1), (1, 1), (1, 1))         # stride 0
+    assert not ok((1, 64, 2, 2), (64, 64, 3, 3), *one)                          # empty output
+
+
+def test_conv_pair_normalisation():
+    from optimum_quanto_amd.tensor.weights import _pair
+
+    assert _pair(2) == [2, 2] and _pair((2,)) == [2, 2] and _pair([1, 3]) == [1, 3] and _pair(torch.Size([4])) == [4, 4]
+
+
 def test_group_size_selection_follows_reference():
     from optimum_quanto_amd.nn.module import select_group_size
     assert [select_group_size(k) for k in (4096, 11008, 14336, 160, 96, 128, 200, 192)] == [128, 128, 128, 32, None, None, None, 96]

@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests (CPU) of the column shard: the N > 1 path is correct by construction."""
+"""gloo tests (CPU, world_size 2, 4 and 8) of the column shard: the N > 1 path is correct by construction."""
 import os
 import socket
 
@@ -55,6 +55,17 @@ def test_column_shard_matches_unsharded(weights, dtype):
     assert len(out) == world and all(e <= tol for e in out.values()), dict(out)
 
 
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("weights", ["qint4", "qint2"])
+def test_column_shard_at_4_and_8_ranks(weights, world):
+    """The sub-byte shard cuts the PACKED rows (vpi output features per byte): N must be a multiple of vpi * G and every rank's
+    slice must stay plane-aligned - exercised at the group sizes the driver's 8-GPU node will run."""
+    port = _free_port()
+    out = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker, args=(world, port, weights, torch.float32, out), nprocs=world, join=True)
+    assert len(out) == world and all(e <= 4.0 for e in out.values()), dict(out)
+
+
 def test_shard_layout_is_a_pure_slice():
     import optimum_quanto_amd as Q
     from optimum_quanto_amd.parallel import shard_qweight, _feature_index
@@ -71,3 +82,14 @@ def test_shard_layout_is_a_pure_slice():
             assert torch.equal(local.dequantize(), full[idx])  # same integers, same scales: bit-identical rows
     with pytest.raises(ValueError):
         shard_qweight(qw, 0, 3)
+    # 8 ranks, int2 (four features per packed byte): 64 features = 2 per rank and plane, bit-identical rows again ...
+    scale2, shift2 = Q.MaxOptimizer()(w, qtype=Q.qint2, axis=0, group_size=128)
+    q2 = Q.quantize_weight(w, Q.qint2, 0, scale2, shift2, group_size=128)
+    full2 = q2.dequantize()
+    for rank in range(8):
+        assert torch.equal(shard_qweight(q2, rank, 8).dequantize(), full2[_feature_index(64, 4, rank, 8)])
+    # ... and 48 features cannot be cut into 8 plane-aligned slices of an int2 weight
+    w48 = torch.randn(48, 256)
+    s48, z48 = Q.MaxOptimizer()(w48, qtype=Q.qint2, axis=0, group_size=128)
+    with pytest.raises(ValueError):
+        shard_qweight(Q.quantize_weight(w48, Q.qint2, 0, s48, z48, group_size=128), 0, 8)

@@ -47,6 +47,19 @@ def _check_inner_tensors(golden, key, tag, qw):
     np.testing.assert_array_equal(to_numpy(qw.dequantize()), golden[key + "/wdq"])
 
 
+def _oracle_dequantized(w, dt):
+    """The dense weight the reference would materialise for the packed int4 weight ``w`` - computed by the numpy oracle on the HOST from the
+    packed bytes, scale and shift, so that the convolution gate does not lean on this library's own device dequantize kernel."""
+    from oracle import quanto_oracle as O
+
+    packed = w._data._data.cpu().numpy()
+    shift = w._shift.cpu()
+    shift = shift.numpy() if shift.dtype == torch.uint8 else to_numpy(shift)
+    k = w.numel() // w.shape[0]
+    dq = O.dequantize_qbits_ref(packed, w._data.bits, to_numpy(w._scale.cpu()), shift, 0, w._group_size, (w.shape[0], k), dt)
+    return torch.from_numpy(np.ascontiguousarray(dq, dtype=np.float64)).reshape(tuple(w.shape))
+
+
 @pytest.mark.parametrize("shape", [(16, 32, 3, 1, 1, 1), (8, 24, 3, 2, 0, 1), (4, 8, (3, 5), (2, 1), (1, 2), (1, 2)), (16, 8, 1, 1, 0, 1),
                                    (3, 5, 2, 3, 2, 1)])
 def test_conv2d_patches_times_flat_weight_is_conv2d(shape):
@@ -214,9 +227,9 @@ def test_qconv2d_int4_implicit_gemm_gpu(dt, zp, cin, cout, k, s, p, d, gs):
     with torch.no_grad():
         y = q(x.cuda())
         assert quanto_hip.lib.last_kernel() == "conv2d_mfma_int4"
-        wdq = q.weight.dequantize()
-        assert wdq.dtype == TORCH_DT[dt]
-        prod = torch.nn.functional.conv2d(x.double(), wdq.cpu().double(), None, conv.stride, conv.padding, conv.dilation)
+        wdq = _oracle_dequantized(q.weight, dt)
+        assert torch.equal(q.weight.dequantize().cpu().double(), wdq)  # (and the device dequantize kernel agrees with the oracle bit for bit)
+        prod = torch.nn.functional.conv2d(x.double(), wdq, None, conv.stride, conv.padding, conv.dilation)
     assert y.shape == prod.shape and y.dtype == TORCH_DT[dt]
     bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
     assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), dt, f"int4 implicit conv {cin}->{cout} k{k} g{gs}")
@@ -245,7 +258,7 @@ def test_qconv2d_implicit_gemm_k_split_gpu(monkeypatch, wq, split):
         if wq == "qint8":  # exact integers, the per-channel scale on the accumulator
             prod = torch.nn.functional.conv2d(x.double(), q.weight._data.cpu().double(), None, 1, 1) * q.weight._scale.cpu().double().reshape(1, -1, 1, 1)
         else:              # the weight the reference dequantizes
-            prod = torch.nn.functional.conv2d(x.double(), q.weight.dequantize().cpu().double(), None, 1, 1)
+            prod = torch.nn.functional.conv2d(x.double(), _oracle_dequantized(q.weight, "bf16"), None, 1, 1)
     bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
     assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), "bf16", f"conv K split {split} {wq}")
     if split == 7 and wq == "qint8":  # the C entry without a workspace: same problem, unsplit, same gate
