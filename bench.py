@@ -763,9 +763,10 @@ def trace_child(names, args, device):
     for name in names:
         step, keep = _child_step(name, device)
         with torch.no_grad():
+            torch.cuda.synchronize()
+            lib.unpack(tag, 4)  # opens the warm-up segment (the first call of a workload belongs to it, not to the previous workload's measured one)
             step()
             torch.cuda.synchronize()
-            lib.unpack(tag, 4)
             if graph_mode:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
@@ -914,6 +915,45 @@ def compact(r):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# Batched decode: where the time of the split-K streaming kernel goes (its built-in ablation switches, csrc/qbits_skinny.hip)
+# ------------------------------------------------------------------------------------------------------------------------
+ABLATIONS = (("full", 0), ("no_tail", 1), ("no_tail_no_mfma", 3), ("no_tail_no_mfma_no_hbm", 31))
+
+
+def ablate_child(name, args, device):
+    """``--ablate-child``: a child process with the library's experiment knobs on (they are read only behind QUANTO_HIP_EXPERIMENT, which the
+    parent - and the driver's command - does not set).  Times the same hipGraph replay with QUANTO_HIP_SKINNY_ABLATE = 0 (the product), 1 (no
+    partial-sum store / arrival counter / reduce: every block but split 0 returns after its K loop), 3 (+ no MFMA / LDS-read work: the DMA stream
+    alone), 31 (+ every DMA re-reads tile 0: no HBM traffic, the launch + instruction-issue floor).  Results are WRONG by construction."""
+    kind, M, K, N, _ = WORKLOADS[name]
+    Nt = sum(N) if isinstance(N, tuple) else N
+    n_weights = max(1, -(-(512 << 20) // (Nt * K // 2)))
+    x, sets = build_inputs(kind, M, K, N, device, n_weights, seed=1234)
+    res = {}
+    for label, bits in ABLATIONS:
+        os.environ["QUANTO_HIP_SKINNY_ABLATE"] = str(bits)
+        step = make_step(kind, x, sets, K, N)
+        with torch.no_grad():
+            elapsed, _ = timed_replay(step, 200, args, None, device, warmup=3)
+        res[label] = round(elapsed * 1e6 / 200, 3)
+    os.environ.pop("QUANTO_HIP_SKINNY_ABLATE", None)
+    print(json.dumps({"ablate": res}), flush=True)
+
+
+def run_ablation(name, timeout_s=120):
+    """Parent side: one child run of this file with the experiment switch set; {} when it fails."""
+    import subprocess
+
+    env = dict(os.environ, QUANTO_HIP_EXPERIMENT="1", QH_BENCH_CHILD="1")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--ablate-child", name], env=env, capture_output=True, text=True, timeout=timeout_s)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)["ablate"]
+    except Exception:
+        return {}
+
+
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` with no launcher around it: start N ranks of this same command, one per GPU."""
     import subprocess
@@ -948,6 +988,7 @@ def main():
     ap.add_argument("--profile", action="store_true", help="run the rocprofv3 child passes for a non-default selection of workloads too")
     ap.add_argument("--trace-child", nargs="+", default=None, help=argparse.SUPPRESS)  # the child run of collect_profiles
     ap.add_argument("--trace-mode", default="graph", choices=["graph", "eager"], help=argparse.SUPPRESS)
+    ap.add_argument("--ablate-child", default=None, help=argparse.SUPPRESS)  # the child run of run_ablation
     args = ap.parse_args()
 
     if args.gpus is None:  # an external launcher's WORLD_SIZE is enough (torchrun --nproc-per-node 8 bench.py --shard)
@@ -987,6 +1028,9 @@ def main():
     if args.trace_child is not None:
         trace_child(args.trace_child, args, device)
         return
+    if args.ablate_child is not None:
+        ablate_child(args.ablate_child, args, device)
+        return
     if args.shard:
         out = run_sharded(args, device, rank, world, dist)
     else:
@@ -1014,6 +1058,10 @@ def main():
                 sub_results.append({"name": "cfg4_sharded", "scaling": "strong", "n_gpus": world, "value": r["value"], "unit": r["unit"],
                                     "compute_only_us": r["compute_only_us"], "with_all_gather_us": r["with_all_gather_us"],
                                     "compute_only_tflops": r["compute_only_tflops"], "parallelism": r["config"]["parallelism"]})
+        if world == 1 and rank == 0 and default_run and out is not None:
+            dec = next((sr for sr in sub_results if sr.get("name") == "int4_decode32"), None)
+            if dec is not None:  # us per launch with parts of the kernel switched off: tail = full - no_tail, MFMA work = no_tail - no_tail_no_mfma, ...
+                dec["ablate_us"] = run_ablation("int4_decode32")
         conv_rec = None
         if world == 1 and rank == 0 and default_run and out is not None:
             try:

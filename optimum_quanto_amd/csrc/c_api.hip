@@ -600,7 +600,7 @@ int quanto_hip_pack(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int6
 
 int64_t quanto_hip_conv2d_workspace_size(int64_t B, int64_t OH, int64_t OW, int64_t OC, int64_t K) {
   if (B < 0 || OH < 0 || OW < 0 || OC <= 0 || K <= 0) return -1;
-  if (B == 0 || OH == 0 || OW == 0 || K % 64) return 0;
+  if (B == 0 || OH == 0 || OW == 0) return 0;
   return (int64_t)conv2d_workspace(B * OH * OW, OC, K);
 }
 
@@ -636,7 +636,7 @@ int quanto_hip_qbits_conv2d(const void* x, const uint8_t* packed, const void* sc
   const PackedGeom g = make_geom(OC, K, bits, group_size);
   const int r = qbits_conv2d_mfma(x, packed, scale, shift, bias, y, B, cin, H, W, OC, KH, KW, OH, OW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, g, dtype,
                                   int_shift, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
-  if (r == QUANTO_HIP_OK) set_last_kernel("conv2d_mfma_int4");
+  if (r == QUANTO_HIP_OK) set_last_kernel(bits == 4 ? "conv2d_mfma_int4" : "conv2d_mfma_int2");
   return r;
 }
 

@@ -29,7 +29,13 @@ constexpr int BM = 128, BN = 128, BK = 64, NT = 512;
 constexpr int TILE_BYTES = BM * BK * 2;  // one operand tile in LDS (16 KiB)
 constexpr int LDS_BYTES = 2 * 2 * TILE_BYTES + 2 * BK * 8;
 
-enum WFmt { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2, W_I4R = 3 };
+enum WFmt { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2, W_I4R = 3, W_I2R = 4 };
+constexpr int planes_of(int fmt) { return fmt == W_I4R ? 2 : (fmt == W_I2R ? 4 : 1); }  // values per packed byte
+
+// byte-aligned 8- and 16-byte loads (K = cin KH KW need not be a multiple of anything: an RGB stem has K = 27 or 147): hipcc lowers them to
+// global_load_dwordx2 / x4, which the gfx950 memory pipeline serves at any alignment (unaligned access mode, the HSA default)
+struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U2u { uint32_t x, y; };
 
 // 128-byte rows of eight 16-byte chunks; chunk kc of row r sits at position kc ^ (r & 7): the fragment reads (16 rows x 4 chunks) and the staging
 // writes are conflict-free
@@ -106,6 +112,31 @@ __device__ __forceinline__ void convert8_i4r(const uint2& w, float s_lo, float z
   hi = make_uint4(h[0], h[1], h[2], h[3]);
 }
 
+// 8 packed bytes of an int2 weight -> 8 weights of each of the four planes (bits 2 pl .. 2 pl + 1), dequantized like convert8_i4r
+template <int DT, bool INT_SHIFT>
+__device__ __forceinline__ void convert8_i2r(const uint2& w, const float (&sc)[4], const float (&z)[4], uint4 (&out)[4]) {
+  using E = Elem<DT>;
+  auto deq = [](uint32_t q, float s, float zz) -> float {
+    if constexpr (INT_SHIFT)
+      return s * ((float)q - zz);
+    else
+      return E::to_f32(E::from_f32(s * (float)q)) - zz;
+  };
+  const uint32_t in[2] = {w.x, w.y};
+#pragma unroll
+  for (int pl = 0; pl < 4; ++pl) {
+    uint32_t o[4];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const uint32_t two = in[d] >> (16 * b);  // bytes 2b, 2b + 1
+        o[2 * d + b] = pack_rne<DT>(deq((two >> (2 * pl)) & 3u, sc[pl], z[pl]), deq((two >> (8 + 2 * pl)) & 3u, sc[pl], z[pl]));
+      }
+    out[pl] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 struct Args {
   const void* x;        // [B, cin, H, W] activation dtype
   const uint8_t* w;     // 8-bit: [OC, K] bytes; int4: packed [OC/2, K] bytes
@@ -123,26 +154,27 @@ struct Args {
 
 // the lane's 4 x 2 accumulator fragments -> output: D row = pixel (lane >> 4) * 4 + r of fragment i, D column = channel lane & 15 of fragment j; NCHW:
 // the lane's four rows are four neighbouring pixels of one channel plane
-template <int DT, bool PACKED4>
+template <int DT, int PL>
 __device__ __forceinline__ void store_tile(const Args& a, const f32x4 (&acc)[4][2], int m0, int nt, int wm, int wn, int lane) {
   using E = Elem<DT>;
   using T = typename E::T;
   T* yg = reinterpret_cast<T*>(a.y);
-  const int M = a.M, N = a.N, P = N >> 1, L = a.OH * a.OW;
+  const int M = a.M, N = a.N, P = N / (PL > 1 ? PL : 2), L = a.OH * a.OW;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int tc = wn * 32 + j * 16 + (lane & 15);
     int n;
-    if constexpr (PACKED4) {
-      const int p = nt * 64 + (tc & 63);
-      n = p < P ? p + (tc >> 6) * P : -1;
+    if constexpr (PL > 1) {  // the tile's 128 columns are (128 / PL) packed rows x PL planes; plane pl holds channels pl * P + p
+      constexpr int RPT = BN / PL;
+      const int p = nt * RPT + (tc % RPT);
+      n = p < P ? p + (tc / RPT) * P : -1;
     } else {
       n = nt * BN + tc;
       n = n < N ? n : -1;
     }
     if (n < 0) continue;
     float sc = 1.f;
-    if constexpr (!PACKED4) sc = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
+    if constexpr (PL == 1) sc = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
     const bool has_bias = a.bias != nullptr;
     const float bv = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
 #pragma unroll
@@ -162,9 +194,13 @@ __device__ __forceinline__ void store_tile(const Args& a, const f32x4 (&acc)[4][
   }
 }
 
-template <int DT, int FMT, bool INT_SHIFT>
+// WIDE: windows of 64 .. 127 taps (two mask words); the narrow form keeps bit 63 (WIDE: bit 127) of the mask free as the "no such k" tap of
+// a ragged last K-tile.
+template <int DT, int FMT, bool INT_SHIFT, bool WIDE>
 __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
-  constexpr bool PACKED4 = FMT == W_I4R;  // a tile's 128 columns are 64 packed rows x both nibble planes
+  constexpr int PL = planes_of(FMT);      // > 1: a tile's 128 columns are 128 / PL packed rows x PL planes
+  constexpr int RPT = BN / PL;            // packed rows per tile
+  constexpr int NO_TAP = WIDE ? 127 : 63;
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
@@ -176,13 +212,14 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
   const int m0 = blockIdx.y * BM, nt = blockIdx.x;
   const int M = a.M, N = a.N, K = a.K;
   const int S = a.S, sp = blockIdx.z;
-  const int kt_lo = (int)((long)sp * (K / BK) / S), nk = (int)((long)(sp + 1) * (K / BK) / S) - kt_lo;  // this split's K-tiles: kt_lo + t, t = 0 .. nk - 1
-  const int P = N >> 1;  // packed rows (int4)
+  const int nk_all = (K + BK - 1) / BK;  // the last K-tile may be ragged: k >= K gathers nothing and multiplies zero weights
+  const int kt_lo = (int)((long)sp * nk_all / S), nk = (int)((long)(sp + 1) * nk_all / S) - kt_lo;  // this split's K-tiles: kt_lo + t, t = 0 .. nk - 1
+  const int P = N / (PL > 1 ? PL : 2);  // packed rows (int4 / int2)
   const uint8_t* xb = reinterpret_cast<const uint8_t*>(a.x);
 
   // ---- the thread's pixel ----------------------------------------------------------------------------------------------------------------
   uint32_t px_off;        // byte offset of input element (b, 0, oh sh, ow sw): the window's top-left tap shifted right / down by the padding
-  uint64_t px_taps = 0;   // bit i KW + j: tap (i, j) of this pixel's window lies inside the image
+  uint64_t px_taps = 0, px_taps_hi = 0;   // bit i KW + j (taps 64 .. 126 in the second word): tap (i, j) of this pixel's window lies inside the image
   {
     const int L = a.OH * a.OW;
     int m = m0 + (tid & 127);
@@ -193,7 +230,13 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
     for (int ki = 0; ki < a.KH; ++ki)
       for (int kj = 0; kj < a.KW; ++kj) {
         const int ih = ih0 + ki * a.dh, iw = iw0 + kj * a.dw;
-        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) px_taps |= 1ull << (ki * a.KW + kj);
+        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+          const int t = ki * a.KW + kj;
+          if (!WIDE || t < 64)
+            px_taps |= 1ull << t;
+          else
+            px_taps_hi |= 1ull << (t - 64);
+        }
       }
   }
   int2* ktab = reinterpret_cast<int2*>(smem + 2 * 2 * TILE_BYTES);  // [2][64] {byte offset relative to px_off (signed), tap number}
@@ -201,14 +244,14 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
     if (tid < BK) {
       const int khw = a.KH * a.KW, k = (kt_lo + t) * BK + tid;
       const int ci = k / khw, rem = k - ci * khw, ki = rem / a.KW, kj = rem - ki * a.KW;
-      ktab[(t & 1) * BK + tid] = make_int2(2 * ((ci * a.H + ki * a.dh) * a.W + kj * a.dw - (a.ph * a.W + a.pw)), rem);
+      ktab[(t & 1) * BK + tid] = k < K ? make_int2(2 * ((ci * a.H + ki * a.dh) * a.W + kj * a.dw - (a.ph * a.W + a.pw)), rem) : make_int2(0, NO_TAP);
     }
   };
 
   // ---- staging registers --------------------------------------------------------------------------------------------------------------------
   uint32_t g_raw[2][8], g_keep = 0;  // gathered elements of the K-tile in flight (taps over the padding hold x[0]) and their validity bits
   uint4 rw;                          // 8-bit: 16 weights of row tid >> 2, part tid & 3; int4: 8 packed bytes (rw.x, rw.y) of packed row tid >> 3, part tid & 7
-  float rs[2] = {0.f, 0.f}, rz[2] = {0.f, 0.f};  // int4: scale / shift of the thread's packed row (low and high plane) in the group of its 8 k
+  float rs[4] = {0.f, 0.f, 0.f, 0.f}, rz[4] = {0.f, 0.f, 0.f, 0.f};  // int4 / int2: scale / shift of the thread's packed row (per plane) in the group of its 8 k
   auto issue_loads = [&](int t) {
     const int k0 = (kt_lo + t) * BK;
 #pragma unroll
@@ -219,31 +262,54 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
       const int off[8] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z}, tap[8] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w};
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const uint32_t ok = (uint32_t)((px_taps >> tap[q]) & 1ull);
+        const uint32_t ok = WIDE ? (uint32_t)((((tap[q] & 64) ? px_taps_hi : px_taps) >> (tap[q] & 63)) & 1ull) : (uint32_t)((px_taps >> tap[q]) & 1ull);
         g_keep = j == 0 && q == 0 ? ok : g_keep | (ok << (8 * j + q));
         const uint32_t voff = (px_off + (uint32_t)off[q]) & (0u - ok);
         g_raw[j][q] = *reinterpret_cast<const uint16_t*>(xb + voff);
       }
     }
-    if constexpr (PACKED4) {
-      int p = nt * 64 + (tid >> 3);
-      p = p < P ? p : P - 1;
-      const uint2 v = *reinterpret_cast<const uint2*>(a.w + (size_t)p * K + k0 + (tid & 7) * 8);
-      rw = make_uint4(v.x, v.y, 0u, 0u);
-      const int g = (k0 + (tid & 7) * 8) / a.C;  // the 8 k of a chunk lie in one group (C % 8 == 0)
+    if constexpr (PL > 1) {
+      // packed sub-byte weight: thread (row tid >> 3 of the tile's RPT packed rows, part tid & 7) takes 8 packed bytes = 8 k of every plane
+      if (PL == 2 || tid < RPT * 8) {
+        int p = nt * RPT + (tid >> 3);
+        p = p < P ? p : P - 1;
+        const int kb = k0 + (tid & 7) * 8;
+        const uint8_t* src = a.w + (size_t)p * K + kb;
+        uint2 v = make_uint2(0u, 0u);
+        if (kb + 8 <= K) {
+          const U2u u = *reinterpret_cast<const U2u*>(src);
+          v = make_uint2(u.x, u.y);
+        } else {  // ragged end of the last K-tile: byte by byte, nothing is read beyond the row
+          for (int b = 0; b < 8; ++b)
+            if (kb + b < K) (b < 4 ? v.x : v.y) |= (uint32_t)src[b] << (8 * (b & 3));
+        }
+        rw = make_uint4(v.x, v.y, 0u, 0u);
+        int g = kb / a.C;  // the 8 k of a chunk lie in one group (C % 8 == 0, or one group per channel)
+        g = g < a.G ? g : a.G - 1;
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-        const size_t idx = (size_t)(pl * P + p) * a.G + g;
-        rs[pl] = E::to_f32(reinterpret_cast<const T*>(a.scale)[idx]);
-        if constexpr (INT_SHIFT)
-          rz[pl] = (float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[idx];
-        else
-          rz[pl] = E::to_f32(reinterpret_cast<const T*>(a.shift)[idx]);
+        for (int pl = 0; pl < PL; ++pl) {
+          const size_t idx = (size_t)(pl * P + p) * a.G + g;
+          rs[pl] = E::to_f32(reinterpret_cast<const T*>(a.scale)[idx]);
+          if constexpr (INT_SHIFT)
+            rz[pl] = (float)(int8_t) reinterpret_cast<const uint8_t*>(a.shift)[idx];
+          else
+            rz[pl] = E::to_f32(reinterpret_cast<const T*>(a.shift)[idx]);
+        }
       }
     } else {
       int n = nt * BN + (tid >> 2);
       n = n < N ? n : N - 1;
-      rw = *reinterpret_cast<const uint4*>(a.w + (size_t)n * K + k0 + (tid & 3) * 16);
+      const int kb = k0 + (tid & 3) * 16;
+      const uint8_t* src = a.w + (size_t)n * K + kb;
+      if (kb + 16 <= K) {
+        const U4u u = *reinterpret_cast<const U4u*>(src);
+        rw = make_uint4(u.x, u.y, u.z, u.w);
+      } else {  // ragged end of the last K-tile: zero bytes (fp8 0.0, int8 0) behind K, nothing is read beyond the row
+        uint32_t d[4] = {0u, 0u, 0u, 0u};
+        for (int b = 0; b < 16; ++b)
+          if (kb + b < K) d[b >> 2] |= (uint32_t)src[b] << (8 * (b & 3));
+        rw = make_uint4(d[0], d[1], d[2], d[3]);
+      }
     }
   };
   auto write_lds = [&](int buf) {
@@ -257,12 +323,20 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
       *reinterpret_cast<uint4*>(sa + lds_off(tid & 127, (tid >> 7) + 4 * j)) =
           make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
     }
-    if constexpr (PACKED4) {
+    if constexpr (PL == 2) {
       uint4 lo, hi;
       convert8_i4r<DT, INT_SHIFT>(make_uint2(rw.x, rw.y), rs[0], rz[0], rs[1], rz[1], lo, hi);
       const int row = tid >> 3, part = tid & 7;
       *reinterpret_cast<uint4*>(sb + lds_off(row, part)) = lo;
       *reinterpret_cast<uint4*>(sb + lds_off(64 + row, part)) = hi;
+    } else if constexpr (PL == 4) {
+      if (tid < RPT * 8) {
+        uint4 o[4];
+        convert8_i2r<DT, INT_SHIFT>(make_uint2(rw.x, rw.y), rs, rz, o);
+        const int row = tid >> 3, part = tid & 7;
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) *reinterpret_cast<uint4*>(sb + lds_off(pl * RPT + row, part)) = o[pl];
+      }
     } else {
       uint4 c0, c1;
       convert16<DT, FMT>(rw, c0, c1);
@@ -317,13 +391,13 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
       for (int j = 0; j < 2; ++j) mine[(i * 2 + j) * 64] = acc[i][j];
     return;
   }
-  store_tile<DT, PACKED4>(a, acc, m0, nt, wm, wn, lane);
+  store_tile<DT, PL>(a, acc, m0, nt, wm, wn, lane);
 }
 
 // split-K tail: one WAVE per (output tile, wave slot of the tile kernel) adds that slot's eight fragments over the S partial tiles in split order
 // (deterministic), four splits' loads in flight together, and runs the epilogue.  (First form: one 512-thread workgroup per tile with one split per
 // loop iteration - 14 workgroups each waiting 12 times for a round trip cost more than the convolution itself.)
-template <int DT, bool PACKED4>
+template <int DT, int PL>
 __global__ void __launch_bounds__(64) qconv2d_reduce_kernel(const Args a) {
   const int lane = threadIdx.x, wave = blockIdx.z, S = a.S;
   f32x4 acc[4][2];
@@ -350,14 +424,14 @@ __global__ void __launch_bounds__(64) qconv2d_reduce_kernel(const Args a) {
           for (int r = 0; r < 4; ++r) acc[f >> 1][f & 1][r] += v[u][f][r];
       }
   }
-  store_tile<DT, PACKED4>(a, acc, blockIdx.y * BM, blockIdx.x, wave >> 2, wave & 3, lane);
+  store_tile<DT, PL>(a, acc, blockIdx.y * BM, blockIdx.x, wave >> 2, wave & 3, lane);
 }
 
 // K split: the tile kernel is bound by its gather per K-tile (~1.9 us per workgroup and K-tile whatever M is), so what matters is how many
 // workgroups run at once: split until the grid reaches ~2 workgroups per CU, keeping at least 3 K-tiles per split.  1 = no split (and no workspace).
 static int pick_split(int64_t M, int64_t N, int64_t K) {
   const int forced = env_int("QUANTO_HIP_CONV_SPLIT", 0);  // experiments
-  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nk = K / BK;
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nk = (K + BK - 1) / BK;
   if (forced > 0) return (int)(forced <= nk ? forced : nk);
   // measured (profiles/r04_qconv2d_forced_split.jsonl): at 196 tiles a split of 2 costs more in partial sums than the second workgroup per CU
   // brings while K is short (9 K-tiles 23.9 -> 31.9 us, 18 K-tiles 43.0 -> 44.7) and pays from ~32 K-tiles on (192 tiles x 45: 81.6 -> 72.9,
@@ -369,23 +443,29 @@ static int pick_split(int64_t M, int64_t N, int64_t K) {
 }
 static size_t split_workspace(int64_t M, int64_t N, int S) { return S <= 1 ? 0 : (size_t)S * ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (BM * BN * 4); }
 
-template <int DT, int FMT, bool INT_SHIFT>
-static int launch(Args a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_mfma_kernel<DT, FMT, INT_SHIFT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  const int ntiles = FMT == W_I4R ? (a.N / 2 + 63) / 64 : (a.N + BN - 1) / BN, mtiles = (a.M + BM - 1) / BM;
+template <int DT, int FMT, bool INT_SHIFT, bool WIDE>
+static int launch_w(Args a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  constexpr int PL = planes_of(FMT);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  const int ntiles = PL > 1 ? (a.N / PL + BN / PL - 1) / (BN / PL) : (a.N + BN - 1) / BN, mtiles = (a.M + BM - 1) / BM;
   int S = pick_split(a.M, a.N, a.K);
   if (S > 1 && (!workspace || workspace_bytes < split_workspace(a.M, a.N, S) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
   a.S = S;
   a.partials = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL((qconv2d_mfma_kernel<DT, FMT, INT_SHIFT>), dim3(ntiles, mtiles, S), dim3(NT), LDS_BYTES, stream, a);
-  if (S > 1) hipLaunchKernelGGL((qconv2d_reduce_kernel<DT, FMT == W_I4R>), dim3(ntiles, mtiles, 8), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL((qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE>), dim3(ntiles, mtiles, S), dim3(NT), LDS_BYTES, stream, a);
+  if (S > 1) hipLaunchKernelGGL((qconv2d_reduce_kernel<DT, PL>), dim3(ntiles, mtiles, 8), dim3(64), 0, stream, a);
   return launch_status();
+}
+template <int DT, int FMT, bool INT_SHIFT>
+static int launch(Args a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  return a.KH * a.KW > 63 ? launch_w<DT, FMT, INT_SHIFT, true>(a, workspace, workspace_bytes, stream)
+                          : launch_w<DT, FMT, INT_SHIFT, false>(a, workspace, workspace_bytes, stream);
 }
 
 static bool geometry_ok(int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW) {
   const int64_t K = cin * KH * KW;
-  // K in whole K-tiles; one validity bit per tap; byte offsets into x and element offsets into y / w in 31 bits; grid.y
-  return B >= 1 && OH >= 1 && OW >= 1 && K % BK == 0 && KH * KW <= 64 && B * cin * H * W < (1ll << 30) && B * OC * OH * OW < (1ll << 31) &&
+  // one validity bit per tap (two mask words, one bit kept free); byte offsets into x and element offsets into y / w in 31 bits; grid.y
+  return B >= 1 && OH >= 1 && OW >= 1 && K >= 1 && KH * KW <= 127 && B * cin * H * W < (1ll << 30) && B * OC * OH * OW < (1ll << 31) &&
          OC * K < (1ll << 31) && (B * OH * OW + BM - 1) / BM <= 65535;  // (the K split is at most 64: grid.z)
 }
 
@@ -404,7 +484,6 @@ int qbytes_conv2d_mfma(const void* x, const void* w, const void* s, const void* 
                        int64_t KH, int64_t KW, int64_t OH, int64_t OW, int sh, int sw, int ph, int pw, int dh, int dw, int a_dtype, int b_dtype,
                        int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbytes_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
-  if (reinterpret_cast<uintptr_t>(w) % 16) return QUANTO_HIP_EALIGN;
   const conv::Args a{x, reinterpret_cast<const uint8_t*>(w), s, nullptr, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), 0, 0,
                      (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr};
   using namespace conv;
@@ -420,10 +499,12 @@ int qbytes_conv2d_mfma(const void* x, const void* w, const void* s, const void* 
 #undef QH_CASE
 }
 
-// int4: group sizes that are multiples of 8 (a staging chunk of 8 k must not straddle groups) and per-channel scales; OC even
+// int4 / int2: group sizes that are multiples of 8 (a staging chunk of 8 k must not straddle groups) or per-channel scales; OC a multiple of the
+// values per byte (the planes of the generic packed layout)
 bool qbits_conv2d_supported(int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, const PackedGeom& g,
                             int dtype) {
-  return g.bits == 4 && g.N == OC && g.K == cin * KH * KW && OC % 2 == 0 && g.C % 8 == 0 && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) &&
+  return (g.bits == 4 || g.bits == 2) && g.N == OC && g.K == cin * KH * KW && OC % g.vpi == 0 && (g.C % 8 == 0 || g.G == 1) &&
+         (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) &&
          OC * g.G < (1ll << 31) && conv::geometry_ok(B, cin, H, W, OC, KH, KW, OH, OW);
 }
 
@@ -431,15 +512,17 @@ int qbits_conv2d_mfma(const void* x, const uint8_t* packed, const void* scale, c
                       int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int sh, int sw, int ph, int pw, int dh, int dw,
                       const PackedGeom& g, int dtype, bool int_shift, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbits_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, g, dtype)) return QUANTO_HIP_ENOTSUP;
-  if (reinterpret_cast<uintptr_t>(packed) % 8) return QUANTO_HIP_EALIGN;
   const conv::Args a{x, packed, scale, shift, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), (int)g.C, (int)g.G,
                      (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr};
   using namespace conv;
-  if (dtype == QUANTO_HIP_BF16)
-    return int_shift ? launch<QUANTO_HIP_BF16, W_I4R, true>(a, workspace, workspace_bytes, stream)
-                     : launch<QUANTO_HIP_BF16, W_I4R, false>(a, workspace, workspace_bytes, stream);
-  return int_shift ? launch<QUANTO_HIP_F16, W_I4R, true>(a, workspace, workspace_bytes, stream)
-                   : launch<QUANTO_HIP_F16, W_I4R, false>(a, workspace, workspace_bytes, stream);
+#define QH_CASE(DT, FMT) return int_shift ? launch<DT, FMT, true>(a, workspace, workspace_bytes, stream) : launch<DT, FMT, false>(a, workspace, workspace_bytes, stream)
+  if (g.bits == 4) {
+    if (dtype == QUANTO_HIP_BF16) QH_CASE(QUANTO_HIP_BF16, W_I4R);
+    QH_CASE(QUANTO_HIP_F16, W_I4R);
+  }
+  if (dtype == QUANTO_HIP_BF16) QH_CASE(QUANTO_HIP_BF16, W_I2R);
+  QH_CASE(QUANTO_HIP_F16, W_I2R);
+#undef QH_CASE
 }
 
 }  // namespace qh

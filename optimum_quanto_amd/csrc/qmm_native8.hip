@@ -66,7 +66,8 @@ struct Args {
 // Tile raster.  The XCD remap in the kernels hands every XCD (its own 4 MiB L2, 32 CUs) one contiguous range of tile indices; all of an
 // XCD's workgroups walk K in step, so its L2 fetches every operand line once per distinct tile row / tile column in that range.  Row-major
 // indices make the range 2 tile rows x 16 tile columns at 4096^3 (18 row-panels of traffic per XCD, 72 % L2 hits), and ONE row x 32 columns for
-// the 128-tiles of (512,8192,8192) (33 panels); walking `gm` tile rows first turns it into a gm x (32 / gm) block: 4 x 8 = 12 panels, 81 % hits.
+// the 128-tiles of (512,8192,8192) (33 panels); walking `gm` tile rows first turns it into a gm x (32 / gm) block: 4 x 8 or 8 x 4 = 12 panels (measured, r5: L2 misses -27 %, (512,8192,8192)
+// int8 / fp8 46.1 / 46.5 -> 42.8 / 43.4 us, int4 prefill 4096^3 104.3 -> 102.4, the square 4096^3 products unchanged).
 // The vector L1 keeps ~57 of its 64 miss slots busy in these kernels (requests x latency / cycles, profiles/r05_native8_row128.md), so the
 // fill rate is slots x 128 B / latency and the L2 hit rate sets the latency.
 __device__ __forceinline__ void tile_of(int bid, int tiles_m, int tiles_n, int gm, int& tm, int& tn) {
@@ -444,10 +445,10 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
 // =============================================================================================================================
 __device__ __forceinline__ int swz128(int row) { return (row >> 1) & 7; }
 
-// V: scheduling experiments (QUANTO_HIP_R128_VARIANT; int8 / 16-bit 256-tiles only).  bit 0: the eight DMA pieces of a pair behind the FIRST
-// four token fragments of the odd step (two per fragment) instead of one behind each of the eight; bit 1: no lgkmcnt(0) in front of the
-// barrier (timing only: the write-after-read margin is then a matter of luck).
-template <int ODT, int KIND, bool SMALL = false, int V = 0>
+// Tried and dropped (r5, profiles/r05_native8_row128.md): the eight DMA pieces of a pair behind the first four token fragments of the odd
+// step instead of one behind each of the eight (w8a8 4096^3 53.0 -> 54.6 us: two back-to-back DMA issues stall the MFMA stream for longer than
+// the earlier landing saves), and no lgkmcnt(0) in front of the barrier (52.9 vs 53.0: the wait is free, so the rigorous form stays).
+template <int ODT, int KIND, bool SMALL = false>
 __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kernel(const Args a) {
   using AV = typename Acc<KIND>::V;
   constexpr bool MX = KIND == K_F8E4M3 || KIND == K_F8E5M2;
@@ -627,7 +628,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
       }
       if (has_next) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (!(V & 2)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
@@ -640,14 +641,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
             if (i < NJ && has_next) wq[0][i] = rd(wp(B ^ 1, 0) + i * FR);
           }
           if (j == 2 % NJ) {
-            if constexpr (V & 1) {
-              if (has_dma && i < 4) {
-                issue_piece(p + 2, mdst[B], 2 * i);
-                issue_piece(p + 2, mdst[B], 2 * i + 1);
-              }
-            } else {
-              if (has_dma) issue_piece(p + 2, mdst[B], i);
-            }
+            if (has_dma) issue_piece(p + 2, mdst[B], i);
           }
           if (j == NJ - 1 && has_next) xf[i] = rd(xp(B ^ 1, 0) + i * FR);
           __builtin_amdgcn_sched_barrier(0);
@@ -670,24 +664,18 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
   epilogue<ODT, KIND, NJ, BM, BN>(a, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
-template <int ODT, int KIND, bool SMALL, int V = 0>
+template <int ODT, int KIND, bool SMALL>
 static int launch_r128(const Args& a, hipStream_t stream) {
   constexpr int T = SMALL ? 128 : 256;
   constexpr int need = 2 * 2 * T * 128;  // two buffers of 128-byte rows: 128 KiB (64 KiB for the 128-tile); the epilogue parks in it
   const int tiles = ((a.N + T - 1) / T) * ((a.M + T - 1) / T);
-  if constexpr (V == 0 && !SMALL && ODT == QUANTO_HIP_BF16 && (KIND == K_I8 || KIND == K_BF16)) {
-    const int v = env_int("QUANTO_HIP_R128_VARIANT", 0);  // experiments
-    if (v == 1) return launch_r128<ODT, KIND, SMALL, 1>(a, stream);
-    if (v == 2) return launch_r128<ODT, KIND, SMALL, 2>(a, stream);
-    if (v == 3) return launch_r128<ODT, KIND, SMALL, 3>(a, stream);
-  }
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_r128_kernel<ODT, KIND, SMALL, V>), hipFuncAttributeMaxDynamicSharedMemorySize, need);
-  hipLaunchKernelGGL((qbytes_native8_r128_kernel<ODT, KIND, SMALL, V>), dim3(tiles), dim3(SMALL ? 256 : 512), need, stream, a);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_r128_kernel<ODT, KIND, SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, need);
+  hipLaunchKernelGGL((qbytes_native8_r128_kernel<ODT, KIND, SMALL>), dim3(tiles), dim3(SMALL ? 256 : 512), need, stream, a);
   return launch_status();
 }
 
 static int raster_group() {
-  const int g = env_int("QUANTO_HIP_NATIVE8_GROUP_M", 4);  // experiments: 1 = row-major
+  const int g = env_int("QUANTO_HIP_NATIVE8_GROUP_M", 8);  // experiments: 1 = row-major
   return g < 1 ? 1 : g;
 }
 

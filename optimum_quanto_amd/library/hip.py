@@ -300,14 +300,14 @@ class _Bindings:
         OH = cls.conv2d_out_size(H, KH, stride[0], padding[0], dilation[0])
         OW = cls.conv2d_out_size(W, KW, stride[1], padding[1], dilation[1])
         K = C * KH * KW
-        return (B >= 1 and OH >= 1 and OW >= 1 and K % 64 == 0 and KH * KW <= 64 and B * C * H * W < (1 << 30) and B * OC * OH * OW < (1 << 31)
+        return (B >= 1 and OH >= 1 and OW >= 1 and K >= 1 and KH * KW <= 127 and B * C * H * W < (1 << 30) and B * OC * OH * OW < (1 << 31)
                 and OC * K < (1 << 31) and (B * OH * OW + 127) // 128 <= 65535)
 
     def qbytes_conv2d_supported(self, x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)) -> bool:
-        """What the kernel takes: NCHW 16-bit activations, an 8-bit OCP weight whose rows start on 16-byte boundaries, and a geometry within
-        ``conv2d_geometry_ok`` (C * KH * KW a multiple of the K-tile, windows of up to 64 taps, 31-bit offsets)."""
+        """What the kernel takes: NCHW 16-bit activations, an 8-bit OCP weight, and a geometry within ``conv2d_geometry_ok`` (windows of up
+        to 127 taps, 31-bit offsets; any C * KH * KW: the last K-tile may be ragged, any weight alignment)."""
         return (x.is_cuda and x.dim() == 4 and w.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and
-                w.dtype in (torch.int8, torch.float8_e4m3fn, torch.float8_e5m2) and (not w.is_contiguous() or w.data_ptr() % 16 == 0) and
+                w.dtype in (torch.int8, torch.float8_e4m3fn, torch.float8_e5m2) and
                 self.conv2d_geometry_ok(tuple(x.shape), tuple(w.shape), stride, padding, dilation))
 
     def qbytes_conv2d(self, x, w, scales, bias, stride, padding, dilation):
@@ -334,11 +334,11 @@ class _Bindings:
 
     # -- quanto::qbits_conv2d (implicit GEMM, int4 dequantized while staged) -----------------------------------
     def qbits_conv2d_supported(self, x, weight_size, bits: int, group_size, stride=(1, 1), padding=(0, 0), dilation=(1, 1)) -> bool:
-        """NCHW 16-bit activations, generic packed int4 weight [OC, C, KH, KW] with OC even and groups of a multiple of 8 (or per-channel scales),
-        geometry within ``conv2d_geometry_ok``."""
+        """NCHW 16-bit activations, generic packed int4 / int2 weight [OC, C, KH, KW] with OC a multiple of the values per byte and groups of a
+        multiple of 8 (or per-channel scales), geometry within ``conv2d_geometry_ok``."""
         oc, c, kh, kw = weight_size
         k = c * kh * kw
-        return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and bits == 4 and oc % 2 == 0 and
+        return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and bits in (2, 4) and oc % (8 // bits) == 0 and
                 (not group_size or (group_size % 8 == 0 and k % group_size == 0)) and oc * (k // (group_size or k)) < (1 << 31) and
                 self.conv2d_geometry_ok(tuple(x.shape), tuple(weight_size), stride, padding, dilation))
 

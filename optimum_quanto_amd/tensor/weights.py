@@ -28,6 +28,17 @@ from .packing import PackedTensor
 __all__ = ["WeightQBytesTensor", "WeightQBitsTensor", "quantize_weight"]
 
 
+_OPS = {}
+
+
+def _op(name: str):
+    """``torch.ops.quanto.<name>.default``, resolved once."""
+    op = _OPS.get(name)
+    if op is None:
+        op = _OPS[name] = getattr(torch.ops.quanto, name).default
+    return op
+
+
 class _NoCtx:
     """Stands in for the autograd context when a linear function's ``forward`` is called directly (nothing is saved: no backward will run)."""
 
@@ -102,8 +113,6 @@ def _implicit_conv2d_qbits(input, weight, bias, stride, padding, dilation, group
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     if not quanto_hip.lib.qbits_conv2d_supported(input, tuple(weight.shape), packed.bits, weight._group_size, stride, padding, dilation):
         return None
-    if packed._data.data_ptr() % 8:
-        return None  # a view the kernel's 8-byte weight loads cannot take: the im2col / reference path copes
     pair = _pair
     if tuple(weight.shape[2:]) == (1, 1) and pair(stride) == [1, 1] and pair(padding) == [0, 0] and weight.shape[1] < 128:
         return None  # pointwise with one K-tile: a permuted view of the input + the tuned GEMM kernels (see _implicit_conv2d)
@@ -165,7 +174,7 @@ class WeightQBytesLinearFunction(QuantizedLinearFunction):
             # quantized activations: integer/fp8 product, rescaled by the product of both scales
             return torch.ops.quanto.qbytes_mm_bias(input._data, other._data, input._scale * other._scale, bias)
         k, n = input.shape[-1], other.shape[0]
-        output = torch.ops.quanto.qbytes_mm_bias(input.reshape(-1, k), other._data, other._scale, bias)
+        output = _op("qbytes_mm_bias")(input.reshape(-1, k), other._data, other._scale, bias)
         return output.reshape(input.shape[:-1] + (n,))
 
 
@@ -355,8 +364,8 @@ class WeightQBitsLinearFunction(QuantizedLinearFunction):
         if type(input) is not torch.Tensor:
             input = input.dequantize()
         n, k = other.shape
-        output = torch.ops.quanto.qbits_mm(input, other._data._data, other._scale, other._shift, bias, other._data.bits,
-                                           other._group_size, n, k)
+        # the resolved overload: torch.ops.quanto.qbits_mm(...) looks the overload up on every call (~1 us of a 15 us decode call)
+        output = _op("qbits_mm")(input, other._data._data, other._scale, other._shift, bias, other._data.bits, other._group_size, n, k)
         return output
 
 

@@ -17,6 +17,8 @@ from optimum_quanto_amd.tensor.weights import conv2d_as_gemm  # noqa: E402
 
 WEIGHTS = sys.argv[1] if len(sys.argv) > 1 else "qint8"
 SHAPES = [(8, 256, 56, 256, 3, 1, 1), (8, 128, 56, 128, 3, 1, 1), (32, 512, 14, 512, 3, 1, 1), (8, 64, 112, 128, 3, 2, 1), (8, 512, 28, 128, 1, 1, 0)]
+if len(sys.argv) > 2 and sys.argv[2] == "stems":  # r5: ragged K (RGB stems) and wide windows - shapes that fell back to F.unfold + GEMM until r5
+    SHAPES = [(8, 3, 224, 64, 7, 2, 3), (32, 3, 224, 64, 7, 2, 3), (8, 3, 224, 32, 3, 2, 1), (8, 3, 32, 64, 3, 1, 1), (8, 16, 64, 64, 9, 1, 4), (8, 3, 227, 96, 11, 4, 0)]
 if len(sys.argv) > 2 and sys.argv[2] == "grid":  # the sweep behind the dispatch rule of tensor/weights.py (_implicit_conv2d_wins)
     SHAPES = [(8, 64, 56, 64, 3, 1, 1), (32, 64, 56, 64, 3, 1, 1), (8, 128, 28, 128, 3, 1, 1), (32, 128, 28, 128, 3, 1, 1), (8, 192, 28, 192, 3, 1, 1),
               (8, 256, 14, 256, 3, 1, 1), (32, 256, 14, 256, 3, 1, 1), (8, 256, 28, 256, 3, 1, 1), (8, 320, 32, 320, 3, 1, 1), (8, 512, 7, 512, 3, 1, 1),
@@ -43,7 +45,7 @@ for (B, C, H, OC, k, s, p) in SHAPES:
     else:
         direct = lambda: torch.ops.quanto.qbits_conv2d(x, w._data._data, w._scale, w._shift, q.bias, 4, w._group_size, list(w.shape), [s, s], [p, p], [1, 1])  # noqa: E731
     with torch.no_grad():
-        t_dir = _time_graph(direct, 5) if (C * k * k) % 64 == 0 else None
+        t_dir = _time_graph(direct, 5)
         t_imp = _time_graph(lambda: q(x), 5)
         t_unf = _time_graph(lambda: conv2d_as_gemm(x, w, q.bias, (s, s), (p, p), (1, 1), 1, gemm), 5)
         t_ref = _time_graph(lambda: torch.nn.functional.conv2d(x, w.dequantize(), q.bias, s, p), 5)

@@ -150,7 +150,9 @@ def test_conv2d_k_split_plan_without_a_gpu():
     assert f(8, 32, 32, 320, 2880) == 2 * (64 * 3) * tile      # 129 .. 256 tiles: two splits once K is at least 32 K-tiles deep (45 here)
     assert f(32, 28, 28, 128, 1152) == 0                       # 196 tiles, 18 K-tiles: not split
     assert f(8, 56, 56, 256, 64) == 0                          # one K-tile
-    assert f(8, 28, 28, 128, 1100) == 0 and f(0, 28, 28, 128, 1152) == 0   # K not in whole K-tiles (the kernel rejects it anyway); empty batch
+    assert f(8, 28, 28, 128, 1100) == 6 * 49 * tile            # a ragged last K-tile counts as a K-tile (r5): 18 of them, as for K = 1152
+    assert f(8, 112, 112, 64, 147) == 0                        # an RGB 7x7 stem: 3 K-tiles, 784 tiles
+    assert f(0, 28, 28, 128, 1152) == 0                        # empty batch
     assert f(-1, 28, 28, 128, 1152) == -1 and f(8, 28, 28, 0, 1152) == -1
 
 
@@ -359,8 +361,9 @@ def test_conv2d_geometry_gate_mirrors_the_kernel_limits():
     ok = _Bindings.conv2d_geometry_ok
     one = ((1, 1), (0, 0), (1, 1))
     assert ok((8, 128, 28, 28), (128, 128, 3, 3), (1, 1), (1, 1), (1, 1))
-    assert not ok((8, 3, 224, 224), (64, 3, 7, 7), (2, 2), (3, 3), (1, 1))      # K = 147: not a multiple of the K-tile
-    assert not ok((1, 64, 32, 32), (64, 64, 9, 9), *one)                        # 81 taps
+    assert ok((8, 3, 224, 224), (64, 3, 7, 7), (2, 2), (3, 3), (1, 1))          # K = 147: a ragged last K-tile (r5)
+    assert ok((1, 64, 32, 32), (64, 64, 9, 9), *one)                            # 81 taps: two mask words (r5)
+    assert ok((1, 8, 32, 32), (8, 8, 11, 11), *one) and not ok((1, 8, 32, 32), (8, 8, 12, 12), *one)  # 121 taps / 144 taps
     assert ok((8, 64, 1024, 1023), (64, 64, 1, 1), *one)                        # 65472 tiles of 128 pixels ...
     assert not ok((8, 64, 1024, 1024), (64, 64, 1, 1), *one)                    # ... 65536: grid.y
     assert not ok((16, 64, 1024, 1024), (64, 64, 1, 1), (8, 8), (0, 0), (1, 1))  # 2^30 input elements

@@ -240,6 +240,73 @@ def test_qconv2d_int4_implicit_gemm_gpu(dt, zp, cin, cout, k, s, p, d, gs):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("wq", ["qint8", "qfloat8_e4m3fn"])
+@pytest.mark.parametrize("cin,cout,k,s,p,d,hw", [(3, 64, 7, 2, 3, 1, (37, 29)),      # the ResNet stem: K = 147, three K-tiles, the last one 19 wide
+                                                 (3, 32, 3, 1, 1, 1, (20, 17)),      # K = 27: a single ragged K-tile
+                                                 (5, 24, (3, 2), 1, 0, 1, (9, 8)),   # K = 30
+                                                 (16, 48, 9, 1, 4, 1, (15, 14)),     # 81 taps: two mask words
+                                                 (8, 40, 11, 4, 2, 1, (40, 33)),     # 121 taps (AlexNet's first layer window), K = 968: ragged as well
+                                                 (64, 40, 8, 1, 3, 1, (12, 12)),     # exactly 64 taps
+                                                 (130, 36, 3, 1, 1, 1, (7, 9))])     # K = 1170: eighteen full K-tiles and one of 18
+def test_qconv2d_implicit_gemm_ragged_k_and_wide_windows_gpu(dt, wq, cin, cout, k, s, p, d, hw):
+    """r5: any K = cin kh kw (a ragged last K-tile: no activation is gathered for k >= K and the weight bytes behind the row end are never
+    read - fp8 garbage there could be a NaN) and windows of up to 127 taps; no ungrouped convolution is left to the materialised F.unfold."""
+    torch.manual_seed(cin * 7 + cout)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, dilation=d).to(TORCH_DT[dt])
+    q = Q.QConv2d.from_module(conv, weights=getattr(Q, wq))
+    Q.freeze(q)
+    q = q.cuda()
+    x = torch.randn(2, cin, *hw).to(TORCH_DT[dt])
+    with torch.no_grad():
+        y = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == "conv2d_mfma"
+        w64 = q.weight._data.cpu().double() if wq == "qint8" else q.weight._data.cpu().float().double()
+        prod = torch.nn.functional.conv2d(x.double(), w64, None, conv.stride, conv.padding, conv.dilation)
+        prod = prod * q.weight._scale.cpu().double().reshape(1, -1, 1, 1)
+    assert y.shape == prod.shape and y.dtype == TORCH_DT[dt] and torch.isfinite(y.float()).all()
+    bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
+    assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), dt, f"implicit conv {cin}->{cout} k{k}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("bits,zp", [(4, False), (4, True), (2, False), (2, True)])
+@pytest.mark.parametrize("cin,cout,k,s,p,d,gs", [(3, 64, 7, 2, 3, 1, None),          # the stem with a sub-byte weight: K = 147, per-channel scales
+                                                 (3, 32, 3, 1, 1, 1, None),          # K = 27
+                                                 (20, 44, 3, 1, 1, 1, 36),           # K = 180 = 5 groups of 36: no multiple of 8 -> not eligible, falls back
+                                                 (16, 48, 9, 1, 4, 1, 144),          # 81 taps, K = 1296 = 9 groups of 144
+                                                 (128, 96, 3, 1, 1, 1, 128), (64, 40, 3, 2, 0, 1, 64), (192, 132, 3, 1, 2, 2, 32), (64, 256, 3, 1, 1, 1, None)])
+def test_qconv2d_subbyte_implicit_gemm_ragged_k_and_qint2_gpu(dt, bits, zp, cin, cout, k, s, p, d, gs):
+    """r5: qint2 weights (four planes per packed byte) and ragged K / wide windows on the sub-byte implicit GEMM.  Gate: float64 convolution with
+    the weight the numpy oracle dequantizes on the host from the packed bytes (the reference's roundings)."""
+    from optimum_quanto_amd.tensor.weights import WeightQBitsTensor
+
+    qt = Q.qint4 if bits == 4 else Q.qint2
+    torch.manual_seed(cin + cout + bits)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, dilation=d).to(TORCH_DT[dt])
+    q = Q.QConv2d.from_module(conv, weights=qt)
+    Q.freeze(q)
+    scale, shift = Q.MaxOptimizer()(conv.weight.detach(), qt, 0, gs, zeropoint=zp)
+    w = Q.quantize_weight(conv.weight.detach(), qt, 0, scale, shift, group_size=gs, optimized=False)
+    assert isinstance(w, WeightQBitsTensor) and w._group_size == gs
+    q.weight = torch.nn.Parameter(w, requires_grad=False)
+    q = q.cuda()
+    x = torch.randn(2, cin, 15, 13).to(TORCH_DT[dt])
+    with torch.no_grad():
+        y = q(x.cuda())
+        eligible = gs is None or gs % 8 == 0
+        assert (quanto_hip.lib.last_kernel() == f"conv2d_mfma_int{bits}") == eligible, quanto_hip.lib.last_kernel()
+        prod = torch.nn.functional.conv2d(x.double(), _oracle_dequantized(q.weight, dt), None, conv.stride, conv.padding, conv.dilation)
+    assert y.shape == prod.shape and y.dtype == TORCH_DT[dt]
+    bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
+    if eligible:
+        assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), dt, f"int{bits} implicit conv {cin}->{cout} k{k} g{gs}")
+    else:  # the fused GEMM kernels fold scale / shift in fp32 instead of rounding the weight first: the reference-similarity gate
+        assert_similar(torch.from_numpy(prod.numpy() + bias).float(), y.float().cpu(), atol=2e-2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("wq", ["qint8", "qint4"])
 @pytest.mark.parametrize("split", [1, 2, 7])
 def test_qconv2d_implicit_gemm_k_split_gpu(monkeypatch, wq, split):
