@@ -337,6 +337,16 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
       wr[0] = *reinterpret_cast<const uint4*>(st + woff[0]);
       wr[1] = *reinterpret_cast<const uint4*>(st + woff[1]);
     }
+    // every activation fragment of the tile up front (r5): TF x 4 (3 for tiles of 96) independent ds_read_b128 in flight together.  hipcc,
+    // left to itself, reused ONE register quad for all of them - read, wait lgkmcnt(0), two MFMAs, eight times per tile: eight exposed LDS
+    // latencies made a tile ~0.6 us of a wave's time and the K loop of a (32,4096,4096) call 3.4 of its 9.8 us (in-kernel timeline,
+    // profiles/r05_batched_decode_timeline.txt)
+    V8 xb[TF][GPT * KS];
+#pragma unroll
+    for (int t = 0; t < GPT * KS; ++t)
+#pragma unroll
+      for (int tf = 0; tf < TF; ++tf) xb[tf][t] = *reinterpret_cast<const V8*>(st + xoff[tf][t]);
+    __builtin_amdgcn_sched_barrier(0);  // (hipcc sinks the reads back next to their MFMAs otherwise: it schedules for a 64-register kernel)
 #pragma unroll
     for (int gq = 0; gq < GPT; ++gq) {
       f32x4 accg[TF], accx[TF];
@@ -367,9 +377,8 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
         const V8 wa = __builtin_bit_cast(V8, make_uint4(op[0], op[1], op[2], op[3]));
 #pragma unroll
         for (int tf = 0; tf < TF; ++tf) {
-          const V8 xb = *reinterpret_cast<const V8*>(st + xoff[tf][t]);
-          accg[tf] = Mma<DT>::run(wa, xb, accg[tf]);
-          accx[tf] = Mma<DT>::run(ones, xb, accx[tf]);
+          accg[tf] = Mma<DT>::run(wa, xb[tf][t], accg[tf]);
+          accx[tf] = Mma<DT>::run(ones, xb[tf][t], accx[tf]);
         }
       }
       // fold the group: acc += s * acc_g - zz * XS

@@ -229,6 +229,14 @@ __global__ void __launch_bounds__(256) qbytes_skinny_kernel(Args a, const Segs s
     uint4 wr[2];
     wr[0] = *reinterpret_cast<const uint4*>(st + woff[0]);
     wr[1] = *reinterpret_cast<const uint4*>(st + woff[1]);
+    // every activation fragment of the tile up front, pinned by the scheduling barrier (r5, as qbits_skinny.hip: hipcc otherwise reads one
+    // fragment, waits, issues its MFMAs, TF x 4 times per tile - one exposed LDS latency each)
+    V8 xb[TF][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int tf = 0; tf < TF; ++tf) xb[tf][t] = *reinterpret_cast<const V8*>(st + xoff[tf][t]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       // k-step t: bytes 8t .. 8t+7 of the lane's 32 = dwords (2t, 2t+1) -> four operand dwords
@@ -240,10 +248,7 @@ __global__ void __launch_bounds__(256) qbytes_skinny_kernel(Args a, const Segs s
       op[3] = convert_pair<DT, FMT>(d1, 1);
       const V8 wa = __builtin_bit_cast(V8, make_uint4(op[0], op[1], op[2], op[3]));
 #pragma unroll
-      for (int tf = 0; tf < TF; ++tf) {
-        const V8 xb = *reinterpret_cast<const V8*>(st + xoff[tf][t]);
-        acc[tf] = Mma<DT>::run(wa, xb, acc[tf]);
-      }
+      for (int tf = 0; tf < TF; ++tf) acc[tf] = Mma<DT>::run(wa, xb[tf][t], acc[tf]);
     }
   };
 
