@@ -28,7 +28,10 @@
 //   * step (kk, i), 32 per K-tile: 2 MFMAs (both planes) x token fragment i; phase kk = 0 converts this tile's k-half-1 operands,
 //     phase kk = 1 the next tile's k-half-0 operands - one pair of weights every step;
 //   * epilogue: the tile is parked in LDS and stored as whole 256-byte rows per column block.
-// Group sizes: multiples of 64 and per-channel (a K-tile lies inside one group).  int4 only.
+// Group sizes: multiples of 64 and per-channel (a K-tile lies inside one group), and - HG, r5 - the other multiples of 32 the reference
+// produces for K % 128 != 0 layers (nn/qmodule.py:121-129: 96, 32): there a group boundary may fall between the two k-halves of a K-tile,
+// so the scale / shift entries are looked up per k-half (the table read of the next tile's k-half 1 goes into the registers of this
+// tile's, dead once its first phase has converted).  int4 only.
 #include <type_traits>
 
 #include "qmm_large_common.h"
@@ -120,7 +123,7 @@ __device__ __forceinline__ uint32_t convert_pair4(uint32_t spread, float s, floa
 // FULLM: M is a multiple of 256 - the activation rows of DMA piece j are the lane's piece-0 row + 64 j, a wave-uniform byte offset added to
 // the SGPR base (one VGPR for all four pieces).  Ragged M clamps every row to M - 1 and recomputes the lane's offset per piece
 // (3 VALU each): four live VGPRs more made hipcc spill INSIDE the loop - among others the registers of weight loads still in flight.
-template <int DT, bool INT_SHIFT, bool FULLM>
+template <int DT, bool INT_SHIFT, bool FULLM, bool HG>
 __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args a) {
   using E = Elem<DT>;
   using T = typename E::T;
@@ -270,13 +273,14 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  // group bookkeeping (wave-uniform): group of the current tile, k offset of the current tile inside its group
+  // group bookkeeping (wave-uniform): group of the current tile (HG: of its k-half 0), k offset of the current tile inside its group
   int g_cur = 0, k_in_g = 0;
-  float sc[2], zc[2], sn[2], zn[2];  // scale / shift (per plane) of the current and of the next tile's group
+  float sc[2], zc[2], sn[2], zn[2];  // scale / shift (per plane) of the current tile's (HG: its k-half 1's) and of the next tile's (k-half 0's) group
   table_read(0, sc, zc);
   raw = read_w(0);
 #pragma unroll
   for (int c = 0; c < 8; ++c) w0[c >> 2][c & 3] = convert(raw, 0, c, sc, zc);
+  if constexpr (HG) table_read(BK / 2 >= C ? 1 : 0, sc, zc);  // tile 0's k-half 1
   xf[0] = *reinterpret_cast<const V8*>(smem + aoff[0]);
   xf[1] = *reinterpret_cast<const V8*>(smem + aoff[0] + 2048);
   xf[2] = *reinterpret_cast<const V8*>(smem + aoff[0] + 4096);
@@ -286,9 +290,22 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
     const bool dma = dma_tag, barrier = barrier_tag;  // integral_constants in the steady state (no branches), run-time flags in the tail
     const uint8_t* st = smem + PS * STAGE_BYTES;
     const uint8_t* sx = smem + PN * STAGE_BYTES;
-    // the next tile's group
+    // the next tile's group (HG: the groups of its two k-halves; C is a multiple of 32, so a k-half lies inside one group)
     int g_next = g_cur, k_next = k_in_g + BK;
-    if (k_next >= C) {
+    int g_next1 = 0;
+    if constexpr (HG) {
+      k_next = k_in_g + BK / 2;
+      if (k_next >= C) {
+        k_next = 0;
+        ++g_next;
+      }
+      k_next += BK / 2;
+      if (k_next >= C) {
+        k_next = 0;
+        ++g_next;
+      }
+      g_next1 = k_next + BK / 2 >= C ? g_next + 1 : g_next;
+    } else if (k_next >= C) {
       k_next = 0;
       ++g_next;
     }
@@ -297,6 +314,7 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
       const int kk = s / MI, i = s % MI;
       if (s == MI) {  // before the first conversion of the second phase: the next tile's scale / shift and packed bytes
         table_read(g_next, sn, zn);
+        if constexpr (HG) table_read(g_next1, sc, zc);  // the next tile's k-half 1: this tile's phase-0 conversions are done with sc / zc
         raw = read_w(PN);
       }
 #pragma unroll
@@ -344,10 +362,12 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
     }
     g_cur = g_next;
     k_in_g = k_next;
+    if constexpr (!HG) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      sc[j] = sn[j];
-      zc[j] = zn[j];
+      for (int j = 0; j < 2; ++j) {
+        sc[j] = sn[j];
+        zc[j] = zn[j];
+      }
     }
   };
   using yes = std::integral_constant<bool, true>;
@@ -416,7 +436,7 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
   }
 }
 
-template <int DT, bool INT_SHIFT, bool FULLM>
+template <int DT, bool INT_SHIFT, bool FULLM, bool HG>
 static int launch_m(const Args& a, hipStream_t stream) {
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N / 2 + BP - 1) / BP, tiles = tiles_m * tiles_n;
   Args b = a;
@@ -429,21 +449,22 @@ static int launch_m(const Args& a, hipStream_t stream) {
     if (forced > 0) g = forced;
     b.group_m = g < tiles_m ? g : tiles_m;
   }
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_mfma_large_kernel<DT, INT_SHIFT, FULLM>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbits_mfma_large_kernel<DT, INT_SHIFT, FULLM, HG>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  hipLaunchKernelGGL((qbits_mfma_large_kernel<DT, INT_SHIFT, FULLM>), dim3(tiles), dim3(NW * 64), LDS_BYTES, stream, b);
+  hipLaunchKernelGGL((qbits_mfma_large_kernel<DT, INT_SHIFT, FULLM, HG>), dim3(tiles), dim3(NW * 64), LDS_BYTES, stream, b);
   return launch_status();
 }
 template <int DT, bool INT_SHIFT>
 static int launch(const Args& a, hipStream_t stream) {
-  return a.M % BM == 0 ? launch_m<DT, INT_SHIFT, true>(a, stream) : launch_m<DT, INT_SHIFT, false>(a, stream);
+  if (a.C % BK != 0) return a.M % BM == 0 ? launch_m<DT, INT_SHIFT, true, true>(a, stream) : launch_m<DT, INT_SHIFT, false, true>(a, stream);
+  return a.M % BM == 0 ? launch_m<DT, INT_SHIFT, true, false>(a, stream) : launch_m<DT, INT_SHIFT, false, false>(a, stream);
 }
 
 }  // namespace l4
 
 bool qbits_mfma_large_supported(int64_t M, const PackedGeom& g, int dtype) {
   return g.bits == 4 && (dtype == QUANTO_HIP_BF16 || dtype == QUANTO_HIP_F16) && g.N % 2 == 0 && g.K % l4::BK == 0 && g.K >= 2 * l4::BK &&
-         g.C % l4::BK == 0 && M >= 1 && M * g.K < (1ll << 30) && g.N * g.K < (1ll << 32) && g.N * g.G < (1ll << 31) && g.N < (1 << 30) && M < (1 << 30);
+         g.C % (l4::BK / 2) == 0 && M >= 1 && M * g.K < (1ll << 30) && g.N * g.K < (1ll << 32) && g.N * g.G < (1ll << 31) && g.N < (1 << 30) && M < (1 << 30);
 }
 
 int qbits_mm_mfma_large(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t M,

@@ -794,6 +794,11 @@ def test_fp8a8_4096_cubed():
     (256, 512, 14336, 128, True, True),     # Llama-3 down_proj depth: 112 groups, zero-point, bias
     (1024, 1024, 4096, 128, False, False),  # 4 x 4 tiles: the XCD-aware raster
     (384, 512, 2304, 192, False, False),    # group size 192 (a multiple of 64 that is not a power of two)
+    (256, 256, 192, 96, False, False),      # group size 96 (nn/qmodule.py:121-129 for K % 128 != 0): a boundary between the k-halves of a K-tile
+    (300, 512, 4800, 96, True, True),       # 50 groups of 96: boundaries at every third k-half, window refill, zero-point, bias, ragged M
+    (512, 320, 2048, 32, False, False),      # group size 32: every k-half its own group (64 groups: the window refilled every 4 tiles)
+    (257, 768, 4096, 32, True, False),      # 128 groups of 32, zero-point
+    (384, 256, 1152, 96, False, False),      # K = 1152 = 12 groups of 96 = 18 K-tiles
 ])
 def test_large_tile_int4_gemm(dt, M, N, K, gs, zp, bias):
     """qbits_mfma_large.hip (forced): packed int4 -> registers -> MFMA operands with the reference's rounding sequence.  Whole output
@@ -818,11 +823,12 @@ def test_large_tile_int4_gemm_operands_are_the_dequantized_weight():
     bit-identical to the reference's dequantize(), test_dequantize_qbits_bit_exact), for float shifts and zero-points, both dtypes."""
     for dt in ("bf16", "fp16"):
         for zp in (False, True):
-            p = make_qbits_problem(512, 512, 512, dt, group_size=128, zeropoint=zp, seed=3)
-            p["x"] = np.eye(512, dtype=np.float32)
-            y = _run_qbits(p, "mfma_large4")  # [512 tokens = k, 512 features]: y[k, n] = W[n, k]
-            w = O.dequantize_qbits_ref(p["packed"], 4, p["scale"], p["shift"], 0, 128, (512, 512), dt)
-            np.testing.assert_array_equal(y, w.T.astype(np.float32))
+            for K, gs in ((512, 128), (576, 96), (512, 32)):  # 96 / 32: scale and shift looked up per k-half (group boundaries inside a K-tile)
+                p = make_qbits_problem(K, 512, K, dt, group_size=gs, zeropoint=zp, seed=3)
+                p["x"] = np.eye(K, dtype=np.float32)
+                y = _run_qbits(p, "mfma_large4")  # [K tokens = k, 512 features]: y[k, n] = W[n, k]
+                w = O.dequantize_qbits_ref(p["packed"], 4, p["scale"], p["shift"], 0, gs, (512, K), dt)
+                np.testing.assert_array_equal(y, w.T.astype(np.float32))
 
 
 def test_auto_takes_the_large_tile_int4_gemm_where_it_wins():
