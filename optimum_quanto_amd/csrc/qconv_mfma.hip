@@ -15,11 +15,19 @@
 //     across a wave and the 64 lanes of a load are 64 neighbouring pixels (one or two cache lines);
 //   * what depends on k only - byte offset of tap (c, i, j) relative to the window's top-left tap, and the tap's number i*KW + j - is computed
 //     once per K-tile by 64 threads into an LDS table (two buffers, rides on the K loop's barrier) and read back by broadcast ds_reads;
-//   * what depends on the pixel only - its base offset and ONE validity bit per tap (64-bit mask: windows of up to 64 taps) - lives in three
-//     registers.  An element costs add + shift + and + and (+ its two-byte load): taps over the padding read element 0 and are zeroed;
-//   * the 16 loads of a K-tile are issued back to back before the MFMAs of the current tile and masked / packed after them.
+//   * what depends on the pixel only - its base offset and ONE bit per tap (set: the tap hangs over the padding; a 32-bit word for windows of up
+//     to 31 taps, two 64-bit words up to 127) - lives in two registers.  The loads are BUFFER loads over x with its true size as the range (r5): an
+//     element costs add + v_bfe_i32 + or (+ its two-byte load) - the sign-extended bit turns the offset of a padding tap into 0xFFFFFFFF, the
+//     range check returns 0 for it, and nothing is masked afterwards (r4: global loads of element 0 for those taps, a keep mask accumulated
+//     per element and an and + sbfe per element at staging: ~9 VALU per element);
+//   * the 16 loads of a K-tile are issued back to back before the MFMAs of the current tile and packed in pairs (v_lshl_or) after them;
+//   * DEPTH = 2 (r5): two staging register sets, the loads of tile t + 2 are issued while tile t multiplies, so a load has a whole iteration
+//     to land instead of the ~0.1 us of MFMAs of one tile (the r4 kernel spent ~2.3 us per K-tile with one workgroup per CU: one exposed
+//     load latency per tile).  Twice the staging registers: one workgroup per CU - taken when the grid cannot give a CU two anyway.
 // History (profiles/r04_qconv2d_*.jsonl): first form - four pixels per thread, a counted (c, i, j) walk and four compares per element, four waves
 // (inside qmm_mfma.hip) - spent 3.7 us per K-tile whatever M was; the table on four waves 2.0 us; this file's eight waves: see DESIGN.md 8.
+#include <type_traits>
+
 #include "qh_common.h"
 
 namespace qh {
@@ -58,6 +66,14 @@ template <int DT>
 __device__ __forceinline__ uint32_t pack_rne(float a, float b) {
   using E = Elem<DT>;
   return (uint32_t)__builtin_bit_cast(uint16_t, E::from_f32(a)) | ((uint32_t)__builtin_bit_cast(uint16_t, E::from_f32(b)) << 16);
+}
+
+// two 16-bit elements -> one dword.  As a two-element vector of 16-bit integers: hipcc emits ONE v_perm_b32 that takes the low halves of both
+// registers; written as lo | hi << 16 on unsigned variables it zero-extends first (a v_and per element)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack16(short lo, short hi) {
+  const s16x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 // 16 one-byte weights -> 16 elements of the activation dtype (every int8 / fp8 value is exact in bf16 and fp16)
@@ -194,13 +210,14 @@ __device__ __forceinline__ void store_tile(const Args& a, const f32x4 (&acc)[4][
   }
 }
 
-// WIDE: windows of 64 .. 127 taps (two mask words); the narrow form keeps bit 63 (WIDE: bit 127) of the mask free as the "no such k" tap of
-// a ragged last K-tile.
-template <int DT, int FMT, bool INT_SHIFT, bool WIDE>
-__global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
+// WIDE: windows of 32 .. 127 taps (two 64-bit mask words); the narrow form keeps bit 31 (WIDE: bit 127) of the mask free as the "no such k" tap of
+// a ragged last K-tile.  DEPTH: K-tiles whose gather is in flight (staging register sets).
+template <int DT, int FMT, bool INT_SHIFT, bool WIDE, int DEPTH>
+__global__ void __launch_bounds__(NT, DEPTH == 2 ? 1 : 2) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 ? 2 : 4, DEPTH == 2 ? 2 : 4)))
+qconv2d_mfma_kernel(const Args a) {
   constexpr int PL = planes_of(FMT);      // > 1: a tile's 128 columns are 128 / PL packed rows x PL planes
   constexpr int RPT = BN / PL;            // packed rows per tile
-  constexpr int NO_TAP = WIDE ? 127 : 63;
+  constexpr int NO_TAP = WIDE ? 127 : 31;
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
@@ -215,11 +232,14 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
   const int nk_all = (K + BK - 1) / BK;  // the last K-tile may be ragged: k >= K gathers nothing and multiplies zero weights
   const int kt_lo = (int)((long)sp * nk_all / S), nk = (int)((long)(sp + 1) * nk_all / S) - kt_lo;  // this split's K-tiles: kt_lo + t, t = 0 .. nk - 1
   const int P = N / (PL > 1 ? PL : 2);  // packed rows (int4 / int2)
-  const uint8_t* xb = reinterpret_cast<const uint8_t*>(a.x);
+  // x as a raw buffer whose range is its true size (geometry_ok: < 2^31 bytes): an offset of 0xFFFFFFFF reads as 0
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)(((long)M / (a.OH * a.OW)) * a.cin * a.H * a.W * 2), 0x00020000);
 
   // ---- the thread's pixel ----------------------------------------------------------------------------------------------------------------
   uint32_t px_off;        // byte offset of input element (b, 0, oh sh, ow sw): the window's top-left tap shifted right / down by the padding
-  uint64_t px_taps = 0, px_taps_hi = 0;   // bit i KW + j (taps 64 .. 126 in the second word): tap (i, j) of this pixel's window lies inside the image
+  uint32_t px_pad0 = ~0u;
+  uint64_t px_pad_lo = ~0ull, px_pad_hi = ~0ull;  // WIDE: taps 0 .. 63 / 64 .. 127  // bit i KW + j (32 taps per word; narrow: word 0 only) SET: tap (i, j) of this pixel's window hangs over the padding (or there is no such tap)
   {
     const int L = a.OH * a.OW;
     int m = m0 + (tid & 127);
@@ -232,10 +252,14 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
         const int ih = ih0 + ki * a.dh, iw = iw0 + kj * a.dw;
         if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
           const int t = ki * a.KW + kj;
-          if (!WIDE || t < 64)
-            px_taps |= 1ull << t;
-          else
-            px_taps_hi |= 1ull << (t - 64);
+          if constexpr (WIDE) {
+            if (t < 64)
+              px_pad_lo &= ~(1ull << t);
+            else
+              px_pad_hi &= ~(1ull << (t - 64));
+          } else {
+            px_pad0 &= ~(1u << t);
+          }
         }
       }
   }
@@ -249,10 +273,22 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
   };
 
   // ---- staging registers --------------------------------------------------------------------------------------------------------------------
-  uint32_t g_raw[2][8], g_keep = 0;  // gathered elements of the K-tile in flight (taps over the padding hold x[0]) and their validity bits
-  uint4 rw;                          // 8-bit: 16 weights of row tid >> 2, part tid & 3; int4: 8 packed bytes (rw.x, rw.y) of packed row tid >> 3, part tid & 7
-  float rs[4] = {0.f, 0.f, 0.f, 0.f}, rz[4] = {0.f, 0.f, 0.f, 0.f};  // int4 / int2: scale / shift of the thread's packed row (per plane) in the group of its 8 k
-  auto issue_loads = [&](int t) {
+  // per staging set (tile t uses set t % DEPTH):
+  // gathered elements of a K-tile in flight (taps over the padding read 0).  16-bit variables on purpose: as uint32_t the zero-extension (a v_and
+  // per element) sits next to the LOAD, hipcc schedules it early and waits for the newest loads right after issuing them
+  short g_raw_[DEPTH][2][8];
+  uint4 rw_[DEPTH];                  // 8-bit: 16 weights of row tid >> 2, part tid & 3; int4: 8 packed bytes (rw.x, rw.y) of packed row tid >> 3, part tid & 7
+  float rs_[DEPTH][4], rz_[DEPTH][4];  // int4 / int2: scale / shift of the thread's packed row (per plane) in the group of its 8 k
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) rs_[d][pl] = rz_[d][pl] = 0.f;
+  auto issue_loads = [&](int t, auto set_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+    short (&g_raw)[2][8] = g_raw_[SET];
+    uint4& rw = rw_[SET];
+    float (&rs)[4] = rs_[SET];
+    float (&rz)[4] = rz_[SET];
     const int k0 = (kt_lo + t) * BK;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -262,10 +298,12 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
       const int off[8] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z}, tap[8] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w};
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const uint32_t ok = WIDE ? (uint32_t)((((tap[q] & 64) ? px_taps_hi : px_taps) >> (tap[q] & 63)) & 1ull) : (uint32_t)((px_taps >> tap[q]) & 1ull);
-        g_keep = j == 0 && q == 0 ? ok : g_keep | (ok << (8 * j + q));
-        const uint32_t voff = (px_off + (uint32_t)off[q]) & (0u - ok);
-        g_raw[j][q] = *reinterpret_cast<const uint16_t*>(xb + voff);
+        int pad;  // -1: over the padding -> offset 0xFFFFFFFF -> out of range -> 0
+        if constexpr (WIDE)
+          pad = -(int)((((tap[q] & 64) ? px_pad_hi : px_pad_lo) >> (tap[q] & 63)) & 1ull);
+        else
+          pad = __builtin_amdgcn_sbfe(px_pad0, tap[q], 1);
+        g_raw[j][q] = (short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, (px_off + (uint32_t)off[q]) | (uint32_t)pad, 0, 0);
       }
     }
     if constexpr (PL > 1) {
@@ -312,17 +350,18 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
       }
     }
   };
-  auto write_lds = [&](int buf) {
+  auto write_lds = [&](int buf, auto set_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+    const short (&e)[2][8] = g_raw_[SET];
+    const uint4& rw = rw_[SET];
+    const float (&rs)[4] = rs_[SET];
+    const float (&rz)[4] = rz_[SET];
     uint8_t* sa = smem + buf * 2 * TILE_BYTES;
     uint8_t* sb = sa + TILE_BYTES;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      uint32_t e[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) e[q] = g_raw[j][q] & (uint32_t)__builtin_amdgcn_sbfe(g_keep, 8 * j + q, 1);  // zero where the tap hangs over the padding
+    for (int j = 0; j < 2; ++j)
       *reinterpret_cast<uint4*>(sa + lds_off(tid & 127, (tid >> 7) + 4 * j)) =
-          make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-    }
+          make_uint4(pack16(e[j][0], e[j][1]), pack16(e[j][2], e[j][3]), pack16(e[j][4], e[j][5]), pack16(e[j][6], e[j][7]));
     if constexpr (PL == 2) {
       uint4 lo, hi;
       convert8_i4r<DT, INT_SHIFT>(make_uint2(rw.x, rw.y), rs[0], rz[0], rs[1], rz[1], lo, hi);
@@ -352,17 +391,30 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  using set0 = std::integral_constant<int, 0>;
+  using set1 = std::integral_constant<int, DEPTH - 1>;  // (DEPTH = 1: both name the only set)
   fill_ktab(0);
   if (nk > 1) fill_ktab(1);
   __syncthreads();
-  issue_loads(0);
-  write_lds(0);
+  issue_loads(0, set0{});
+  if constexpr (DEPTH == 2) {
+    if (nk > 1) issue_loads(1, set1{});
+    __syncthreads();  // every thread has read tables 0 and 1
+    if (nk > 2) fill_ktab(2);
+  }
+  write_lds(0, set0{});
   __syncthreads();
   int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) issue_loads(kt + 1);
-    // table of tile kt + 2 into the buffer whose last reader was tile kt's gather (an iteration ago); visible after this iteration's barrier
-    if (kt + 2 < nk) fill_ktab(kt + 2);
+  // iteration kt: the gather of tile kt + DEPTH is issued into the set tile kt left free (staged an iteration ago); its tap table was filled an
+  // iteration (or the prologue) ago, the table of tile kt + DEPTH + 1 goes into the buffer whose last reader was the gather issued an iteration ago
+  // (both behind a barrier); tile kt multiplies; tile kt + 1 is staged into the other LDS buffer
+  // STEADY (compile time): every condition below holds - the loop body is branch-free, so that hipcc's s_waitcnt pass sees ONE path around the
+  // back edge (with run-time conditions it assumes a trip that skipped the staging, finds the set's loads still pending at the loop head and
+  // drains them - vmcnt(0) - before the next gather is issued: the overlap DEPTH = 2 exists for was gone, read off the ISA)
+  auto iteration = [&](int kt, auto this_set, auto next_set, auto steady) {
+    constexpr bool STEADY = decltype(steady)::value;
+    if (STEADY || kt + DEPTH < nk) issue_loads(kt + DEPTH, this_set);
+    if (STEADY || kt + DEPTH + 1 < nk) fill_ktab(kt + DEPTH + 1);
     const uint8_t* sa = smem + cur * 2 * TILE_BYTES;
     const uint8_t* sb = sa + TILE_BYTES;
 #pragma unroll
@@ -378,10 +430,22 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = Mma<DT>::run(fa[i], fb[j], acc[i][j]);
     }
-    if (kt + 1 < nk) write_lds(cur ^ 1);
+    if (STEADY || kt + 1 < nk) write_lds(cur ^ 1, next_set);
     __syncthreads();
     cur ^= 1;
+  };
+  using yes = std::true_type;
+  using no = std::false_type;
+  int kt = 0;
+  for (; kt + DEPTH + 2 < nk; kt += 2) {  // both tiles still have a tile kt + DEPTH + 1 whose table is to be filled
+    iteration(kt, set0{}, set1{}, yes{});
+    iteration(kt + 1, set1{}, set0{}, yes{});
   }
+  // at most DEPTH + 2 tiles left (kt is even): straight-line, run-time conditions
+  if (kt < nk) iteration(kt, set0{}, set1{}, no{});
+  if (kt + 1 < nk) iteration(kt + 1, set1{}, set0{}, no{});
+  if (kt + 2 < nk) iteration(kt + 2, set0{}, set1{}, no{});
+  if (kt + 3 < nk) iteration(kt + 3, set1{}, set0{}, no{});
 
   if (S > 1) {  // park the partial sums: one 1 KiB store per wave and fragment
     f32x4* mine = reinterpret_cast<f32x4*>(a.partials) + ((size_t)(sp * gridDim.y + blockIdx.y) * gridDim.x + nt) * (8 * 8 * 64) + (wave * 8) * 64 + lane;
@@ -443,22 +507,34 @@ static int pick_split(int64_t M, int64_t N, int64_t K) {
 }
 static size_t split_workspace(int64_t M, int64_t N, int S) { return S <= 1 ? 0 : (size_t)S * ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (BM * BN * 4); }
 
+template <int DT, int FMT, bool INT_SHIFT, bool WIDE, int DEPTH>
+static int launch_d(const Args& a, int ntiles, int mtiles, hipStream_t stream) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipLaunchKernelGGL((qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE, DEPTH>), dim3(ntiles, mtiles, a.S), dim3(NT), LDS_BYTES, stream, a);
+  return 0;
+}
 template <int DT, int FMT, bool INT_SHIFT, bool WIDE>
 static int launch_w(Args a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   constexpr int PL = planes_of(FMT);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   const int ntiles = PL > 1 ? (a.N / PL + BN / PL - 1) / (BN / PL) : (a.N + BN - 1) / BN, mtiles = (a.M + BM - 1) / BM;
   int S = pick_split(a.M, a.N, a.K);
   if (S > 1 && (!workspace || workspace_bytes < split_workspace(a.M, a.N, S) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
   a.S = S;
   a.partials = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL((qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE>), dim3(ntiles, mtiles, S), dim3(NT), LDS_BYTES, stream, a);
+  // two K-tiles of gather in flight (one workgroup per CU: twice the staging registers) while the grid gives few CUs a second workgroup anyway;
+  // beyond that two co-resident workgroups with one tile in flight each hide each other's load latency (QUANTO_HIP_CONV_DEPTH = 1 / 2 forces)
+  const int forced = env_int("QUANTO_HIP_CONV_DEPTH", 0);
+  const bool deep = forced ? forced == 2 : (long)ntiles * mtiles * S <= env_int("QUANTO_HIP_CONV_DEEP_MAX_WG", 320);
+  if (deep)
+    launch_d<DT, FMT, INT_SHIFT, WIDE, 2>(a, ntiles, mtiles, stream);
+  else
+    launch_d<DT, FMT, INT_SHIFT, WIDE, 1>(a, ntiles, mtiles, stream);
   if (S > 1) hipLaunchKernelGGL((qconv2d_reduce_kernel<DT, PL>), dim3(ntiles, mtiles, 8), dim3(64), 0, stream, a);
   return launch_status();
 }
 template <int DT, int FMT, bool INT_SHIFT>
 static int launch(Args a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  return a.KH * a.KW > 63 ? launch_w<DT, FMT, INT_SHIFT, true>(a, workspace, workspace_bytes, stream)
+  return a.KH * a.KW > 31 ? launch_w<DT, FMT, INT_SHIFT, true>(a, workspace, workspace_bytes, stream)
                           : launch_w<DT, FMT, INT_SHIFT, false>(a, workspace, workspace_bytes, stream);
 }
 

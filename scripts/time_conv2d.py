@@ -44,6 +44,12 @@ for (B, C, H, OC, k, s, p) in SHAPES:
         direct = lambda: torch.ops.quanto.qbytes_conv2d(x, w._data, w._scale, q.bias, [s, s], [p, p], [1, 1])  # noqa: E731
     else:
         direct = lambda: torch.ops.quanto.qbits_conv2d(x, w._data._data, w._scale, w._shift, q.bias, 4, w._group_size, list(w.shape), [s, s], [p, p], [1, 1])  # noqa: E731
+    if os.environ.get("TIME_CONV2D_DIRECT_ONLY"):  # A/B of kernel knobs: the convolution kernel alone
+        with torch.no_grad():
+            t_dir = _time_graph(direct, 5)
+        print(json.dumps({"weights": WEIGHTS, "B": B, "C": C, "H": H, "OC": OC, "k": k, "stride": s, "K": C * k * k, "conv_kernel_direct_us": round(t_dir, 1),
+                          "depth": os.environ.get("QUANTO_HIP_CONV_DEPTH", "auto"), "split": os.environ.get("QUANTO_HIP_CONV_SPLIT", "auto")}), flush=True)
+        continue
     with torch.no_grad():
         t_dir = _time_graph(direct, 5)
         t_imp = _time_graph(lambda: q(x), 5)

@@ -47,6 +47,22 @@ def time_us(fn, n=20, reps=5):
     return float(np.median(out))
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "large":  # r5: prefill sizes - the large-tile int4 GEMM (no dense weight) against dequantize + dense GEMM
+    for (M, N, K, gs) in ((4096, 4096, 4800, 96), (4096, 4096, 4096, 32), (4096, 4096, 4096, 128), (8192, 8192, 8256, 96), (8192, 8192, 8192, 32),
+                          (8192, 8192, 8192, 128), (2048, 14336, 4800, 96)):
+        x, packed, scale, shift = problem(M, N, K, gs)
+        row = {"M": M, "N": N, "K": K, "group_size": gs}
+        for kernel in ("auto", "mfma_large4", "dequant_mfma"):
+            try:
+                us = time_us(lambda: lib.qbits_mm(x, packed, scale, shift, None, 4, gs, N, K, kernel=kernel), n=5)
+                row[kernel] = round(us, 1)
+                if kernel == "auto":
+                    row["auto_kernel"] = lib.last_kernel()
+            except Exception as e:  # noqa: BLE001
+                row[kernel] = type(e).__name__
+        print(json.dumps(row), flush=True)
+    sys.exit(0)
+
 for gs in (64, 32, None):
     for M in (8, 24, 32, 64, 128, 192):
         N = K = 4096
