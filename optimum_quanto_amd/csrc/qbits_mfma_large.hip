@@ -29,9 +29,10 @@
 //     phase kk = 1 the next tile's k-half-0 operands - one pair of weights every step;
 //   * epilogue: the tile is parked in LDS and stored as whole 256-byte rows per column block.
 // Group sizes: multiples of 64 and per-channel (a K-tile lies inside one group), and - HG, r5 - the other multiples of 32 the reference
-// produces for K % 128 != 0 layers (nn/qmodule.py:121-129: 96, 32): there a group boundary may fall between the two k-halves of a K-tile,
-// so the scale / shift entries are looked up per k-half (the table read of the next tile's k-half 1 goes into the registers of this
-// tile's, dead once its first phase has converted).  int4 only.
+// produces for K % 128 != 0 layers (nn/qmodule.py:121-129: 96, 32): there a group boundary may fall on k = 32 of a K-tile.  A lane's 16
+// packed bytes are k = 16 fg .. 16 fg + 15 of the tile (its two MFMA k-halves are the lower and the upper 8 of them), so lane groups
+// fg = 0, 1 take the scale / shift of the group of the tile's first 32 k and fg = 2, 3 that of its last 32 - one table entry per lane and
+// tile, as before, with a lane-dependent group index.  int4 only.
 #include <type_traits>
 
 #include "qmm_large_common.h"
@@ -273,14 +274,13 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  // group bookkeeping (wave-uniform): group of the current tile (HG: of its k-half 0), k offset of the current tile inside its group
+  // group bookkeeping (wave-uniform): group of the current tile (HG: of its first 32 k), k offset of the current tile inside its group
   int g_cur = 0, k_in_g = 0;
-  float sc[2], zc[2], sn[2], zn[2];  // scale / shift (per plane) of the current tile's (HG: its k-half 1's) and of the next tile's (k-half 0's) group
-  table_read(0, sc, zc);
+  float sc[2], zc[2], sn[2], zn[2];  // scale / shift (per plane) of the current and of the next tile's group (HG: the group of the lane's 16 k)
+  table_read(HG && fg >= 2 && BK / 2 >= C ? 1 : 0, sc, zc);
   raw = read_w(0);
 #pragma unroll
   for (int c = 0; c < 8; ++c) w0[c >> 2][c & 3] = convert(raw, 0, c, sc, zc);
-  if constexpr (HG) table_read(BK / 2 >= C ? 1 : 0, sc, zc);  // tile 0's k-half 1
   xf[0] = *reinterpret_cast<const V8*>(smem + aoff[0]);
   xf[1] = *reinterpret_cast<const V8*>(smem + aoff[0] + 2048);
   xf[2] = *reinterpret_cast<const V8*>(smem + aoff[0] + 4096);
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
     const bool dma = dma_tag, barrier = barrier_tag;  // integral_constants in the steady state (no branches), run-time flags in the tail
     const uint8_t* st = smem + PS * STAGE_BYTES;
     const uint8_t* sx = smem + PN * STAGE_BYTES;
-    // the next tile's group (HG: the groups of its two k-halves; C is a multiple of 32, so a k-half lies inside one group)
+    // the next tile's group (HG: the groups of its first and of its last 32 k; C is a multiple of 32)
     int g_next = g_cur, k_next = k_in_g + BK;
     int g_next1 = 0;
     if constexpr (HG) {
@@ -313,8 +313,7 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
     for (int s = 0; s < STEPS; ++s) {
       const int kk = s / MI, i = s % MI;
       if (s == MI) {  // before the first conversion of the second phase: the next tile's scale / shift and packed bytes
-        table_read(g_next, sn, zn);
-        if constexpr (HG) table_read(g_next1, sc, zc);  // the next tile's k-half 1: this tile's phase-0 conversions are done with sc / zc
+        table_read(HG && fg >= 2 ? g_next1 : g_next, sn, zn);
         raw = read_w(PN);
       }
 #pragma unroll
@@ -362,12 +361,10 @@ __global__ void __launch_bounds__(NW * 64, 1) qbits_mfma_large_kernel(const Args
     }
     g_cur = g_next;
     k_in_g = k_next;
-    if constexpr (!HG) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        sc[j] = sn[j];
-        zc[j] = zn[j];
-      }
+    for (int j = 0; j < 2; ++j) {
+      sc[j] = sn[j];
+      zc[j] = zn[j];
     }
   };
   using yes = std::integral_constant<bool, true>;

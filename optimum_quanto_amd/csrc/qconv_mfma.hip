@@ -44,6 +44,7 @@ constexpr int planes_of(int fmt) { return fmt == W_I4R ? 2 : (fmt == W_I2R ? 4 :
 // global_load_dwordx2 / x4, which the gfx950 memory pipeline serves at any alignment (unaligned access mode, the HSA default)
 struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(1))) U2u { uint32_t x, y; };
+struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };
 
 // 128-byte rows of eight 16-byte chunks; chunk kc of row r sits at position kc ^ (r & 7): the fragment reads (16 rows x 4 chunks) and the staging
 // writes are conflict-free
@@ -211,13 +212,21 @@ __device__ __forceinline__ void store_tile(const Args& a, const f32x4 (&acc)[4][
 }
 
 // WIDE: windows of 32 .. 127 taps (two 64-bit mask words); the narrow form keeps bit 31 (WIDE: bit 127) of the mask free as the "no such k" tap of
-// a ragged last K-tile.  DEPTH: K-tiles whose gather is in flight (staging register sets).
-template <int DT, int FMT, bool INT_SHIFT, bool WIDE, int DEPTH>
-__global__ void __launch_bounds__(NT, DEPTH == 2 ? 1 : 2) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 ? 2 : 4, DEPTH == 2 ? 2 : 4)))
-qconv2d_mfma_kernel(const Args a) {
+// a ragged last K-tile.
+// PAIR (r5): a thread gathers TWO neighbouring output pixels of one row (ow even, ow + 1) with ONE 4-byte load per tap - half the load
+// instructions per tile, and the load instructions a workgroup pushes through its CU's address unit are what bounds this kernel (two K-tiles of
+// gather in flight instead of one changed nothing, profiles/r05_qconv2d_depth2_negative.jsonl).  Needs stride 1 along the width (the two pixels'
+// taps are neighbours in memory) and an even OW (a pair never straddles an output row).  Thread (pair tid & 63, chunk kc = tid >> 6 - k is still
+// uniform across a wave, whose 64 loads now cover 128 neighbouring pixels).  Borders: per tap a validity bit for each of the two pixels; left
+// border (iw = -1 for the first pixel only): load one element further right and shift the dword up by 16; right border (iw = W for the second
+// pixel only): load one element further left and shift down; neither valid: element 0 and a zero selector.  The shifts are one v_perm_b32 with
+// a per-lane selector; the loads stay inside x whatever the tap (global loads at 2-byte alignment: unaligned access mode, r4 probe).
+template <int DT, int FMT, bool INT_SHIFT, bool WIDE, bool PAIR>
+__global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
   constexpr int PL = planes_of(FMT);      // > 1: a tile's 128 columns are 128 / PL packed rows x PL planes
   constexpr int RPT = BN / PL;            // packed rows per tile
   constexpr int NO_TAP = WIDE ? 127 : 31;
+  constexpr int NCH = PAIR ? 1 : 2;       // 8-element chunks of a K-tile per thread
   using E = Elem<DT>;
   using T = typename E::T;
   using V8 = typename Mma<DT>::V8;
@@ -232,37 +241,48 @@ qconv2d_mfma_kernel(const Args a) {
   const int nk_all = (K + BK - 1) / BK;  // the last K-tile may be ragged: k >= K gathers nothing and multiplies zero weights
   const int kt_lo = (int)((long)sp * nk_all / S), nk = (int)((long)(sp + 1) * nk_all / S) - kt_lo;  // this split's K-tiles: kt_lo + t, t = 0 .. nk - 1
   const int P = N / (PL > 1 ? PL : 2);  // packed rows (int4 / int2)
+  const uint8_t* xb = reinterpret_cast<const uint8_t*>(a.x);
   // x as a raw buffer whose range is its true size (geometry_ok: < 2^31 bytes): an offset of 0xFFFFFFFF reads as 0
   const __amdgpu_buffer_rsrc_t xrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)(((long)M / (a.OH * a.OW)) * a.cin * a.H * a.W * 2), 0x00020000);
 
-  // ---- the thread's pixel ----------------------------------------------------------------------------------------------------------------
-  uint32_t px_off;        // byte offset of input element (b, 0, oh sh, ow sw): the window's top-left tap shifted right / down by the padding
-  uint32_t px_pad0 = ~0u;
-  uint64_t px_pad_lo = ~0ull, px_pad_hi = ~0ull;  // WIDE: taps 0 .. 63 / 64 .. 127  // bit i KW + j (32 taps per word; narrow: word 0 only) SET: tap (i, j) of this pixel's window hangs over the padding (or there is no such tap)
+  // ---- the thread's pixel (PAIR: its two pixels m, m + 1) ------------------------------------------------------------------------------------
+  // px_off: byte offset of input element (b, 0, oh sh, ow sw) - the window's top-left tap shifted right / down by the padding.
+  // Bit i KW + j of a validity word (64 taps per word; narrow: 32 bits) is SET when tap (i, j) of the pixel's window lies inside the image.
+  uint32_t px_off;
+  uint64_t ok_a0 = 0, ok_a1 = 0, ok_b0 = 0, ok_b1 = 0;  // first / second pixel of the pair, taps 0..63 / 64..127 (scalars: a dynamically indexed array would live in scratch)
   {
     const int L = a.OH * a.OW;
-    int m = m0 + (tid & 127);
-    m = m < M ? m : M - 1;
+    int m = PAIR ? m0 + 2 * (tid & 63) : m0 + (tid & 127);
+    m = m < M ? m : (PAIR ? M - 2 : M - 1);
     const int b = m / L, l = m - b * L, oh = l / a.OW, ow = l - oh * a.OW;
     const int ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
     px_off = 2u * (uint32_t)(b * a.cin * a.H * a.W + oh * a.sh * a.W + ow * a.sw);
     for (int ki = 0; ki < a.KH; ++ki)
       for (int kj = 0; kj < a.KW; ++kj) {
         const int ih = ih0 + ki * a.dh, iw = iw0 + kj * a.dw;
-        if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
-          const int t = ki * a.KW + kj;
-          if constexpr (WIDE) {
-            if (t < 64)
-              px_pad_lo &= ~(1ull << t);
-            else
-              px_pad_hi &= ~(1ull << (t - 64));
-          } else {
-            px_pad0 &= ~(1u << t);
-          }
+        const int t = ki * a.KW + kj;
+        const uint64_t bit = 1ull << (t & 63);
+        const bool row_ok = ih >= 0 && ih < a.H;
+        const bool hi = WIDE && t >= 64;
+        if (row_ok && iw >= 0 && iw < a.W) {
+          ok_a0 |= hi ? 0ull : bit;
+          ok_a1 |= hi ? bit : 0ull;
+        }
+        if (PAIR && row_ok && iw + 1 >= 0 && iw + 1 < a.W) {  // (stride 1 along the width)
+          ok_b0 |= hi ? 0ull : bit;
+          ok_b1 |= hi ? bit : 0ull;
         }
       }
   }
+  // -1 when tap `tp` of pixel `px` of the pair lies inside the image, else 0
+  auto tap_ok = [&](int px, int tp) -> int {
+    const uint64_t w0 = px ? ok_b0 : ok_a0, w1 = px ? ok_b1 : ok_a1;  // (px is a literal at every call)
+    if constexpr (WIDE)
+      return -(int)((((tp & 64) ? w1 : w0) >> (tp & 63)) & 1ull);
+    else
+      return __builtin_amdgcn_sbfe((uint32_t)w0, tp, 1);
+  };
   int2* ktab = reinterpret_cast<int2*>(smem + 2 * 2 * TILE_BYTES);  // [2][64] {byte offset relative to px_off (signed), tap number}
   auto fill_ktab = [&](int t) {
     if (tid < BK) {
@@ -273,37 +293,36 @@ qconv2d_mfma_kernel(const Args a) {
   };
 
   // ---- staging registers --------------------------------------------------------------------------------------------------------------------
-  // per staging set (tile t uses set t % DEPTH):
-  // gathered elements of a K-tile in flight (taps over the padding read 0).  16-bit variables on purpose: as uint32_t the zero-extension (a v_and
+  // gathered elements of the K-tile in flight (taps over the padding read 0).  16-bit variables on purpose: as uint32_t the zero-extension (a v_and
   // per element) sits next to the LOAD, hipcc schedules it early and waits for the newest loads right after issuing them
-  short g_raw_[DEPTH][2][8];
-  uint4 rw_[DEPTH];                  // 8-bit: 16 weights of row tid >> 2, part tid & 3; int4: 8 packed bytes (rw.x, rw.y) of packed row tid >> 3, part tid & 7
-  float rs_[DEPTH][4], rz_[DEPTH][4];  // int4 / int2: scale / shift of the thread's packed row (per plane) in the group of its 8 k
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d)
-#pragma unroll
-    for (int pl = 0; pl < 4; ++pl) rs_[d][pl] = rz_[d][pl] = 0.f;
-  auto issue_loads = [&](int t, auto set_tag) {
-    constexpr int SET = decltype(set_tag)::value;
-    short (&g_raw)[2][8] = g_raw_[SET];
-    uint4& rw = rw_[SET];
-    float (&rs)[4] = rs_[SET];
-    float (&rz)[4] = rz_[SET];
+  short g_raw[2][8];
+  uint32_t g_pair[8], g_sel[8];      // PAIR: the dword of both pixels per tap and the v_perm selector that realigns / zeroes it
+  uint4 rw;                          // 8-bit: 16 weights of row tid >> 2, part tid & 3; int4: 8 packed bytes (rw.x, rw.y) of packed row tid >> 3, part tid & 7
+  float rs[4] = {0.f, 0.f, 0.f, 0.f}, rz[4] = {0.f, 0.f, 0.f, 0.f};  // int4 / int2: scale / shift of the thread's packed row (per plane) in the group of its 8 k
+  auto issue_loads = [&](int t) {
     const int k0 = (kt_lo + t) * BK;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int kc = __builtin_amdgcn_readfirstlane(tid >> 7) + 4 * j;
+    for (int j = 0; j < NCH; ++j) {
+      const int kc = PAIR ? wave : __builtin_amdgcn_readfirstlane(tid >> 7) + 4 * j;
       const int4* tp = reinterpret_cast<const int4*>(ktab + (t & 1) * BK + kc * 8);
       const int4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
       const int off[8] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z}, tap[8] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w};
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        int pad;  // -1: over the padding -> offset 0xFFFFFFFF -> out of range -> 0
-        if constexpr (WIDE)
-          pad = -(int)((((tap[q] & 64) ? px_pad_hi : px_pad_lo) >> (tap[q] & 63)) & 1ull);
-        else
-          pad = __builtin_amdgcn_sbfe(px_pad0, tap[q], 1);
-        g_raw[j][q] = (short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, (px_off + (uint32_t)off[q]) | (uint32_t)pad, 0, 0);
+        if constexpr (PAIR) {
+          const int va = tap_ok(0, tap[q]), vb = tap_ok(1, tap[q]);  // -1: valid
+          // first pixel over the left border (va = 0, vb = -1): + 2 bytes; second pixel over the right border (va = -1, vb = 0): - 2 bytes
+          const uint32_t addr = (px_off + (uint32_t)off[q] + (uint32_t)(2 * (vb - va))) & (uint32_t)(va | vb);
+          constexpr uint32_t IDENT = 0x07060504u, UP16 = 0x05040c0cu, DOWN16 = 0x0c0c0706u, ZERO = 0x0c0c0c0cu;
+          uint32_t sel = ((uint32_t)va & IDENT) | (~(uint32_t)va & UP16);     // first pixel invalid: its half becomes 0, the second pixel's element moves up
+          sel = ((uint32_t)vb & sel) | (~(uint32_t)vb & DOWN16);             // second pixel invalid: the first pixel's element moves down
+          sel = ((uint32_t)(va | vb) & sel) | (~(uint32_t)(va | vb) & ZERO);   // neither
+          g_sel[q] = sel;
+          g_pair[q] = reinterpret_cast<const U1u*>(xb + addr)->x;
+        } else {
+          // -1: over the padding -> offset 0xFFFFFFFF -> out of range -> 0
+          g_raw[j][q] = (short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, (px_off + (uint32_t)off[q]) | ~(uint32_t)tap_ok(0, tap[q]), 0, 0);
+        }
       }
     }
     if constexpr (PL > 1) {
@@ -350,18 +369,27 @@ qconv2d_mfma_kernel(const Args a) {
       }
     }
   };
-  auto write_lds = [&](int buf, auto set_tag) {
-    constexpr int SET = decltype(set_tag)::value;
-    const short (&e)[2][8] = g_raw_[SET];
-    const uint4& rw = rw_[SET];
-    const float (&rs)[4] = rs_[SET];
-    const float (&rz)[4] = rz_[SET];
+  auto write_lds = [&](int buf) {
     uint8_t* sa = smem + buf * 2 * TILE_BYTES;
     uint8_t* sb = sa + TILE_BYTES;
+    if constexpr (PAIR) {
+      uint32_t d[8];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      *reinterpret_cast<uint4*>(sa + lds_off(tid & 127, (tid >> 7) + 4 * j)) =
-          make_uint4(pack16(e[j][0], e[j][1]), pack16(e[j][2], e[j][3]), pack16(e[j][4], e[j][5]), pack16(e[j][6], e[j][7]));
+      for (int q = 0; q < 8; ++q) d[q] = __builtin_amdgcn_perm(g_pair[q], 0u, g_sel[q]);  // [first pixel | second pixel] of tap q, realigned, padding zeroed
+      const int row = 2 * (tid & 63);
+      // first pixel: the low halves of the eight dwords; second pixel: the high halves
+      *reinterpret_cast<uint4*>(sa + lds_off(row, wave)) =
+          make_uint4(__builtin_amdgcn_perm(d[1], d[0], 0x05040100u), __builtin_amdgcn_perm(d[3], d[2], 0x05040100u),
+                     __builtin_amdgcn_perm(d[5], d[4], 0x05040100u), __builtin_amdgcn_perm(d[7], d[6], 0x05040100u));
+      *reinterpret_cast<uint4*>(sa + lds_off(row + 1, wave)) =
+          make_uint4(__builtin_amdgcn_perm(d[1], d[0], 0x07060302u), __builtin_amdgcn_perm(d[3], d[2], 0x07060302u),
+                     __builtin_amdgcn_perm(d[5], d[4], 0x07060302u), __builtin_amdgcn_perm(d[7], d[6], 0x07060302u));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<uint4*>(sa + lds_off(tid & 127, (tid >> 7) + 4 * j)) =
+            make_uint4(pack16(g_raw[j][0], g_raw[j][1]), pack16(g_raw[j][2], g_raw[j][3]), pack16(g_raw[j][4], g_raw[j][5]), pack16(g_raw[j][6], g_raw[j][7]));
+    }
     if constexpr (PL == 2) {
       uint4 lo, hi;
       convert8_i4r<DT, INT_SHIFT>(make_uint2(rw.x, rw.y), rs[0], rz[0], rs[1], rz[1], lo, hi);
@@ -391,30 +419,17 @@ qconv2d_mfma_kernel(const Args a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  using set0 = std::integral_constant<int, 0>;
-  using set1 = std::integral_constant<int, DEPTH - 1>;  // (DEPTH = 1: both name the only set)
   fill_ktab(0);
   if (nk > 1) fill_ktab(1);
   __syncthreads();
-  issue_loads(0, set0{});
-  if constexpr (DEPTH == 2) {
-    if (nk > 1) issue_loads(1, set1{});
-    __syncthreads();  // every thread has read tables 0 and 1
-    if (nk > 2) fill_ktab(2);
-  }
-  write_lds(0, set0{});
+  issue_loads(0);
+  write_lds(0);
   __syncthreads();
   int cur = 0;
-  // iteration kt: the gather of tile kt + DEPTH is issued into the set tile kt left free (staged an iteration ago); its tap table was filled an
-  // iteration (or the prologue) ago, the table of tile kt + DEPTH + 1 goes into the buffer whose last reader was the gather issued an iteration ago
-  // (both behind a barrier); tile kt multiplies; tile kt + 1 is staged into the other LDS buffer
-  // STEADY (compile time): every condition below holds - the loop body is branch-free, so that hipcc's s_waitcnt pass sees ONE path around the
-  // back edge (with run-time conditions it assumes a trip that skipped the staging, finds the set's loads still pending at the loop head and
-  // drains them - vmcnt(0) - before the next gather is issued: the overlap DEPTH = 2 exists for was gone, read off the ISA)
-  auto iteration = [&](int kt, auto this_set, auto next_set, auto steady) {
-    constexpr bool STEADY = decltype(steady)::value;
-    if (STEADY || kt + DEPTH < nk) issue_loads(kt + DEPTH, this_set);
-    if (STEADY || kt + DEPTH + 1 < nk) fill_ktab(kt + DEPTH + 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) issue_loads(kt + 1);
+    // table of tile kt + 2 into the buffer whose last reader was tile kt's gather (an iteration ago); visible after this iteration's barrier
+    if (kt + 2 < nk) fill_ktab(kt + 2);
     const uint8_t* sa = smem + cur * 2 * TILE_BYTES;
     const uint8_t* sb = sa + TILE_BYTES;
 #pragma unroll
@@ -430,22 +445,10 @@ qconv2d_mfma_kernel(const Args a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = Mma<DT>::run(fa[i], fb[j], acc[i][j]);
     }
-    if (STEADY || kt + 1 < nk) write_lds(cur ^ 1, next_set);
+    if (kt + 1 < nk) write_lds(cur ^ 1);
     __syncthreads();
     cur ^= 1;
-  };
-  using yes = std::true_type;
-  using no = std::false_type;
-  int kt = 0;
-  for (; kt + DEPTH + 2 < nk; kt += 2) {  // both tiles still have a tile kt + DEPTH + 1 whose table is to be filled
-    iteration(kt, set0{}, set1{}, yes{});
-    iteration(kt + 1, set1{}, set0{}, yes{});
   }
-  // at most DEPTH + 2 tiles left (kt is even): straight-line, run-time conditions
-  if (kt < nk) iteration(kt, set0{}, set1{}, no{});
-  if (kt + 1 < nk) iteration(kt + 1, set1{}, set0{}, no{});
-  if (kt + 2 < nk) iteration(kt + 2, set0{}, set1{}, no{});
-  if (kt + 3 < nk) iteration(kt + 3, set1{}, set0{}, no{});
 
   if (S > 1) {  // park the partial sums: one 1 KiB store per wave and fragment
     f32x4* mine = reinterpret_cast<f32x4*>(a.partials) + ((size_t)(sp * gridDim.y + blockIdx.y) * gridDim.x + nt) * (8 * 8 * 64) + (wave * 8) * 64 + lane;
@@ -507,11 +510,10 @@ static int pick_split(int64_t M, int64_t N, int64_t K) {
 }
 static size_t split_workspace(int64_t M, int64_t N, int S) { return S <= 1 ? 0 : (size_t)S * ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (BM * BN * 4); }
 
-template <int DT, int FMT, bool INT_SHIFT, bool WIDE, int DEPTH>
-static int launch_d(const Args& a, int ntiles, int mtiles, hipStream_t stream) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  hipLaunchKernelGGL((qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE, DEPTH>), dim3(ntiles, mtiles, a.S), dim3(NT), LDS_BYTES, stream, a);
-  return 0;
+template <int DT, int FMT, bool INT_SHIFT, bool WIDE, bool PAIR>
+static void launch_k(const Args& a, int ntiles, int mtiles, hipStream_t stream) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipLaunchKernelGGL((qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE, PAIR>), dim3(ntiles, mtiles, a.S), dim3(NT), LDS_BYTES, stream, a);
 }
 template <int DT, int FMT, bool INT_SHIFT, bool WIDE>
 static int launch_w(Args a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -521,14 +523,12 @@ static int launch_w(Args a, void* workspace, size_t workspace_bytes, hipStream_t
   if (S > 1 && (!workspace || workspace_bytes < split_workspace(a.M, a.N, S) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
   a.S = S;
   a.partials = reinterpret_cast<float*>(workspace);
-  // two K-tiles of gather in flight (one workgroup per CU: twice the staging registers) while the grid gives few CUs a second workgroup anyway;
-  // beyond that two co-resident workgroups with one tile in flight each hide each other's load latency (QUANTO_HIP_CONV_DEPTH = 1 / 2 forces)
-  const int forced = env_int("QUANTO_HIP_CONV_DEPTH", 0);
-  const bool deep = forced ? forced == 2 : (long)ntiles * mtiles * S <= env_int("QUANTO_HIP_CONV_DEEP_MAX_WG", 320);
-  if (deep)
-    launch_d<DT, FMT, INT_SHIFT, WIDE, 2>(a, ntiles, mtiles, stream);
+  // two output pixels per load wherever the geometry allows it (QUANTO_HIP_CONV_PAIR=0: experiments)
+  const bool pair = a.sw == 1 && a.OW % 2 == 0 && a.W >= 2 && env_int("QUANTO_HIP_CONV_PAIR", 1) != 0;
+  if (pair)
+    launch_k<DT, FMT, INT_SHIFT, WIDE, true>(a, ntiles, mtiles, stream);
   else
-    launch_d<DT, FMT, INT_SHIFT, WIDE, 1>(a, ntiles, mtiles, stream);
+    launch_k<DT, FMT, INT_SHIFT, WIDE, false>(a, ntiles, mtiles, stream);
   if (S > 1) hipLaunchKernelGGL((qconv2d_reduce_kernel<DT, PL>), dim3(ntiles, mtiles, 8), dim3(64), 0, stream, a);
   return launch_status();
 }

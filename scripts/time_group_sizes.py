@@ -49,7 +49,7 @@ def time_us(fn, n=20, reps=5):
 
 if len(sys.argv) > 1 and sys.argv[1] == "large":  # r5: prefill sizes - the large-tile int4 GEMM (no dense weight) against dequantize + dense GEMM
     for (M, N, K, gs) in ((4096, 4096, 4800, 96), (4096, 4096, 4096, 32), (4096, 4096, 4096, 128), (8192, 8192, 8256, 96), (8192, 8192, 8192, 32),
-                          (8192, 8192, 8192, 128), (2048, 14336, 4800, 96)):
+                          (8192, 8192, 8192, 128), (2048, 14336, 4800, 96), (16384, 8192, 8192, 128), (4096, 28672, 8192, 128), (4096, 8192, 28672, 128)):
         x, packed, scale, shift = problem(M, N, K, gs)
         row = {"M": M, "N": N, "K": K, "group_size": gs}
         for kernel in ("auto", "mfma_large4", "dequant_mfma"):

@@ -342,6 +342,45 @@ def test_qconv2d_implicit_gemm_k_split_gpu(monkeypatch, wq, split):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("wq", ["qint8", "qfloat8_e4m3fn", "qint4", "qint2"])
+@pytest.mark.parametrize("cin,cout,k,s,p,d,hw", [(64, 96, 3, 1, 1, 1, (13, 12)),          # both borders of every row: the +2 / -2 byte realignments
+                                                 (64, 40, 3, (2, 1), (0, 2), 1, (9, 10)),    # padding 2: taps with NEITHER pixel inside the row; stride 2 down
+                                                 (32, 48, (3, 5), 1, (1, 2), (1, 2), (8, 14)),  # dilation 2 along the width, rectangular window
+                                                 (16, 24, 3, 1, 1, 1, (5, 2)),              # W = OW = 2: a pair is a whole row
+                                                 (128, 72, 1, 1, 0, 1, (6, 6)),             # pointwise: no border at all
+                                                 (8, 40, 7, 1, 3, 1, (10, 12)),             # 49 taps: two 64-bit validity words per pixel
+                                                 (3, 32, 3, 1, 1, 1, (20, 16)),             # K = 27: a ragged K-tile
+                                                 (64, 64, (1, 2), 1, 0, 1, (4, 9))])        # OW = 8 from W = 9 (even window along the width)
+def test_qconv2d_pair_gather_gpu(monkeypatch, dt, wq, cin, cout, k, s, p, d, hw):
+    """r5: two neighbouring output pixels per 4-byte load (stride 1 along the width, even OW).  Same staged operand as the one-pixel gather, so
+    the two kernels' outputs must be IDENTICAL bit for bit (the one-pixel form is forced through QUANTO_HIP_CONV_PAIR=0), and each passes the
+    float64 gate; borders on both sides, paddings wider than one element, dilation, W = 2, ragged M, every weight format."""
+    torch.manual_seed(cin * 3 + cout)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, dilation=d).to(TORCH_DT[dt])
+    q = Q.QConv2d.from_module(conv, weights=getattr(Q, wq))
+    Q.freeze(q)
+    q = q.cuda()
+    x = torch.randn(3, cin, *hw).to(TORCH_DT[dt])
+    sub = wq in ("qint4", "qint2")
+    with torch.no_grad():
+        y = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == {"qint4": "conv2d_mfma_int4", "qint2": "conv2d_mfma_int2"}.get(wq, "conv2d_mfma")
+        assert y.shape[-1] % 2 == 0
+        monkeypatch.setenv("QUANTO_HIP_CONV_PAIR", "0")
+        y1 = q(x.cuda())
+        monkeypatch.delenv("QUANTO_HIP_CONV_PAIR")
+        if sub:
+            prod = torch.nn.functional.conv2d(x.double(), _oracle_dequantized(q.weight, dt), None, conv.stride, conv.padding, conv.dilation)
+        else:
+            w64 = q.weight._data.cpu().double() if wq == "qint8" else q.weight._data.cpu().float().double()
+            prod = torch.nn.functional.conv2d(x.double(), w64, None, conv.stride, conv.padding, conv.dilation) * q.weight._scale.cpu().double().reshape(1, -1, 1, 1)
+    assert torch.equal(y, y1), f"pair gather differs from the one-pixel gather: {(y != y1).sum().item()} of {y.numel()} elements"
+    bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
+    assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), dt, f"pair gather {wq} {cin}->{cout} k{k}")
+
+
+@pytest.mark.gpu
 def test_qconv2d_grouped_convolution_keeps_reference_behaviour_gpu():
     """groups != 1 is not lowered to a GEMM: dequantize + float convolution on the device, as the reference does."""
     torch.manual_seed(9)
