@@ -131,19 +131,18 @@ static bool mmv_wins(int64_t M, const PackedGeom& g) {
 }
 
 // Large-tile int4 GEMM (qbits_mfma_large.hip: reference-rounded operands built in registers, no workspace, 2 x less traffic) against
-// dequantize + dense GEMM, r4, us (bf16, group size 128; profiles/r04_large4_vs_dequant_dense.jsonl): 4096^3 138.9 / 116.8,
-// (4096,8192,8192) 503 / 471, (8192,4096,14336) 846 / 774, (8192,14336,4096) 804 / 799, (2048,8192,8192) 246 / 252, but 8192^3 932 / 1339,
-// (16384,8192,8192) 1872 / 2702, (4096,8192,28672) 1643 / 2167, (4096,28672,8192) 1607 / 1914.  Its conversion costs ~2.9 VALU per MFMA where
-// the dense path pays one dequantize pass; it wins once the dense weight (N*K*2 bytes, written and re-read) together with the activations no
-// longer sits in the 256 MiB Infinity Cache: N*K >= 8192^2 with M >= 8192, or N*K >= 3 x 8192^2 - and it is what AUTO takes at prefill sizes
-// when the caller has no workspace at all.
+// dequantize + dense GEMM.  r4 (64-byte-row dense kernel): 4096^3 138.9 / 116.8 us, but 8192^3 932 / 1339, (16384,8192,8192) 1872 / 2702,
+// (4096,8192,28672) 1643 / 2167 - it won once the dense weight fell out of the Infinity Cache.  r5: with the 128-byte-row dense kernel and its grouped
+// tile raster (qmm_native8.hip) dequantize + dense wins at EVERY size measured (profiles/r05_large4_vs_dequant_dense.jsonl, group sizes 128 / 96 / 32):
+// 4096^3 133.7 / 110.8, 8192^3 958.9 / 791.0, (16384,8192,8192) 1959 / 1677, (4096,28672,8192) 1697 / 1517, (4096,8192,28672) 1684 / 1524 -
+// its conversion (~2.9 VALU per MFMA) costs more than one dequantize pass.  It remains what AUTO takes at prefill sizes when the caller has
+// no workspace for the dense weight (N * K * 2 bytes), and a forced kernel (QUANTO_HIP_LARGE4=2: whenever supported).
 static bool large4_wins(int64_t M, const PackedGeom& g, bool have_workspace) {
   const int mode = env_int("QUANTO_HIP_LARGE4", 1);  // experiments: 0 never, 2 whenever supported
   if (mode == 0) return false;
   if (mode == 2) return M > 192;
-  if (!have_workspace) return M > 1024;  // otherwise: passes of the streaming kernel / the one-thread-per-output kernel
-  const int64_t nk = g.N * g.K;
-  return nk >= (64ll << 20) && (M >= 8192 || nk >= (192ll << 20)) && M >= 2048;
+  (void)g;
+  return !have_workspace && M > 1024;  // otherwise: passes of the streaming kernel / the one-thread-per-output kernel
 }
 
 static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {

@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
         if constexpr (PAIR) {
           const int va = tap_ok(0, tap[q]), vb = tap_ok(1, tap[q]);  // -1: valid
           // first pixel over the left border (va = 0, vb = -1): + 2 bytes; second pixel over the right border (va = -1, vb = 0): - 2 bytes
-          const uint32_t addr = (px_off + (uint32_t)off[q] + (uint32_t)(2 * (vb - va))) & (uint32_t)(va | vb);
+          const uint32_t addr = (px_off + (uint32_t)off[q] + (uint32_t)(2 * (va - vb))) & (uint32_t)(va | vb);
           constexpr uint32_t IDENT = 0x07060504u, UP16 = 0x05040c0cu, DOWN16 = 0x0c0c0706u, ZERO = 0x0c0c0c0cu;
           uint32_t sel = ((uint32_t)va & IDENT) | (~(uint32_t)va & UP16);     // first pixel invalid: its half becomes 0, the second pixel's element moves up
           sel = ((uint32_t)vb & sel) | (~(uint32_t)vb & DOWN16);             // second pixel invalid: the first pixel's element moves down

@@ -16,4 +16,4 @@ for PAIRV in 0 1; do
   TIME_CONV2D_DIRECT_ONLY=1 QUANTO_HIP_CONV_PAIR=$PAIRV timeout 300 python scripts/time_conv2d.py qint8 grid 2>&1 | grep "^{" | sed "s/^{/{\"pair\": $PAIRV, /" | tee -a $OUT/conv_pair_grid.jsonl
 done
 echo "== large4 vs dequant + dense"
-timeout 400 python scripts/time_group_sizes.py large 2>&1 | grep "^{" | tee $OUT/large4_group_sizes.jsonl
+timeout 200 python -m pytest tests/test_hip_parity.py -m gpu -q -p no:cacheprovider -k "auto_takes_the_large" 2>&1 | tail -3 | tee $OUT/large4_auto_tail.txt

@@ -832,18 +832,23 @@ def test_large_tile_int4_gemm_operands_are_the_dequantized_weight():
 
 
 def test_auto_takes_the_large_tile_int4_gemm_where_it_wins():
-    """8192^3: AUTO = the large-tile int4 GEMM (r4: 932 vs 1339 us).  It multiplies the same rounded weight as
-    dequantize + dense GEMM, so the two outputs may only differ by the fp32 accumulation order: compared element by element in bf16 ulps
-    (a float64 product of this size is left to the smaller shapes above); 24 sampled rows against the float64 oracle."""
+    """8192^3.  r5: with a workspace AUTO = dequantize + dense GEMM again (the 128-byte-row dense kernel: 791 vs 959 us); WITHOUT one (the C entry
+    called with a null workspace) AUTO = the large-tile int4 GEMM, which needs none.  Both multiply the same rounded weight, so their outputs may
+    only differ by the fp32 accumulation order: compared element by element in bf16 ulps (a float64 product of this size is left to the smaller
+    shapes above); 24 sampled rows against the float64 oracle."""
     M, N, K = 8192, 8192, 8192
     g = torch.Generator(device=DEV).manual_seed(5)
     x = torch.randn((M, K), generator=g, device=DEV).to(torch.bfloat16)
     p = make_qbits_problem(8, N, K, "bf16", seed=11)
     packed, scale, shift = torch.from_numpy(p["packed"]).to(DEV), to_torch(p["scale"], "bf16", DEV), to_torch(p["shift"], "bf16", DEV)
     lib = quanto_hip.lib
-    y = lib.qbits_mm(x, packed, scale, shift, None, 4, 128, N, K)
-    assert lib.last_kernel() == "mfma_large4"
-    y2 = lib.qbits_mm(x, packed, scale, shift, None, 4, 128, N, K, kernel="dequant_mfma")
+    y2 = lib.qbits_mm(x, packed, scale, shift, None, 4, 128, N, K)
+    assert lib.last_kernel() == "dequant_mfma"
+    y = torch.empty_like(y2)
+    st = lib._c.quanto_hip_qbits_mm(x.data_ptr(), packed.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0, y.data_ptr(), M, N, K, 4, 128, 2, 2, 0, 0, 0, None)
+    torch.cuda.synchronize()
+    assert st == 0 and lib.last_kernel() == "mfma_large4"
+    assert torch.equal(y, lib.qbits_mm(x, packed, scale, shift, None, 4, 128, N, K, kernel="mfma_large4"))
     ulps = O.ulp_distance(to_numpy(y), to_numpy(y2), "bf16")
     big = np.abs(to_numpy(y2)) > 1e-2 * np.abs(to_numpy(y2)).max()
     assert (ulps <= 1).mean() >= 0.995 and ulps[big].max() <= 2

@@ -87,11 +87,12 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert [lib.quanto_hip_qbits_mm_pick(8, n, k, 4, 96, 2) for n, k in ((4000, 1152), (4096, 96))] == [GEMV, GEMV]  # N not in 64-feature blocks; one group = per-channel
     assert [lib.quanto_hip_qbits_mm_pick(m, 4096, 4096, 2, 128, 2) for m in (4, 8, 25, 192, 193)] == [GEMV, SKINNY, SKINNY, SKINNY, DEQUANT]  # qint2 (r4)
     assert lib.quanto_hip_qbits_mm_pick(8, 4096, 4096, 2, 64, 2) == GEMV                                          # qint2, group size 64: GEMV passes
-    # r4: the large-tile int4 GEMM where the dense weight leaves the Infinity Cache; dequantize + dense below
     LARGE4 = 10
-    assert [lib.quanto_hip_qbits_mm_pick(m, 8192, 8192, 4, 128, 2) for m in (2048, 4096, 8192)] == [DEQUANT, DEQUANT, LARGE4]
-    assert lib.quanto_hip_qbits_mm_pick(4096, 28672, 8192, 4, 128, 2) == LARGE4 and lib.quanto_hip_qbits_mm_pick(8192, 14336, 4096, 4, 128, 2) == DEQUANT
-    assert lib.quanto_hip_qbits_mm_workspace_size(8192, 8192, 8192, 4, 128, 2, 0) == 0                               # ... and it needs no workspace
+    # r5: with a workspace dequantize + dense GEMM at every prefill size (the 128-byte-row dense kernel); the large-tile int4 GEMM only without one
+    assert [lib.quanto_hip_qbits_mm_pick(m, 8192, 8192, 4, 128, 2) for m in (2048, 4096, 8192)] == [DEQUANT, DEQUANT, DEQUANT]
+    assert lib.quanto_hip_qbits_mm_pick(4096, 28672, 8192, 4, 128, 2) == DEQUANT and lib.quanto_hip_qbits_mm_pick(8192, 14336, 4096, 4, 128, 2) == DEQUANT
+    assert lib.quanto_hip_qbits_mm_workspace_size(8192, 8192, 8192, 4, 128, 2, 0) == 8192 * 8192 * 2                   # the dense weight
+    assert lib.quanto_hip_qbits_mm_workspace_size(8192, 8192, 8192, 4, 128, 2, LARGE4) == 0                          # forced: it needs no workspace
     # int8, M = 96 off the fitted grid (r4): the tile kernel from 40 tiles on while K is short
     assert [lib.quanto_hip_qbytes_mm_pick(96, n, k, 2, 3, 2) for n, k in ((5120, 5120), (2048, 2048), (5120, 11008), (8192, 8192))] == [4, 5, 5, 4]
     assert lib.quanto_hip_qbits_mm_pick(64, 192, 14336, 4, 32, 2) == DEQUANT  # 448 groups' tables do not fit next to the ring

@@ -3,6 +3,7 @@ by the real QConv2d: quantize -> freeze -> forward), and on the GPU the im2col +
 (tensor/weights.py conv2d_as_gemm) against exact math on the reference's integers and against the reference's outputs with
 the tolerance the reference's own test uses (tests/nn/test_qconv2d.py: assert_similar, atol 1e-2 class)."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -19,6 +20,8 @@ from helpers import TORCH_DT, assert_close_to_exact, assert_close_with_bias, ass
 QTYPES = {"int8": "qint8", "int4": "qint4", "e4m3fn": "qfloat8_e4m3fn"}
 CONVS = {"c16k3": (16, 32, 3, 1, 1), "c32k3s2": (32, 24, 3, 2, 0), "c64k1": (64, 48, 1, 1, 0)}
 CASES = [(t, c, d) for t in QTYPES for c in CONVS for d in ("fp32", "bf16")]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _build(golden, tag, cname, dt, device="cpu"):
@@ -339,6 +342,19 @@ def test_qconv2d_implicit_gemm_k_split_gpu(monkeypatch, wq, split):
         torch.cuda.synchronize()
         assert st == 0
         assert_close_with_bias(to_numpy(yy), prod.numpy(), np.broadcast_to(bias, prod.shape), "bf16", "conv without a workspace")
+
+
+@pytest.mark.parametrize("geom", [(2, 2, 6, 8, 3, 3, 1, 1, 1, 1, 1), (1, 3, 5, 10, 3, 3, 2, 0, 2, 1, 1), (2, 1, 8, 14, 3, 5, 1, 1, 2, 1, 2),
+                                  (3, 2, 5, 2, 3, 3, 1, 1, 1, 1, 1), (1, 1, 10, 12, 7, 7, 1, 3, 3, 1, 1), (1, 1, 4, 4, 3, 3, 1, 2, 3, 2, 1)])
+def test_conv_pair_gather_address_model(geom):
+    """CPU model of the kernel's two-pixels-per-load gather (scripts/models/conv_pair_gather_model.py): every load inside the tensor, every
+    extracted element the im2col value (0 over the padding) - borders on both sides, paddings wider than one element, W = 2, dilation."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("conv_pair_gather_model", os.path.join(ROOT, "scripts", "models", "conv_pair_gather_model.py"))
+    model = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(model)
+    assert model.check(*geom) > 0
 
 
 @pytest.mark.gpu
