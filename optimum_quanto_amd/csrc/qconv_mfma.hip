@@ -30,6 +30,11 @@
 
 #include "qh_common.h"
 
+#ifndef QH_CONV_ABLATE
+#define QH_CONV_ABLATE 0  // timing experiments only (scripts/probes/conv_ablate.hip; WRONG results): 1 no gather loads, 2 no MFMAs / fragment reads, 4 no weight
+#endif                      // loads, 8 no gather address arithmetic either, 16 no staging writes, 32 no tap-table fill
+
+
 namespace qh {
 namespace conv {
 
@@ -167,7 +172,9 @@ struct Args {
   // ([S][tiles][8 waves][8 fragments][64 lanes] float4: whole lines per store); qconv2d_reduce_kernel adds them in split order and runs the epilogue
   int S;
   float* partials;
+  uint32_t khw_magic, kw_magic;  // ceil(2^32 / (KH KW)), ceil(2^32 / KW); 0 when the divisor is 1 (fill_ktab)
 };
+static uint32_t div_magic(int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
 
 // the lane's 4 x 2 accumulator fragments -> output: D row = pixel (lane >> 4) * 4 + r of fragment i, D column = channel lane & 15 of fragment j; NCHW:
 // the lane's four rows are four neighbouring pixels of one channel plane
@@ -284,10 +291,20 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
       return __builtin_amdgcn_sbfe((uint32_t)w0, tp, 1);
   };
   int2* ktab = reinterpret_cast<int2*>(smem + 2 * 2 * TILE_BYTES);  // [2][64] {byte offset relative to px_off (signed), tap number}
+  // k -> (channel, tap row, tap column): two divisions by small run-time constants per table entry, done by ONE wave per K-tile while the other
+  // seven wait for it at the barrier.  As integer divisions they were ~60 of that wave's instructions per tile; here q = mulhi(n, ceil(2^32 / d)),
+  // exact for n < 2^24 and d <= 127 (n (M d - 2^32) < 2^24 * 127 < 2^32); the magic numbers come from the host (0: d = 1)
+  auto div_small = [](int n, int d, uint32_t magic, int& rem) {
+    const int q = magic ? (int)__umulhi((uint32_t)n, magic) : n;
+    rem = n - q * d;
+    return q;
+  };
   auto fill_ktab = [&](int t) {
-    if (tid < BK) {
-      const int khw = a.KH * a.KW, k = (kt_lo + t) * BK + tid;
-      const int ci = k / khw, rem = k - ci * khw, ki = rem / a.KW, kj = rem - ki * a.KW;
+    if (tid < BK && !((QH_CONV_ABLATE & 32) && t > 1)) {
+      const int k = (kt_lo + t) * BK + tid;
+      int rem, kj;
+      const int ci = div_small(k, a.KH * a.KW, a.khw_magic, rem);
+      const int ki = div_small(rem, a.KW, a.kw_magic, kj);
       ktab[(t & 1) * BK + tid] = k < K ? make_int2(2 * ((ci * a.H + ki * a.dh) * a.W + kj * a.dw - (a.ph * a.W + a.pw)), rem) : make_int2(0, NO_TAP);
     }
   };
@@ -302,7 +319,7 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
   auto issue_loads = [&](int t) {
     const int k0 = (kt_lo + t) * BK;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
+    for (int j = 0; j < ((QH_CONV_ABLATE & 8) ? 0 : NCH); ++j) {
       const int kc = PAIR ? wave : __builtin_amdgcn_readfirstlane(tid >> 7) + 4 * j;
       const int4* tp = reinterpret_cast<const int4*>(ktab + (t & 1) * BK + kc * 8);
       const int4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
@@ -318,7 +335,7 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
           sel = ((uint32_t)vb & sel) | (~(uint32_t)vb & DOWN16);             // second pixel invalid: the first pixel's element moves down
           sel = ((uint32_t)(va | vb) & sel) | (~(uint32_t)(va | vb) & ZERO);   // neither
           g_sel[q] = sel;
-          g_pair[q] = reinterpret_cast<const U1u*>(xb + addr)->x;
+          g_pair[q] = (QH_CONV_ABLATE & 1) ? addr : reinterpret_cast<const U1u*>(xb + addr)->x;
         } else {
           // -1: over the padding -> offset 0xFFFFFFFF -> out of range -> 0
           g_raw[j][q] = (short)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, (px_off + (uint32_t)off[q]) | ~(uint32_t)tap_ok(0, tap[q]), 0, 0);
@@ -358,7 +375,9 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
       n = n < N ? n : N - 1;
       const int kb = k0 + (tid & 3) * 16;
       const uint8_t* src = a.w + (size_t)n * K + kb;
-      if (kb + 16 <= K) {
+      if (QH_CONV_ABLATE & 4) {
+        rw = make_uint4(kb, kb, kb, kb);
+      } else if (kb + 16 <= K) {
         const U4u u = *reinterpret_cast<const U4u*>(src);
         rw = make_uint4(u.x, u.y, u.z, u.w);
       } else {  // ragged end of the last K-tile: zero bytes (fp8 0.0, int8 0) behind K, nothing is read beyond the row
@@ -370,6 +389,15 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
     }
   };
   auto write_lds = [&](int buf) {
+    if (QH_CONV_ABLATE & 16) {  // keep the loaded registers alive
+      if constexpr (PAIR) {
+        uint32_t t = rw.x ^ rw.y ^ rw.z ^ rw.w;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t ^= g_pair[q] ^ g_sel[q];
+        if (t == 0x12345678u) smem[tid] = 1;
+      }
+      return;
+    }
     uint8_t* sa = smem + buf * 2 * TILE_BYTES;
     uint8_t* sb = sa + TILE_BYTES;
     if constexpr (PAIR) {
@@ -433,7 +461,7 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
     const uint8_t* sa = smem + cur * 2 * TILE_BYTES;
     const uint8_t* sb = sa + TILE_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < ((QH_CONV_ABLATE & 2) ? 0 : 2); ++kk) {
       V8 fa[4], fb[2];
       const int kc = kk * 4 + (lane >> 4);
 #pragma unroll
@@ -541,7 +569,7 @@ static int launch(Args a, void* workspace, size_t workspace_bytes, hipStream_t s
 static bool geometry_ok(int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW) {
   const int64_t K = cin * KH * KW;
   // one validity bit per tap (two mask words, one bit kept free); byte offsets into x and element offsets into y / w in 31 bits; grid.y
-  return B >= 1 && OH >= 1 && OW >= 1 && K >= 1 && KH * KW <= 127 && B * cin * H * W < (1ll << 30) && B * OC * OH * OW < (1ll << 31) &&
+  return B >= 1 && OH >= 1 && OW >= 1 && K >= 1 && K < (1ll << 24) && KH * KW <= 127 && B * cin * H * W < (1ll << 30) && B * OC * OH * OW < (1ll << 31) &&
          OC * K < (1ll << 31) && (B * OH * OW + BM - 1) / BM <= 65535;  // (the K split is at most 64: grid.z)
 }
 
@@ -561,7 +589,7 @@ int qbytes_conv2d_mfma(const void* x, const void* w, const void* s, const void* 
                        int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbytes_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
   const conv::Args a{x, reinterpret_cast<const uint8_t*>(w), s, nullptr, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), 0, 0,
-                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr};
+                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr, conv::div_magic((int)(KH * KW)), conv::div_magic((int)KW)};
   using namespace conv;
 #define QH_CASE(DT, FMT) return launch<DT, FMT, false>(a, workspace, workspace_bytes, stream)
   if (out_dtype == QUANTO_HIP_BF16) {
@@ -589,7 +617,7 @@ int qbits_conv2d_mfma(const void* x, const uint8_t* packed, const void* scale, c
                       const PackedGeom& g, int dtype, bool int_shift, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbits_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, g, dtype)) return QUANTO_HIP_ENOTSUP;
   const conv::Args a{x, packed, scale, shift, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), (int)g.C, (int)g.G,
-                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr};
+                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr, conv::div_magic((int)(KH * KW)), conv::div_magic((int)KW)};
   using namespace conv;
 #define QH_CASE(DT, FMT) return int_shift ? launch<DT, FMT, true>(a, workspace, workspace_bytes, stream) : launch<DT, FMT, false>(a, workspace, workspace_bytes, stream)
   if (g.bits == 4) {

@@ -300,7 +300,7 @@ class _Bindings:
         OH = cls.conv2d_out_size(H, KH, stride[0], padding[0], dilation[0])
         OW = cls.conv2d_out_size(W, KW, stride[1], padding[1], dilation[1])
         K = C * KH * KW
-        return (B >= 1 and OH >= 1 and OW >= 1 and K >= 1 and KH * KW <= 127 and B * C * H * W < (1 << 30) and B * OC * OH * OW < (1 << 31)
+        return (B >= 1 and OH >= 1 and OW >= 1 and K >= 1 and K < (1 << 24) and KH * KW <= 127 and B * C * H * W < (1 << 30) and B * OC * OH * OW < (1 << 31)
                 and OC * K < (1 << 31) and (B * OH * OW + 127) // 128 <= 65535)
 
     def qbytes_conv2d_supported(self, x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)) -> bool:
