@@ -177,13 +177,32 @@ struct Args {
 static uint32_t div_magic(int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
 
 // the lane's 4 x 2 accumulator fragments -> output: D row = pixel (lane >> 4) * 4 + r of fragment i, D column = channel lane & 15 of fragment j; NCHW:
-// the lane's four rows are four neighbouring pixels of one channel plane
+// the lane's four rows are four neighbouring pixels of one channel plane - ONE 8-byte store when they lie in one image and the plane size is a
+// multiple of 4 (r5; before: four 2-byte stores, each with its own integer division by the plane size - the epilogue and the prologue were a
+// third of a (8,128,56,56) -> 128 call, profiles/r05_qconv2d_ablations.jsonl).  m < 2^24 (geometry_ok): m / L through the fp32 reciprocal, corrected.
 template <int DT, int PL>
 __device__ __forceinline__ void store_tile(const Args& a, const f32x4 (&acc)[4][2], int m0, int nt, int wm, int wn, int lane) {
   using E = Elem<DT>;
   using T = typename E::T;
   T* yg = reinterpret_cast<T*>(a.y);
   const int M = a.M, N = a.N, P = N / (PL > 1 ? PL : 2), L = a.OH * a.OW;
+  const float r_l = 1.0f / (float)L;
+  const bool vec = (L & 3) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 7) == 0;
+  int bq[4], lq[4];  // image and offset inside the plane of the first of the lane's four pixels of fragment i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
+    int b = (int)((float)m * r_l), l = m - b * L;
+    if (l < 0) {
+      --b;
+      l += L;
+    } else if (l >= L) {
+      ++b;
+      l -= L;
+    }
+    bq[i] = b;
+    lq[i] = l;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int tc = wn * 32 + j * 16 + (lane & 15);
@@ -203,16 +222,30 @@ __device__ __forceinline__ void store_tile(const Args& a, const f32x4 (&acc)[4][
     const float bv = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
+      if (m >= M) continue;
+      T out[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        if (m < M) {
-          float v = acc[i][j][r] * sc;
-          asm volatile("" : "+v"(v));  // product rounded to fp32 first, with and without bias (no single-rounding v_fma_mixlo_f16)
-          if (has_bias) v = E::to_f32(E::from_f32(v)) + bv;  // the reference's order: rounded convolution output + bias, rounded again
-          const int b = m / L;
-          yg[((size_t)b * N + n) * L + (m - b * L)] = E::from_f32(v);
-        }
+        float v = acc[i][j][r] * sc;
+        asm volatile("" : "+v"(v));  // product rounded to fp32 first, with and without bias (no single-rounding v_fma_mixlo_f16)
+        if (has_bias) v = E::to_f32(E::from_f32(v)) + bv;  // the reference's order: rounded convolution output + bias, rounded again
+        out[r] = E::from_f32(v);
+      }
+      T* dst = yg + ((size_t)bq[i] * N + n) * L + lq[i];
+      if (vec && m + 3 < M) {  // (L % 4 == 0 and m % 4 == 0: the four pixels are in one image, 8-byte aligned)
+        *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(out);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (m + r < M) {
+            int bb = bq[i], ll = lq[i] + r;
+            while (ll >= L) {  // an image ends inside the lane's four pixels (planes of fewer than 4 pixels: more than once)
+              ll -= L;
+              ++bb;
+            }
+            yg[((size_t)bb * N + n) * L + ll] = out[r];
+          }
       }
     }
   }

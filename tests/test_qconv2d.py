@@ -367,7 +367,8 @@ def test_conv_pair_gather_address_model(geom):
                                                  (128, 72, 1, 1, 0, 1, (6, 6)),             # pointwise: no border at all
                                                  (8, 40, 7, 1, 3, 1, (10, 12)),             # 49 taps: two 64-bit validity words per pixel
                                                  (3, 32, 3, 1, 1, 1, (20, 16)),             # K = 27: a ragged K-tile
-                                                 (64, 64, (1, 2), 1, 0, 1, (4, 9))])        # OW = 8 from W = 9 (even window along the width)
+                                                 (64, 64, (1, 2), 1, 0, 1, (4, 9)),         # OW = 8 from W = 9 (even window along the width)
+                                                 (64, 32, 3, 1, 1, 1, (1, 2))])             # planes of TWO pixels: a lane's four output pixels span two images
 def test_qconv2d_pair_gather_gpu(monkeypatch, dt, wq, cin, cout, k, s, p, d, hw):
     """r5: two neighbouring output pixels per 4-byte load (stride 1 along the width, even OW).  Same staged operand as the one-pixel gather, so
     the two kernels' outputs must be IDENTICAL bit for bit (the one-pixel form is forced through QUANTO_HIP_CONV_PAIR=0), and each passes the
