@@ -556,7 +556,8 @@ __global__ void __launch_bounds__(64) qconv2d_reduce_kernel(const Args a) {
 }
 
 // K split: the tile kernel is bound by its gather per K-tile (~1.9 us per workgroup and K-tile whatever M is), so what matters is how many
-// workgroups run at once: split until the grid reaches ~2 workgroups per CU, keeping at least 3 K-tiles per split.  1 = no split (and no workspace).
+// workgroups run at once: split until the grid reaches ~2 workgroups per CU, keeping at least 4 K-tiles per split (r5, after the gather and the
+// epilogue got cheaper: profiles/r05_qconv2d_split_sweep.jsonl - 3 per split over-split 26-49-tile grids by 10-14 %).  1 = no split (and no workspace).
 static int pick_split(int64_t M, int64_t N, int64_t K) {
   const int forced = env_int("QUANTO_HIP_CONV_SPLIT", 0);  // experiments
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nk = (K + BK - 1) / BK;
@@ -566,7 +567,7 @@ static int pick_split(int64_t M, int64_t N, int64_t K) {
   // 256 tiles x 49: 86.8 -> 84.3)
   if (tiles > 128) return tiles <= 256 && nk >= 32 ? 2 : 1;
   int s = 1;
-  while (tiles * (s + 1) <= 512 && nk / (s + 1) >= 3 && s < 64) ++s;
+  while (tiles * (s + 1) <= 512 && nk / (s + 1) >= 4 && s < 64) ++s;
   return s;
 }
 static size_t split_workspace(int64_t M, int64_t N, int S) { return S <= 1 ? 0 : (size_t)S * ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (BM * BN * 4); }
