@@ -614,7 +614,10 @@ int qbytes_mm_mfma_large(const void* x, const void* w, const void* s, const void
   // but (1280,8192) 82 -> 99, (2048,8192) 107 -> 125
   const int forced = env_int("QUANTO_HIP_LARGE_CFG", -1);  // experiments
   const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
-  const int cfg = forced >= 0 ? forced : (tiles128 > 512 ? lt::CFG_256_8W : lt::CFG_128_4W);
+  // e4m3fnuz on 256-tiles: the 1 x 8 layout - the patched-pattern converter (qh_common.h) spills in the 2 x 4 layout (104-116 B of scratch per
+  // lane; 0 in 1 x 8, which measures within 2 % of 2 x 4 on the other formats: profiles/r05_cfg2_wave_layouts_ab.jsonl)
+  const int cfg256 = b_dtype == QUANTO_HIP_F8_E4M3FNUZ ? lt::CFG_256_1X8 : lt::CFG_256_8W;
+  const int cfg = forced >= 0 ? forced : (tiles128 > 512 ? cfg256 : lt::CFG_128_4W);
   if (cfg != lt::CFG_128_4W) split = 1;  // the workspace is sized for 128-tiles
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
   lt::Args a{x, reinterpret_cast<const uint8_t*>(w), s, bias, y, (int)M, (int)N, (int)K, 1, split, reinterpret_cast<int*>(workspace),

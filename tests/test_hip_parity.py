@@ -510,7 +510,8 @@ def test_qbytes_naive_any_shape(dt, kind, M, N, K):
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K,kernel", [(1, 256, 1024, "gemv"), (2, 512, 4096, "gemv"), (8, 256, 1024, "skinny"), (40, 512, 2048, "skinny"),
-                                          (64, 1024, 4096, "skinny"), (300, 512, 1024, "mfma_large"), (1024, 1024, 4096, "mfma_large")])
+                                          (64, 1024, 4096, "skinny"), (300, 512, 1024, "mfma_large"), (1024, 1024, 4096, "mfma_large"),
+                                          (2176, 4096, 256, "mfma_large")])  # 544 tiles of 128: the 256-tile form (r5: its 1 x 8 wave layout, no scratch)
 def test_qbytes_e4m3fnuz_on_the_fast_kernels(dt, M, N, K, kernel):
     """float8_e4m3fnuz weights (the reference's tests/library/test_mm.py:32; an MI300-era checkpoint) no longer fall to the
     one-thread-per-output kernel: the OCP converter at scale 1/2 + the three byte patterns the two formats disagree on (0x7F / 0xFF =
