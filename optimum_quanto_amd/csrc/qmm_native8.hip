@@ -448,13 +448,7 @@ __device__ __forceinline__ int swz128(int row) { return (row >> 1) & 7; }
 // Tried and dropped (r5, profiles/r05_native8_row128.md): the eight DMA pieces of a pair behind the first four token fragments of the odd
 // step instead of one behind each of the eight (w8a8 4096^3 53.0 -> 54.6 us: two back-to-back DMA issues stall the MFMA stream for longer than
 // the earlier landing saves), and no lgkmcnt(0) in front of the barrier (52.9 vs 53.0: the wait is free, so the rigorous form stays).
-// RING (int8 / 16-bit loop, r5): the LDS is a ring of FIVE operand parts (the 128-byte-row image of 256 rows of ONE operand, 32 KiB; 16 KiB for the
-// 128-tile) instead of two buffers of two: parts go round in stream order A0 W0 A1 W1 A2 ..., part t lives in slot t % 5.  The barrier in the middle
-// of pair p retires A(p) and W(p); their slots take W(p+2) and A(p+3).  So half of every pair's bytes (the activation part) is in flight for TWO
-// barrier periods instead of one and the vector L1 never runs dry behind a barrier: the K loop of this kernel is bound by the L1 fill rate (64 misses
-// in flight x 128 B / latency; K scaling against the vendor's kernels in profiles/r05_native8_k_scaling_vs_vendor.jsonl), and with two buffers every
-// byte of a pair had to be requested AND delivered between two consecutive barriers.  Slots are run-time values (six address adds per pair).
-template <int ODT, int KIND, bool SMALL = false, bool RING = false>
+template <int ODT, int KIND, bool SMALL = false>
 __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kernel(const Args a) {
   using AV = typename Acc<KIND>::V;
   constexpr bool MX = KIND == K_F8E4M3 || KIND == K_F8E5M2;
@@ -531,14 +525,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
   if (np > 1) {
 #pragma unroll
     for (int q = 0; q < 2 * PPW; ++q) issue_piece(1, mdst[1], q);
-    if (RING && !MX && np > 2) {  // the ring's fifth slot: the activation part of pair 2 is in flight from the start
-#pragma unroll
-      for (int q = 0; q < PPW; ++q)
-        glds16(a.a + (size_t)2 * RB, asrc[q], __builtin_amdgcn_readfirstlane(lds_base + 4u * OP_BYTES + (uint32_t)((q * NWAVES + wave) * 1024)));
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -599,91 +586,6 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
         }
       }
     }
-  } else if constexpr (RING) {
-    // ---- int8 / 16-bit on the five-part ring (see the kernel's header comment) ----
-    uint4 xf[8], wq[2][NJ];
-    auto rd = [&](const uint8_t* p) -> uint4 { return *reinterpret_cast<const uint4*>(p); };
-    auto mma = [&](AV& c, const uint4& w, const uint4& x) {
-      if constexpr (KIND == K_I8) {
-        c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, w), __builtin_bit_cast(i32x4, x), c, 0, 0, 0);
-      } else if constexpr (KIND == K_BF16) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
-      } else {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), c, 0, 0, 0);
-      }
-    };
-    // (the prologue above put pair 0 into slots 0 / 2 and pair 1 into slots 1 / 3 of the TWO-buffer image [A0 | A1 | W0 | W1]: as ring slots that is
-    // A0 -> 0, A1 -> 1, W0 -> 2, W1 -> 3; the ring keeps that assignment for the first two pairs and goes round from there: the slot of a part is
-    // looked up in a five-entry cycle)
-    const int boff0 = boff - W_BASE;  // the lane's fragment offset inside a weight part
-    // slot cycle.  Parts in stream order A0 W0 A1 W1 A2 W2 A3 ...; A0, W0, A1, W1 sit in slots 0, 2, 1, 3 (prologue), A2 goes to the free slot 4;
-    // from then on a part takes the slot the barrier of two pairs earlier retired: W(p+2) <- slot of A(p), A(p+3) <- slot of W(p).
-    int sa = 0, sw = 2, sa1 = 1, sw1 = 3, sa2 = 4;  // slots of A(p), W(p), A(p+1), W(p+1), A(p+2)
-    auto part_dst = [&](int slot, int q) -> uint32_t {  // DMA destination of piece q of the part in `slot` (wave-uniform)
-      return __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)slot * OP_BYTES + (uint32_t)((q * NWAVES + wave) * 1024));
-    };
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) wq[0][j] = rd(smem + 2 * OP_BYTES + boff0 + j * FR);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) xf[i] = rd(smem + aoff + i * FR);
-
-    // pair p: [even step: k-step 2p, prefetching k-step 2p+1 from the same parts] -> A(p+1), W(p+1) landed (only A(p+2) may still be in flight),
-    // own reads returned -> barrier -> [odd step: k-step 2p+1, prefetching k-step 2p+2 from A(p+1) / W(p+1); W(p+2) into A(p)'s slot and A(p+3) into
-    // W(p)'s slot, one DMA piece behind each token fragment's MFMAs]
-    auto pair = [&](int p, auto steady) {
-      constexpr bool ST = decltype(steady)::value;
-      const bool has_next = ST || p + 1 < np, has_w2 = ST || p + 2 < np, has_a3 = ST || p + 3 < np;
-      const uint8_t* xa1 = smem + sa * OP_BYTES + (aoff ^ 64);
-      const uint8_t* wa1 = smem + sw * OP_BYTES + (boff0 ^ 64);
-      const uint8_t* xn0 = smem + sa1 * OP_BYTES + aoff;
-      const uint8_t* wn0 = smem + sw1 * OP_BYTES + boff0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          mma(acc[j][i], wq[0][j], xf[i]);
-          if (j == 1 % NJ) {
-            if (i < NJ) wq[1][i] = rd(wa1 + i * FR);
-          }
-          if (j == NJ - 1) xf[i] = rd(xa1 + i * FR);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if (has_next) {
-        if (has_w2)  // A(p+2) was issued a pair ago (prologue for p = 0) and may stay in flight
-          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          mma(acc[j][i], wq[1][j], xf[i]);
-          if (j == 1 % NJ) {
-            if (i < NJ && has_next) wq[0][i] = rd(wn0 + i * FR);
-          }
-          if (j == 2 % NJ) {
-            if (i < PPW) {
-              if (has_w2) glds16(a.w + (size_t)(p + 2) * RB, wsrc[i], part_dst(sa, i));
-            } else {
-              if (has_a3) glds16(a.a + (size_t)(p + 3) * RB, asrc[i - PPW], part_dst(sw, i - PPW));
-            }
-          }
-          if (j == NJ - 1 && has_next) xf[i] = rd(xn0 + i * FR);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      // the ring moves on: pair p+1's parts become current; W(p+2) took A(p)'s slot, A(p+3) W(p)'s
-      const int nsa = sa1, nsw = sw1, nsa1 = sa2, nsw1 = sa, nsa2 = sw;
-      sa = nsa; sw = nsw; sa1 = nsa1; sw1 = nsw1; sa2 = nsa2;
-    };
-    int p = 0;
-    for (; p + 3 < np; ++p) pair(p, std::true_type{});
-    for (; p < np; ++p) pair(p, std::false_type{});
   } else {
     // ---- int8 / 16-bit: k-steps of 64 bytes; xf is refilled in place, the weight fragments ping-pong between two register sets ----
     uint4 xf[8], wq[2][NJ];
@@ -762,23 +664,14 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
   epilogue<ODT, KIND, NJ, BM, BN>(a, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
-template <int ODT, int KIND, bool SMALL, bool RING>
-static int launch_r128_k(const Args& a, hipStream_t stream) {
-  constexpr int T = SMALL ? 128 : 256;
-  // two buffers of 128-byte rows: 128 KiB (64 KiB for the 128-tile: two workgroups per CU); RING: five operand parts = 160 KiB (80 KiB); the epilogue parks in it
-  constexpr int need = (RING ? 5 : 4) * T * 128;
-  const int tiles = ((a.N + T - 1) / T) * ((a.M + T - 1) / T);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_r128_kernel<ODT, KIND, SMALL, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, need);
-  hipLaunchKernelGGL((qbytes_native8_r128_kernel<ODT, KIND, SMALL, RING>), dim3(tiles), dim3(SMALL ? 256 : 512), need, stream, a);
-  return launch_status();
-}
 template <int ODT, int KIND, bool SMALL>
 static int launch_r128(const Args& a, hipStream_t stream) {
-  constexpr bool MX = KIND == K_F8E4M3 || KIND == K_F8E5M2;
-  if constexpr (!MX) {
-    if (env_int("QUANTO_HIP_NATIVE8_RING", 1) != 0) return launch_r128_k<ODT, KIND, SMALL, true>(a, stream);
-  }
-  return launch_r128_k<ODT, KIND, SMALL, false>(a, stream);
+  constexpr int T = SMALL ? 128 : 256;
+  constexpr int need = 2 * 2 * T * 128;  // two buffers of 128-byte rows: 128 KiB (64 KiB for the 128-tile); the epilogue parks in it
+  const int tiles = ((a.N + T - 1) / T) * ((a.M + T - 1) / T);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_r128_kernel<ODT, KIND, SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, need);
+  hipLaunchKernelGGL((qbytes_native8_r128_kernel<ODT, KIND, SMALL>), dim3(tiles), dim3(SMALL ? 256 : 512), need, stream, a);
+  return launch_status();
 }
 
 static int raster_group() {

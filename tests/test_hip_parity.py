@@ -602,15 +602,13 @@ def test_qbytes_fp8_fp8_mfma(dt, kind, M, N, K):
     assert_close_to_exact(to_numpy(y), want, dt, "fp8 x fp8 native")
 
 
-@pytest.mark.parametrize("ring", ["1", "0"])
 @pytest.mark.parametrize("small", ["0", "1"])
-@pytest.mark.parametrize("K", [128, 256, 384, 512, 640, 768, 1152])
+@pytest.mark.parametrize("K", [128, 256, 384, 512, 640, 1152])
 @pytest.mark.parametrize("M,N", [(256, 256), (300, 700), (1, 17), (520, 257)])
-def test_native8_128_byte_rows_bit_exact(monkeypatch, ring, small, K, M, N):
-    """qmm_native8.hip's 128-byte-row kernel - the ring of five operand parts (r5 default) and the two-buffer form (QUANTO_HIP_NATIVE8_RING=0) -
-    against the exact integer reference and against the 64-byte-row kernel, on 1..9 K-tiles (every prologue / steady-state / tail combination,
-    one full turn of the ring and more), ragged and full tiles, 256- and 128-tiles."""
-    monkeypatch.setenv("QUANTO_HIP_NATIVE8_RING", ring)
+def test_native8_128_byte_rows_bit_exact(monkeypatch, small, K, M, N):
+    """qmm_native8.hip's 128-byte-row kernel (two LDS buffers, one barrier per 128 bytes of K) against the exact integer reference and
+    against the 64-byte-row kernel, on 1..9 K-tiles (every prologue / steady-state / tail combination of the unrolled pair loop),
+    ragged and full tiles, 256- and 128-tiles."""
     rng = np.random.default_rng(M * 7 + N * 3 + K)
     a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
     b = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
@@ -656,8 +654,6 @@ def test_dense_gemm_128_byte_rows(monkeypatch, dt, M, N, K):
     assert quanto_hip.lib.last_kernel() == "dequant_mfma"
     w = O.dequantize_qbits_ref(p["packed"], 4, p["scale"], p["shift"], 0, 64, (N, K), dt).astype(np.float64)
     assert_close_to_exact(y, np.matmul(p["x"].astype(np.float64), w.T), dt, "dense GEMM, 128-byte rows")
-    monkeypatch.setenv("QUANTO_HIP_NATIVE8_RING", "0")  # the two-buffer form of the 128-byte-row kernel: same bits
-    np.testing.assert_array_equal(_run_qbits(p, "dequant_mfma"), y)
     monkeypatch.setenv("QUANTO_HIP_NATIVE8_ROW128", "0")
     np.testing.assert_array_equal(_run_qbits(p, "dequant_mfma"), y)
 
