@@ -22,6 +22,13 @@
 namespace qh {
 namespace n8 {
 
+#ifdef QH_N8_STAMPS  // scripts/probes/native8_timing.hip: s_memrealtime (100 MHz) per workgroup at entry / loop start / loop end / stores issued / exit
+__device__ unsigned long long g_stamps[4096 * 8];
+#define QH_N8_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define QH_N8_STAMP(i) do { } while (0)
+#endif
+
 constexpr int BK = 64;  // bytes per row and K-tile, both operands
 constexpr int STAGES = 4;
 
@@ -463,6 +470,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
   static_assert(PPW == 4, "piece bookkeeping below assumes four pieces per wave and operand");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
+  QH_N8_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = SMALL ? 0 : wave >> 2, wn = wave & 3;
@@ -532,6 +540,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
+  QH_N8_STAMP(1);
   if constexpr (MX) {
     // ---- fp8 x fp8: an operand is the lane's 16 bytes of the first half followed by its 16 bytes of the second half of the row ----
     typedef __attribute__((ext_vector_type(8))) int i32x8;
@@ -661,7 +670,13 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
     if (p + 2 < np) pair(p + 2, b0{}, false, false);
   }
 
+  QH_N8_STAMP(2);
   epilogue<ODT, KIND, NJ, BM, BN>(a, acc, smem, m0, n0, wm, wn, wave, lane);
+#ifdef QH_N8_STAMPS
+  QH_N8_STAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  QH_N8_STAMP(4);
+#endif
 }
 
 template <int ODT, int KIND, bool SMALL>
