@@ -15,17 +15,18 @@
 //     across a wave and the 64 lanes of a load are 64 neighbouring pixels (one or two cache lines);
 //   * what depends on k only - byte offset of tap (c, i, j) relative to the window's top-left tap, and the tap's number i*KW + j - is computed
 //     once per K-tile by 64 threads into an LDS table (two buffers, rides on the K loop's barrier) and read back by broadcast ds_reads;
-//   * what depends on the pixel only - its base offset and ONE bit per tap (set: the tap hangs over the padding; a 32-bit word for windows of up
-//     to 31 taps, two 64-bit words up to 127) - lives in two registers.  The loads are BUFFER loads over x with its true size as the range (r5): an
-//     element costs add + v_bfe_i32 + or (+ its two-byte load) - the sign-extended bit turns the offset of a padding tap into 0xFFFFFFFF, the
-//     range check returns 0 for it, and nothing is masked afterwards (r4: global loads of element 0 for those taps, a keep mask accumulated
-//     per element and an and + sbfe per element at staging: ~9 VALU per element);
-//   * the 16 loads of a K-tile are issued back to back before the MFMAs of the current tile and packed in pairs (v_lshl_or) after them;
-//   * DEPTH = 2 (r5): two staging register sets, the loads of tile t + 2 are issued while tile t multiplies, so a load has a whole iteration
-//     to land instead of the ~0.1 us of MFMAs of one tile (the r4 kernel spent ~2.3 us per K-tile with one workgroup per CU: one exposed
-//     load latency per tile).  Twice the staging registers: one workgroup per CU - taken when the grid cannot give a CU two anyway.
-// History (profiles/r04_qconv2d_*.jsonl): first form - four pixels per thread, a counted (c, i, j) walk and four compares per element, four waves
-// (inside qmm_mfma.hip) - spent 3.7 us per K-tile whatever M was; the table on four waves 2.0 us; this file's eight waves: see DESIGN.md 8.
+//   * what depends on the pixel only - its base offset and ONE validity bit per tap (set: the tap lies inside the image; a 32-bit word for windows
+//     of up to 31 taps, two 64-bit words up to 127) - lives in two registers.  The one-pixel gather uses BUFFER loads over x with its true size as
+//     the range (r5): an element costs add + v_bfe_i32 + or (+ its two-byte load) - the sign-extended bit turns the offset of a padding tap into
+//     0xFFFFFFFF, the range check returns 0 for it, and nothing is masked afterwards (r4: global loads of element 0 for those taps, a keep mask
+//     accumulated per element and an and + sbfe per element at staging: ~9 VALU per element); the pixel-PAIR gather is described at the kernel;
+//   * the loads of a K-tile are issued back to back before the MFMAs of the current tile and packed in pairs (one v_perm_b32 each) after them;
+//   * two K-tiles of gather in flight (a second staging register set, r5) were measured and dropped: no gain with one workgroup per CU, a loss
+//     with two (profiles/r05_qconv2d_depth2_negative.jsonl) - the kernel pays the instruction stream of its waves, not a load latency
+//     (compile-time ablations: QH_CONV_ABLATE below, profiles/r05_qconv2d_ablations*.jsonl).
+// History (profiles/r04_qconv2d_*.jsonl, r05_qconv2d_*.jsonl): first form - four pixels per thread, a counted (c, i, j) walk and four compares per
+// element, four waves (inside qmm_mfma.hip) - 3.7 us per K-tile whatever M was; the table on four waves 2.0; eight waves 1.85 (r4); buffer-load
+// gather, pixel pairs, magic-number table, 8-byte epilogue stores (r5): ~1.2 us per K-tile; DESIGN.md 4.8.
 #include <type_traits>
 
 #include "qh_common.h"
