@@ -34,7 +34,9 @@ Round 4 additions to the default line (all measured in the same process / on the
   * ``roofline.frac`` is computed from the SAME host-bracketed time as ``value`` (``ms_per_step``); the device-event time of the same
     replay is ``event_us`` (r3 divided by the event time: 0.5544 next to a value that said 0.548);
   * ``kernel_us`` / ``kernel_us_min``: kernel-only duration from a ``rocprofv3 --kernel-trace`` pass of this same file (a child
-    process, ``--trace-child``), next to the launch-inclusive ``us_per_step``; ``traffic`` = fabric bytes per step from two more child
+    process, ``--trace-child``; r5: one steady-state hipGraph replay), next to the launch-inclusive ``us_per_step``.  The profiler stamps a
+    dispatch from the start of its set-up, which an unprofiled replay overlaps with the tail of the previous kernel (~0.5 us): for kernels
+    of a few us the average can therefore exceed ``us_per_step`` (north-star 4.7 vs 4.2); ``kernel_us_min`` (3.2) does not; ``traffic`` = fabric bytes per step from two more child
     passes (``--pmc FETCH_SIZE`` / ``--pmc WRITE_SIZE``, corrected as MI355X_MICROARCH.md prescribes); when rocprofv3 is not usable the
     committed ``profiles/pmc_*.json`` figure is reported with ``traffic_stale: true``;
   * ``ref_rocm_us``: the op sequence the UNMODIFIED reference issues for the same call on a ROCm device (elementwise dequantize +
@@ -1080,7 +1082,7 @@ def main():
             for sr in sub_results:
                 apply_profile(sr, prof.get(sr["name"]), compacted=True)
             out["profile_passes"] = {"ok": bool(prof), "seconds": round(time.perf_counter() - t_prof, 1),
-                                     "what": "rocprofv3 child runs of this file: --kernel-trace of one steady-state hipGraph replay (kernel_us), --pmc FETCH_SIZE / WRITE_SIZE (traffic, FETCH x2: gfx950)"}
+                                     "what": "rocprofv3 child runs of this file: --kernel-trace of one steady-state hipGraph replay (kernel_us = begin-to-end per dispatch as the profiler stamps it, ~0.5 us of dispatch set-up included that an unprofiled replay overlaps with the previous kernel: on us-scale kernels it can exceed us_per_step, kernel_us_min does not), --pmc FETCH_SIZE / WRITE_SIZE (traffic, FETCH x2: gfx950)"}
         if world == 1 and rank == 0 and default_run and not args.no_cfg5 and out is not None:
             try:
                 rec = run_cfg5(args, device)
