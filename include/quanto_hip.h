@@ -67,7 +67,7 @@ typedef enum {
   QUANTO_HIP_KERNEL_MFMA_FUSED4 = 8,  /* qbits_mm, 64 < M <= ~1-1.5 k (AUTO: its own time model): packed int4 -> MFMA operands in registers,
                                        * per-group fp32 fold, no dequantized weight; workspace only when K is split (plan / workspace_size say so) */
   QUANTO_HIP_KERNEL_MMV = 9,          /* qbits_mm, 4 < M <= 16 (AUTO; the kernel itself accepts up to 32 rows): register-streaming MFMA kernel, K split over the waves of a block (no workspace) */
-  QUANTO_HIP_KERNEL_MFMA_LARGE4 = 10  /* qbits_mm (int4, group size a multiple of 64 or per-channel), prefill-sized M: packed int4 -> registers -> MFMA
+  QUANTO_HIP_KERNEL_MFMA_LARGE4 = 10  /* qbits_mm (int4, group size a multiple of 32 or per-channel), prefill-sized M: packed int4 -> registers -> MFMA
                                          operands with the reference's rounding sequence (the product multiplies exactly the reference's dequantized
                                          weight), 256 x 256 tiles, no workspace, no dense weight in memory */
 } quanto_hip_kernel;
@@ -280,8 +280,9 @@ int quanto_hip_pack(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int6
  * is gathered inside the kernel's staging loads, nothing is materialised.
  *   x: dtype[B, cin, H, W] (NCHW, contiguous); w: 8-bit [OC, cin, KH, KW] (I8 / F8_E4M3FN / F8_E5M2); scales: dtype[OC]; bias: dtype[OC] or NULL;
  *   y: dtype[B, OC, OH, OW] with OH = (H + 2 ph - dh (KH - 1) - 1) / sh + 1 (OW alike), passed by the caller.  dtype in {F16, BF16}.
- *   Requires cin * KH * KW to be a multiple of 64 and KH * KW <= 64; QUANTO_HIP_ENOTSUP otherwise (the caller then lowers the convolution to
- *   im2col + qbytes_mm or keeps the reference's dequantize + float convolution).  Kernel: csrc/qconv_mfma.hip.
+ *   Any K = cin * KH * KW below 2^24 (r5: the last K-tile may be ragged), windows of up to 127 taps, B cin H W < 2^30, B OC OH OW < 2^31,
+ *   OC K < 2^31; QUANTO_HIP_ENOTSUP otherwise (the caller then lowers the convolution to im2col + qbytes_mm or keeps the reference's dequantize +
+ *   float convolution).  Kernel: csrc/qconv_mfma.hip.
  *   workspace / workspace_bytes: optional scratch for the K split, see quanto_hip_conv2d_workspace_size below (NULL, 0: unsplit).
  */
 int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, const void* bias, void* y, int64_t B, int64_t cin, int64_t H,
@@ -298,7 +299,7 @@ int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, c
 int64_t quanto_hip_conv2d_workspace_size(int64_t B, int64_t OH, int64_t OW, int64_t OC, int64_t K);
 
 /*
- * F.conv2d with an int4 weight - what QConv2d.forward (nn/qconv2d.py:54-55) reaches through WeightQBitsTensor's dispatch (qfallback: dequantize
+ * F.conv2d with an int4 / int2 weight - what QConv2d.forward (nn/qconv2d.py:54-55) reaches through WeightQBitsTensor's dispatch (qfallback: dequantize
  * the whole weight, float convolution).  The same implicit GEMM as quanto_hip_qbytes_conv2d; the packed bytes are dequantized while they are
  * staged, with the reference's own roundings (tensor/qbits.py:27-49: T(T(scale q) - shift) for float shifts, T(scale (q - zero_point)) for
  * integer zero-points), so the matrix cores multiply by exactly the dense weight the reference would have materialised.  No dense weight and no
@@ -306,8 +307,8 @@ int64_t quanto_hip_conv2d_workspace_size(int64_t B, int64_t OH, int64_t OW, int6
  *   x: dtype[B, cin, H, W]; packed: the generic PackedTensor bytes of the axis-0 quantized weight [OC, cin, KH, KW] viewed as [OC, K = cin KH KW]
  *   (byte (p, k) = q[p, k] | q[p + OC/2, k] << 4); scale / shift: [OC * K / group_size] as for quanto_hip_qbits_mm (group_size 0 = per-channel);
  *   bias: dtype[OC] or NULL; y: dtype[B, OC, OH, OW].  dtype in {F16, BF16}; shift_dtype = dtype or U8 / I8.
- *   Requires bits = 4, OC even, K a multiple of 64, KH * KW <= 64 and group_size a multiple of 8; QUANTO_HIP_ENOTSUP otherwise (the caller then
- *   lowers the convolution to im2col + qbits_mm or keeps the reference's dequantize + float convolution).
+ *   bits = 4 (OC even) or 2 (OC a multiple of 4; r5), group_size a multiple of 8 or 0, the geometry limits of quanto_hip_qbytes_conv2d;
+ *   QUANTO_HIP_ENOTSUP otherwise (the caller then lowers the convolution to im2col + qbits_mm or keeps the reference's dequantize + float convolution).
  */
 int quanto_hip_qbits_conv2d(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t B, int64_t cin,
                             int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,

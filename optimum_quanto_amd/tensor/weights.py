@@ -79,8 +79,8 @@ def conv2d_patches(input, kernel_size, stride, padding, dilation):
 
 def _implicit_conv2d(input, weight, scale, bias, stride, padding, dilation, groups):
     """``quanto::qbytes_conv2d`` - the convolution as an implicit GEMM, im2col inside the kernel's staging loads (r4) - when the call is
-    eligible: dense (groups = 1), batched NCHW 16-bit input on a ROCm device, int8 / OCP fp8 weight, C*kh*kw a multiple of 64, windows of up
-    to 64 taps, no gradient wanted.  None otherwise: the caller then lowers to a materialised im2col + GEMM (conv2d_as_gemm) or keeps the reference behaviour."""
+    eligible: dense (groups = 1), batched NCHW 16-bit input on a ROCm device, int8 / OCP fp8 weight, windows of up to 127 taps (r5: any
+    C*kh*kw), no gradient wanted.  None otherwise: the caller then lowers to a materialised im2col + GEMM (conv2d_as_gemm) or keeps the reference behaviour."""
     from ..library.hip import quanto_hip
 
     if groups != 1 or isinstance(padding, str) or type(input) is not torch.Tensor or input.dim() != 4 or input.device.type != "cuda":
