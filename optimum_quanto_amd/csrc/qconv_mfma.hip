@@ -262,15 +262,8 @@ __device__ __forceinline__ void store_tile(const Args& a, const f32x4 (&acc)[4][
 // border (iw = -1 for the first pixel only): load one element further right and shift the dword up by 16; right border (iw = W for the second
 // pixel only): load one element further left and shift down; neither valid: element 0 and a zero selector.  The shifts are one v_perm_b32 with
 // a per-lane selector; the loads stay inside x whatever the tap (global loads at 2-byte alignment: unaligned access mode, r4 probe).
-// TAB (r5; PAIR, windows of up to 9 taps): what the pair gather computes per (pixel pair, tap) - the realigned base offset, the in-range mask and the
-// v_perm selector, ~8 VALU per load - depends on the tap but not on the channel, and a K-tile walks the same <= 9 taps seven times over.  The thread
-// computes its 10 entries ({px_off + realignment, mask, selector}; entry 9 = "no such k") once, parks them in LDS ([tap][thread], 16 bytes: 80 KiB, so one
-// workgroup per CU) and a load costs one ds_read_b128 + add + and.
-constexpr int TAB_TAPS = 10;
-constexpr int TAB_BYTES = TAB_TAPS * NT * 16;
-template <int DT, int FMT, bool INT_SHIFT, bool WIDE, bool PAIR, bool TAB = false>
-__global__ void __launch_bounds__(NT, TAB ? 1 : 2) qconv2d_mfma_kernel(const Args a) {
-  static_assert(!TAB || (PAIR && !WIDE), "the tap table serves the pair gather of small windows");
+template <int DT, int FMT, bool INT_SHIFT, bool WIDE, bool PAIR>
+__global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
   constexpr int PL = planes_of(FMT);      // > 1: a tile's 128 columns are 128 / PL packed rows x PL planes
   constexpr int RPT = BN / PL;            // packed rows per tile
   constexpr int NO_TAP = WIDE ? 127 : 31;
@@ -346,25 +339,10 @@ __global__ void __launch_bounds__(NT, TAB ? 1 : 2) qconv2d_mfma_kernel(const Arg
       int rem, kj;
       const int ci = div_small(k, a.KH * a.KW, a.khw_magic, rem);
       const int ki = div_small(rem, a.KW, a.kw_magic, kj);
-      // second field: the tap number (TAB: the byte offset of the tap's row of the table; "no such k" = row 9)
-      const int no_tap = TAB ? (TAB_TAPS - 1) * NT * 16 : NO_TAP, tapf = TAB ? rem * (NT * 16) : rem;
-      ktab[(t & 1) * BK + tid] = k < K ? make_int2(2 * ((ci * a.H + ki * a.dh) * a.W + kj * a.dw - (a.ph * a.W + a.pw)), tapf) : make_int2(0, no_tap);
+      ktab[(t & 1) * BK + tid] = k < K ? make_int2(2 * ((ci * a.H + ki * a.dh) * a.W + kj * a.dw - (a.ph * a.W + a.pw)), rem) : make_int2(0, NO_TAP);
     }
   };
 
-  // TAB: the thread's entry per tap, [tap][thread]
-  uint4* ptab = reinterpret_cast<uint4*>(smem + 2 * 2 * TILE_BYTES + 2 * BK * 8);
-  if constexpr (TAB) {
-    constexpr uint32_t IDENT = 0x07060504u, UP16 = 0x05040c0cu, DOWN16 = 0x0c0c0706u, ZERO = 0x0c0c0c0cu;
-    for (int t = 0; t < TAB_TAPS; ++t) {
-      const bool exists = t < a.KH * a.KW;
-      const int va = exists ? tap_ok(0, t) : 0, vb = exists ? tap_ok(1, t) : 0;
-      uint32_t sel = ((uint32_t)va & IDENT) | (~(uint32_t)va & UP16);
-      sel = ((uint32_t)vb & sel) | (~(uint32_t)vb & DOWN16);
-      sel = ((uint32_t)(va | vb) & sel) | (~(uint32_t)(va | vb) & ZERO);
-      ptab[t * NT + tid] = make_uint4(px_off + (uint32_t)(2 * (va - vb)), (uint32_t)(va | vb), sel, 0u);
-    }
-  }
   // ---- staging registers --------------------------------------------------------------------------------------------------------------------
   // gathered elements of the K-tile in flight (taps over the padding read 0).  16-bit variables on purpose: as uint32_t the zero-extension (a v_and
   // per element) sits next to the LOAD, hipcc schedules it early and waits for the newest loads right after issuing them
@@ -382,12 +360,7 @@ __global__ void __launch_bounds__(NT, TAB ? 1 : 2) qconv2d_mfma_kernel(const Arg
       const int off[8] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z}, tap[8] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w};
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        if constexpr (TAB) {
-          const uint4 e = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(ptab + tid) + tap[q]);
-          g_sel[q] = e.z;
-          const uint32_t addr = (e.x + (uint32_t)off[q]) & e.y;
-          g_pair[q] = (QH_CONV_ABLATE & 1) ? addr : reinterpret_cast<const U1u*>(xb + addr)->x;
-        } else if constexpr (PAIR) {
+        if constexpr (PAIR) {
           const int va = tap_ok(0, tap[q]), vb = tap_ok(1, tap[q]);  // -1: valid
           // first pixel over the left border (va = 0, vb = -1): + 2 bytes; second pixel over the right border (va = -1, vb = 0): - 2 bytes
           const uint32_t addr = (px_off + (uint32_t)off[q] + (uint32_t)(2 * (va - vb))) & (uint32_t)(va | vb);
@@ -600,11 +573,10 @@ static int pick_split(int64_t M, int64_t N, int64_t K) {
 }
 static size_t split_workspace(int64_t M, int64_t N, int S) { return S <= 1 ? 0 : (size_t)S * ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (BM * BN * 4); }
 
-template <int DT, int FMT, bool INT_SHIFT, bool WIDE, bool PAIR, bool TAB = false>
+template <int DT, int FMT, bool INT_SHIFT, bool WIDE, bool PAIR>
 static void launch_k(const Args& a, int ntiles, int mtiles, hipStream_t stream) {
-  constexpr int lds = LDS_BYTES + (TAB ? TAB_BYTES : 0);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE, PAIR, TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE, PAIR, TAB>), dim3(ntiles, mtiles, a.S), dim3(NT), lds, stream, a);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipLaunchKernelGGL((qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE, PAIR>), dim3(ntiles, mtiles, a.S), dim3(NT), LDS_BYTES, stream, a);
 }
 template <int DT, int FMT, bool INT_SHIFT, bool WIDE>
 static int launch_w(Args a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -616,16 +588,7 @@ static int launch_w(Args a, void* workspace, size_t workspace_bytes, hipStream_t
   a.partials = reinterpret_cast<float*>(workspace);
   // two output pixels per load wherever the geometry allows it (QUANTO_HIP_CONV_PAIR=0: experiments)
   const bool pair = a.sw == 1 && a.OW % 2 == 0 && a.W >= 2 && env_int("QUANTO_HIP_CONV_PAIR", 1) != 0;
-  // the per-tap table of the pair gather (windows of up to 9 taps; one workgroup per CU): QUANTO_HIP_CONV_TAB = 0 / 1 forces, default: while the grid
-  // cannot give a CU two workgroups anyway
-  bool tab = false;
-  if constexpr (!WIDE) {
-    const int forced = env_int("QUANTO_HIP_CONV_TAB", -1);
-    tab = pair && a.KH * a.KW <= TAB_TAPS - 1 && (forced >= 0 ? forced != 0 : (long)ntiles * mtiles * S <= env_int("QUANTO_HIP_CONV_TAB_MAX_WG", 320));
-    if (tab) launch_k<DT, FMT, INT_SHIFT, false, true, true>(a, ntiles, mtiles, stream);
-  }
-  if (tab) {
-  } else if (pair)
+  if (pair)
     launch_k<DT, FMT, INT_SHIFT, WIDE, true>(a, ntiles, mtiles, stream);
   else
     launch_k<DT, FMT, INT_SHIFT, WIDE, false>(a, ntiles, mtiles, stream);

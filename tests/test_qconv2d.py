@@ -387,12 +387,6 @@ def test_qconv2d_pair_gather_gpu(monkeypatch, dt, wq, cin, cout, k, s, p, d, hw)
         monkeypatch.setenv("QUANTO_HIP_CONV_PAIR", "0")
         y1 = q(x.cuda())
         monkeypatch.delenv("QUANTO_HIP_CONV_PAIR")
-        monkeypatch.setenv("QUANTO_HIP_CONV_TAB", "0")  # the pair gather computing its per-tap values per load (no LDS table)
-        y2 = q(x.cuda())
-        monkeypatch.setenv("QUANTO_HIP_CONV_TAB", "1")  # ... and with the table wherever the window has at most 9 taps
-        y3 = q(x.cuda())
-        monkeypatch.delenv("QUANTO_HIP_CONV_TAB")
-        assert torch.equal(y, y2) and torch.equal(y, y3), "pair gather: table and per-load forms differ"
         if sub:
             prod = torch.nn.functional.conv2d(x.double(), _oracle_dequantized(q.weight, dt), None, conv.stride, conv.padding, conv.dilation)
         else:
