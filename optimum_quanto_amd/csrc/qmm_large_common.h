@@ -10,7 +10,7 @@ constexpr int STAGES = 3;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// LDS-DMA, 16 bytes per lane, wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset (see v2 for why asm).
+// LDS-DMA, 16 bytes per lane, wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset (inline asm: through the builtin hipcc puts a vmcnt(0) in front of every ds_read that follows).
 // M0 is written and not restored: on gfx9+ the compiler only needs M0 for constructs this kernel does not contain
 // (movrel, GWS, sendmsg, its own LDS-DMA builtins), and two SALU instructions per piece matter in a one-wave-per-SIMD
 // instruction stream where every issue slot next to an MFMA is accounted for.
