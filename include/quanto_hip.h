@@ -291,12 +291,10 @@ int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, c
                              void* stream);
 
 /*
- * Workspace bytes the convolution kernels want for their K split (0: the problem is not split): when the 128 x 128 output tiles alone cannot
- * occupy the chip the K-tiles are dealt over up to 64 workgroups per tile, and the last workgroup of a tile to arrive adds the fp32 partial tiles
- * in split order (deterministic; r5: inside the convolution kernel, r4 used a second launch).  The library's common split-K layout: the first
- * QUANTO_HIP_WS_COUNTER_BYTES bytes are arrival counters that MUST BE ZERO on entry (the kernel leaves them zero), the partial tiles follow and
- * need no initialisation - a buffer that served any other split-K call of this library can be passed as it is.  K = cin * KH * KW.  Both
- * quanto_hip_q*_conv2d entries take the buffer (16-byte aligned); with NULL / too few bytes they run unsplit.  -1 on invalid arguments.
+ * Scratch bytes the convolution kernels want for their K split (0: the problem is not split): when the 128 x 128 output tiles alone cannot
+ * occupy the chip the K-tiles are dealt over up to 64 workgroups per tile, whose fp32 sums a second kernel adds in split order (deterministic,
+ * no atomics, nothing to zero).  K = cin * KH * KW.  Both quanto_hip_q*_conv2d entries take the buffer (16-byte aligned); with NULL / too few
+ * bytes they run unsplit.  -1 on invalid arguments.
  */
 int64_t quanto_hip_conv2d_workspace_size(int64_t B, int64_t OH, int64_t OW, int64_t OC, int64_t K);
 

@@ -169,11 +169,10 @@ struct Args {
   void* y;              // [B, OC, OH, OW]
   int M, N, K, C, G;    // M = B OH OW, N = OC, K = cin KH KW; int4: group size C, G = K / C groups per channel
   int cin, H, W, KH, KW, OH, OW, sh, sw, ph, pw, dh, dw;
-  // K split over blockIdx.z (S > 1): split z multiplies K-tiles [z nk / S, (z + 1) nk / S), parks its fp32 sums in `partials`, and the last workgroup of a tile adds them
+  // K split over blockIdx.z (S > 1): split z multiplies K-tiles [z nk / S, (z + 1) nk / S) and parks its fp32 sums in `partials`
   // ([S][tiles][8 waves][8 fragments][64 lanes] float4: whole lines per store); qconv2d_reduce_kernel adds them in split order and runs the epilogue
   int S;
   float* partials;
-  int* counters;        // [tiles] arrival counters of the K split: zero on entry, zero on exit
   uint32_t khw_magic, kw_magic;  // ceil(2^32 / (KH KW)), ceil(2^32 / KW); 0 when the divisor is 1 (fill_ktab)
 };
 static uint32_t div_magic(int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
@@ -513,55 +512,48 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
     cur ^= 1;
   }
 
-  if (S > 1) {
-    // ---- K split: park the partial sums (fragment-major: one 1 KiB store per wave and fragment), elect the last workgroup of this tile, which adds the
-    // partial tiles in split order (deterministic) and runs the epilogue (r5: in the same launch; until then a second kernel did - its launch and its own
-    // round trips were a quarter of a (8,128,28,28) -> 128 call).  Same protocol and workspace contract as qbits_skinny.hip: the workgroups of a tile may
-    // run on different XCDs, so the partials travel with system-coherent (sc0 sc1) 16-byte stores and loads and the only ordering needed is "my stores
-    // are acknowledged (vmcnt(0)) before my workgroup's arrival is counted"; counters zero on entry, left zero.
-    const int tile_id = blockIdx.y * gridDim.x + nt, tiles = gridDim.y * gridDim.x;
-    float* mine = a.partials + (((size_t)sp * tiles + tile_id) * (8 * 8 * 64) + (size_t)(wave * 8) * 64 + lane) * 4;
+  if (S > 1) {  // park the partial sums: one 1 KiB store per wave and fragment
+    f32x4* mine = reinterpret_cast<f32x4*>(a.partials) + ((size_t)(sp * gridDim.y + blockIdx.y) * gridDim.x + nt) * (8 * 8 * 64) + (wave * 8) * 64 + lane;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)  // s_nop: gfx9 hazard "VMEM store of > 64 bits, then VALU write of its data VGPRs" - hipcc cannot see into the asm
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(mine + (i * 2 + j) * 64 * 4), "v"(acc[i][j]) : "memory");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int* flag = reinterpret_cast<int*>(smem);  // (the tiles are free: the K loop ended behind a barrier)
-    if (tid == 0) *flag = __hip_atomic_fetch_add(a.counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __syncthreads();
-    if (*flag != S - 1) return;
-    if (tid == 0) __hip_atomic_store(a.counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // leave the workspace as found
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // fixed order: the result does not depend on which workgroup arrived last; two splits' sixteen loads in flight together
-    for (int q0 = 0; q0 < S; q0 += 2) {
-      f32x4 v[2][8];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int q = q0 + u < S ? q0 + u : S - 1;
-        const float* theirs = a.partials + (((size_t)q * tiles + tile_id) * (8 * 8 * 64) + (size_t)(wave * 8) * 64 + lane) * 4;
-#pragma unroll
-        for (int f = 0; f < 8; ++f) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[u][f]) : "v"(theirs + f * 64 * 4) : "memory");
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int f = 0; f < 8; ++f) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[u][f])::"memory");  // ties the uses below to the wait
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        if (q0 + u < S) {
-#pragma unroll
-          for (int f = 0; f < 8; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[f >> 1][f & 1][r] += v[u][f][r];
-        }
-    }
+      for (int j = 0; j < 2; ++j) mine[(i * 2 + j) * 64] = acc[i][j];
+    return;
   }
   store_tile<DT, PL>(a, acc, m0, nt, wm, wn, lane);
+}
+
+// split-K tail: one WAVE per (output tile, wave slot of the tile kernel) adds that slot's eight fragments over the S partial tiles in split order
+// (deterministic), four splits' loads in flight together, and runs the epilogue.  (First form: one 512-thread workgroup per tile with one split per
+// loop iteration - 14 workgroups each waiting 12 times for a round trip cost more than the convolution itself.)
+template <int DT, int PL>
+__global__ void __launch_bounds__(64) qconv2d_reduce_kernel(const Args a) {
+  const int lane = threadIdx.x, wave = blockIdx.z, S = a.S;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4* base = reinterpret_cast<const f32x4*>(a.partials) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (8 * 8 * 64) + (wave * 8) * 64 + lane;
+  const size_t split_stride = (size_t)gridDim.y * gridDim.x * (8 * 8 * 64);
+  for (int sp0 = 0; sp0 < S; sp0 += 4) {
+    f32x4 v[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int sp = sp0 + u < S ? sp0 + u : S - 1;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) v[u][f] = base[sp * split_stride + f * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (sp0 + u < S) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[f >> 1][f & 1][r] += v[u][f][r];
+      }
+  }
+  store_tile<DT, PL>(a, acc, blockIdx.y * BM, blockIdx.x, wave >> 2, wave & 3, lane);
 }
 
 // K split: the tile kernel is bound by its gather per K-tile (~1.9 us per workgroup and K-tile whatever M is), so what matters is how many
@@ -579,10 +571,7 @@ static int pick_split(int64_t M, int64_t N, int64_t K) {
   while (tiles * (s + 1) <= 512 && nk / (s + 1) >= 4 && s < 64) ++s;
   return s;
 }
-// [arrival counters: the library's common QUANTO_HIP_WS_COUNTER_BYTES region, zero on entry and on exit | S x tiles fp32 partial tiles]
-static size_t split_workspace(int64_t M, int64_t N, int S) {
-  return S <= 1 ? 0 : QUANTO_HIP_WS_COUNTER_BYTES + (size_t)S * ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (BM * BN * 4);
-}
+static size_t split_workspace(int64_t M, int64_t N, int S) { return S <= 1 ? 0 : (size_t)S * ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (BM * BN * 4); }
 
 template <int DT, int FMT, bool INT_SHIFT, bool WIDE, bool PAIR>
 static void launch_k(const Args& a, int ntiles, int mtiles, hipStream_t stream) {
@@ -596,14 +585,14 @@ static int launch_w(Args a, void* workspace, size_t workspace_bytes, hipStream_t
   int S = pick_split(a.M, a.N, a.K);
   if (S > 1 && (!workspace || workspace_bytes < split_workspace(a.M, a.N, S) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
   a.S = S;
-  a.counters = reinterpret_cast<int*>(workspace);
-  a.partials = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + QUANTO_HIP_WS_COUNTER_BYTES);
+  a.partials = reinterpret_cast<float*>(workspace);
   // two output pixels per load wherever the geometry allows it (QUANTO_HIP_CONV_PAIR=0: experiments)
   const bool pair = a.sw == 1 && a.OW % 2 == 0 && a.W >= 2 && env_int("QUANTO_HIP_CONV_PAIR", 1) != 0;
   if (pair)
     launch_k<DT, FMT, INT_SHIFT, WIDE, true>(a, ntiles, mtiles, stream);
   else
     launch_k<DT, FMT, INT_SHIFT, WIDE, false>(a, ntiles, mtiles, stream);
+  if (S > 1) hipLaunchKernelGGL((qconv2d_reduce_kernel<DT, PL>), dim3(ntiles, mtiles, 8), dim3(64), 0, stream, a);
   return launch_status();
 }
 template <int DT, int FMT, bool INT_SHIFT>
@@ -635,7 +624,7 @@ int qbytes_conv2d_mfma(const void* x, const void* w, const void* s, const void* 
                        int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbytes_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
   const conv::Args a{x, reinterpret_cast<const uint8_t*>(w), s, nullptr, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), 0, 0,
-                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr, nullptr, conv::div_magic((int)(KH * KW)), conv::div_magic((int)KW)};
+                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr, conv::div_magic((int)(KH * KW)), conv::div_magic((int)KW)};
   using namespace conv;
 #define QH_CASE(DT, FMT) return launch<DT, FMT, false>(a, workspace, workspace_bytes, stream)
   if (out_dtype == QUANTO_HIP_BF16) {
@@ -663,7 +652,7 @@ int qbits_conv2d_mfma(const void* x, const uint8_t* packed, const void* scale, c
                       const PackedGeom& g, int dtype, bool int_shift, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbits_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, g, dtype)) return QUANTO_HIP_ENOTSUP;
   const conv::Args a{x, packed, scale, shift, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), (int)g.C, (int)g.G,
-                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr, nullptr, conv::div_magic((int)(KH * KW)), conv::div_magic((int)KW)};
+                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr, conv::div_magic((int)(KH * KW)), conv::div_magic((int)KW)};
   using namespace conv;
 #define QH_CASE(DT, FMT) return int_shift ? launch<DT, FMT, true>(a, workspace, workspace_bytes, stream) : launch<DT, FMT, false>(a, workspace, workspace_bytes, stream)
   if (g.bits == 4) {

@@ -283,12 +283,11 @@ class _Bindings:
         return (size + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
     def _conv2d_scratch(self, x, B, OH, OW, OC, K):
-        """(buffer, bytes) for the convolution kernels' K split - the library's split-K workspace (arrival counters zero on entry, left zero by
-        the kernel: r5, when the reduce moved into the convolution kernel); (None, 0) when the problem is not split."""
+        """(buffer, bytes) for the convolution kernels' K split - plain scratch, nothing to zero; (None, 0) when the problem is not split."""
         nbytes = int(self._c.quanto_hip_conv2d_workspace_size(B, max(OH, 0), max(OW, 0), OC, K))
         if nbytes <= 0:
             return None, 0
-        return self._zeroed_workspace(x.device, nbytes, self._stream(x).value), nbytes
+        return self._scratch(x.device, nbytes, self._stream(x).value), nbytes
 
     @classmethod
     def conv2d_geometry_ok(cls, x_shape, w_shape, stride, padding, dilation) -> bool:

@@ -16,7 +16,7 @@ int main() {
     std::vector<uint16_t> hs(s.OC, 0x3C00);
     void *x, *w, *sc, *y, *ws;
     const size_t ws_bytes = 64u << 20;
-    hipMalloc(&x, hx.size() * 2); hipMalloc(&w, hw.size()); hipMalloc(&sc, s.OC * 2); hipMalloc(&y, (size_t)s.B * s.OC * OH * OW * 2); hipMalloc(&ws, ws_bytes); hipMemset(ws, 0, 4096);  // (the K split's arrival counters: zero on entry)
+    hipMalloc(&x, hx.size() * 2); hipMalloc(&w, hw.size()); hipMalloc(&sc, s.OC * 2); hipMalloc(&y, (size_t)s.B * s.OC * OH * OW * 2); hipMalloc(&ws, ws_bytes);
     hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), hw.size(), hipMemcpyHostToDevice);
     hipMemcpy(sc, hs.data(), s.OC * 2, hipMemcpyHostToDevice);
     auto run = [&]() {

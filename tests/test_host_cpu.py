@@ -140,19 +140,19 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
 
 def test_conv2d_k_split_plan_without_a_gpu():
     """quanto_hip_conv2d_workspace_size is the host-side statement of the convolution kernel's K split (csrc/qconv_mfma.hip: pick_split): up to
-    ~2 workgroups per CU, at least 4 K-tiles per split (r5; 3 until the gather got cheaper), no split beyond 128 output tiles; the 4 KiB counter region + one 128 x 128 fp32 tile per (split, tile)."""
+    ~2 workgroups per CU, at least 4 K-tiles per split (r5; 3 until the gather got cheaper), no split beyond 128 output tiles; one 128 x 128 fp32 tile per (split, tile)."""
     f = quanto_hip.cdll.quanto_hip_conv2d_workspace_size
     f.restype, f.argtypes = ctypes.c_int64, [ctypes.c_int64] * 5
     tile = 128 * 128 * 4
-    assert f(8, 7, 7, 512, 4608) == 4096 + 18 * (4 * 4) * tile        # 16 tiles, 72 K-tiles: 18 splits of 4
-    assert f(8, 28, 28, 128, 1152) == 4096 + 4 * 49 * tile            # 49 tiles, 18 K-tiles: 4 splits of 4 or 5
-    assert f(1, 28, 28, 256, 2304) == 4096 + 9 * (7 * 2) * tile       # 14 tiles, 36 K-tiles
-    assert f(8, 28, 28, 256, 2304) == 4096 + 5 * (49 * 2) * tile      # 98 tiles: 5 splits keep the grid under 512 workgroups
+    assert f(8, 7, 7, 512, 4608) == 18 * (4 * 4) * tile        # 16 tiles, 72 K-tiles: 18 splits of 4
+    assert f(8, 28, 28, 128, 1152) == 4 * 49 * tile            # 49 tiles, 18 K-tiles: 4 splits of 4 or 5
+    assert f(1, 28, 28, 256, 2304) == 9 * (7 * 2) * tile       # 14 tiles, 36 K-tiles
+    assert f(8, 28, 28, 256, 2304) == 5 * (49 * 2) * tile      # 98 tiles: 5 splits keep the grid under 512 workgroups
     assert f(8, 56, 56, 64, 576) == 0 and f(32, 56, 56, 64, 576) == 0   # 196 / 784 tiles: not split
-    assert f(8, 32, 32, 320, 2880) == 4096 + 2 * (64 * 3) * tile      # 129 .. 256 tiles: two splits once K is at least 32 K-tiles deep (45 here)
+    assert f(8, 32, 32, 320, 2880) == 2 * (64 * 3) * tile      # 129 .. 256 tiles: two splits once K is at least 32 K-tiles deep (45 here)
     assert f(32, 28, 28, 128, 1152) == 0                       # 196 tiles, 18 K-tiles: not split
     assert f(8, 56, 56, 256, 64) == 0                          # one K-tile
-    assert f(8, 28, 28, 128, 1100) == 4096 + 4 * 49 * tile            # a ragged last K-tile counts as a K-tile (r5): 18 of them, as for K = 1152
+    assert f(8, 28, 28, 128, 1100) == 4 * 49 * tile            # a ragged last K-tile counts as a K-tile (r5): 18 of them, as for K = 1152
     assert f(8, 112, 112, 64, 147) == 0                        # an RGB 7x7 stem: 3 K-tiles, 784 tiles
     assert f(0, 28, 28, 128, 1152) == 0                        # empty batch
     assert f(-1, 28, 28, 128, 1152) == -1 and f(8, 28, 28, 0, 1152) == -1

@@ -331,10 +331,6 @@ def test_qconv2d_implicit_gemm_k_split_gpu(monkeypatch, wq, split):
             prod = torch.nn.functional.conv2d(x.double(), _oracle_dequantized(q.weight, "bf16"), None, 1, 1)
     bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
     assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), "bf16", f"conv K split {split} {wq}")
-    with torch.no_grad():  # r5: the last workgroup of a tile reduces in the kernel - same workspace call after call (counters restored), same bits
-        xd = x.cuda()
-        for _ in range(25):
-            assert torch.equal(q(xd), y)
     if split == 7 and wq == "qint8":  # the C entry without a workspace: same problem, unsplit, same gate
         lib = quanto_hip.lib
         w = q.weight
