@@ -117,9 +117,13 @@ static size_t dequant_mfma_workspace(const PackedGeom& g) { return (size_t)g.N *
 // dequantize + dense is flat in M up to ~1 k rows (one dequantize pass + a dense GEMM that cannot fill the chip) and wins once the
 // fused kernel needs more than ~1.6 rounds of 128-token tiles (1.2 until two 64-token workgroups shared a CU: (1536,4096,4096) 71.5 / 81.4).  QUANTO_HIP_FUSED4_MAX_COST (x 100) / _MIN_M override the limits in experiments.
 float qbits_mfma_fused_cost(int64_t, const PackedGeom&);
+// r5: the dense kernel behind dequantize + dense got faster (128-byte rows, qmm_native8.hip) and gains most on wide outputs (more tiles per round):
+// off the fitted grid AUTO was 1.31 x behind at (1024, K = 11008, N = 5120) (fused 193 vs 147 us) and 1.11 x at (1024,5120,5120) (87.8 vs 79.1),
+// while N = 4096 still hands over at ~1.6 rounds ((1536,4096,4096) 72.2 vs 83.9, (1536,14336,4096) 250 vs 256; profiles/r05_auto_vs_best.jsonl,
+// r05_prefill_handover.jsonl): beyond 4096 output features the limit is 1.3 rounds.
 static bool fused4_wins(int64_t M, const PackedGeom& g) {
   if (M <= env_int("QUANTO_HIP_FUSED4_MIN_M", 64)) return false;
-  return qbits_mfma_fused_cost(M, g) * 100.f <= (float)env_int("QUANTO_HIP_FUSED4_MAX_COST", 160);
+  return qbits_mfma_fused_cost(M, g) * 100.f <= (float)env_int("QUANTO_HIP_FUSED4_MAX_COST", g.N > 4096 ? 130 : 160);
 }
 
 // The register-streaming kernel (K split inside the block, no split-K tail) against the LDS-streaming one, us per launch:
