@@ -91,10 +91,8 @@ def _implicit_conv2d(input, weight, scale, bias, stride, padding, dilation, grou
     if weight.dim() != 4 or input.shape[1] != weight.shape[1] or not quanto_hip.lib.qbytes_conv2d_supported(input, weight._data, stride, padding, dilation):
         return None
     pair = _pair
-    if tuple(weight.shape[2:]) == (1, 1) and pair(stride) == [1, 1] and pair(padding) == [0, 0] and weight.shape[1] < 128:
-        # pointwise with ONE K-tile: the "patches" are a permuted view of the input, one copy + the tuned GEMM kernels is ahead ((8,64,56,56) -> 256:
-        # 21.5 vs 25.0 us); from two K-tiles on the convolution kernel is ((8,256,56,56) -> 64: 14.9 vs 37.6, (8,512,28,28) -> 128: 19.4 vs 29.2)
-        return None
+    # (until r5 pointwise convolutions with ONE K-tile - fewer than 128 input channels - went to a permuted view + the tuned GEMM kernels: 21.5 vs 25.0 us at
+    # (8,64,56,56) -> 256; with the r5 gather and epilogue the convolution kernel takes that shape in 12.0 us: profiles/r05_qconv2d_paths_grid.jsonl)
     return torch.ops.quanto.qbytes_conv2d(input, weight._data, scale, bias, pair(stride), pair(padding), pair(dilation))
 
 
@@ -114,8 +112,6 @@ def _implicit_conv2d_qbits(input, weight, bias, stride, padding, dilation, group
     if not quanto_hip.lib.qbits_conv2d_supported(input, tuple(weight.shape), packed.bits, weight._group_size, stride, padding, dilation):
         return None
     pair = _pair
-    if tuple(weight.shape[2:]) == (1, 1) and pair(stride) == [1, 1] and pair(padding) == [0, 0] and weight.shape[1] < 128:
-        return None  # pointwise with one K-tile: a permuted view of the input + the tuned GEMM kernels (see _implicit_conv2d)
     return torch.ops.quanto.qbits_conv2d(input, packed._data, weight._scale, weight._shift, bias, packed.bits, weight._group_size,
                                          list(weight.shape), pair(stride), pair(padding), pair(dilation))
 

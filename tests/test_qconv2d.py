@@ -177,7 +177,7 @@ def test_qconv2d_fused_gemm_gpu(golden, tag, cname, dt):
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("wq", ["qint8", "qfloat8_e4m3fn", "qfloat8_e5m2"])
 @pytest.mark.parametrize("cin,cout,k,s,p,d", [(64, 96, 3, 1, 1, 1), (64, 40, 3, 2, 0, 1), (128, 64, (3, 5), (2, 1), (1, 2), (1, 2)), (64, 32, 1, 2, 0, 1),
-                                              (192, 130, 3, 1, 2, 2), (128, 72, 1, 1, 0, 1)])
+                                              (192, 130, 3, 1, 2, 2), (128, 72, 1, 1, 0, 1), (64, 96, 1, 1, 0, 1)])  # (the last: pointwise with ONE K-tile - the kernel's since r5)
 def test_qconv2d_implicit_gemm_gpu(dt, wq, cin, cout, k, s, p, d):
     """quanto::qbytes_conv2d (r4): the convolution as an IMPLICIT GEMM - the im2col operand is gathered inside the kernel's staging loads,
     the output is written NCHW.  Strides, paddings, dilations, rectangular windows, ragged M (3 x 13 x 11 pixels) and ragged output channels;
