@@ -48,7 +48,7 @@ for (B, C, H, OC, k, s, p) in SHAPES:
         with torch.no_grad():
             t_dir = _time_graph(direct, 5)
         print(json.dumps({"weights": WEIGHTS, "B": B, "C": C, "H": H, "OC": OC, "k": k, "stride": s, "K": C * k * k, "conv_kernel_direct_us": round(t_dir, 1),
-                          "depth": os.environ.get("QUANTO_HIP_CONV_DEPTH", "auto"), "split": os.environ.get("QUANTO_HIP_CONV_SPLIT", "auto")}), flush=True)
+                          "pair": os.environ.get("QUANTO_HIP_CONV_PAIR", "auto"), "split": os.environ.get("QUANTO_HIP_CONV_SPLIT", "auto")}), flush=True)
         continue
     with torch.no_grad():
         t_dir = _time_graph(direct, 5)
