@@ -34,6 +34,7 @@ bool qbits_conv2d_supported(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t
 int qbits_conv2d_mfma(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
                       int64_t, int64_t, int, int, int, int, int, int, const PackedGeom&, int, bool, void*, size_t, hipStream_t);
 size_t conv2d_workspace(int64_t, int64_t, int64_t);
+bool conv2d_last_was_rows();
 int qbytes_conv2d_mfma(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
                        int64_t, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t);
 int qbytes_mm_gemv_multi(const void*, int, const void* const*, const void* const*, const void* const*, void* const*, const int64_t*, int64_t,
@@ -619,7 +620,7 @@ int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, c
   if (!x || !w || !scales || !y) return QUANTO_HIP_EINVAL;
   const int r = qbytes_conv2d_mfma(x, w, scales, bias, y, B, cin, H, W, OC, KH, KW, OH, OW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, a_dtype,
                                    b_dtype, out_dtype, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
-  if (r == QUANTO_HIP_OK) set_last_kernel("conv2d_mfma");
+  if (r == QUANTO_HIP_OK) set_last_kernel(conv2d_last_was_rows() ? "conv2d_mfma_rows" : "conv2d_mfma");
   return r;
 }
 

@@ -33,7 +33,7 @@
 
 #ifndef QH_CONV_ABLATE
 #define QH_CONV_ABLATE 0  // timing experiments only (scripts/probes/conv_ablate.hip; WRONG results): 1 no gather loads, 2 no MFMAs / fragment reads, 4 no weight
-#endif                      // loads, 8 no gather address arithmetic either, 16 no staging writes, 32 no tap-table fill
+#endif                      // loads, 8 no gather address arithmetic either, 16 no staging writes, 32 no tap-table fill, 64 (row form) no weight conversion, 128 (row form) no epilogue
 
 
 namespace qh {
@@ -75,6 +75,20 @@ __device__ __forceinline__ uint32_t pack_rne(float a, float b) {
   return (uint32_t)__builtin_bit_cast(uint16_t, E::from_f32(a)) | ((uint32_t)__builtin_bit_cast(uint16_t, E::from_f32(b)) << 16);
 }
 
+// two floats that are EXACT in the 16-bit type (int8 / fp8 weights) -> one dword with one instruction (v_cvt_pk_bf16_f32 / v_cvt_pkrtz_f16_f32);
+// pack_rne converts element by element and ors the halves (two conversions + shift + or)
+template <int DT>
+__device__ __forceinline__ uint32_t pack_exact(float a, float b) {
+  if constexpr (DT == QUANTO_HIP_BF16) {
+    bf16x2 r;
+    r.x = (__bf16)a;
+    r.y = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, r);
+  } else {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+  }
+}
+
 // two 16-bit elements -> one dword.  As a two-element vector of 16-bit integers: hipcc emits ONE v_perm_b32 that takes the low halves of both
 // registers; written as lo | hi << 16 on unsigned variables it zero-extends first (a v_and per element)
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -103,8 +117,8 @@ __device__ __forceinline__ void convert16(const uint4& w, uint4& c0, uint4& c1) 
       const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_bf8((int)in[d], false), hi = __builtin_amdgcn_cvt_pk_f32_bf8((int)in[d], true);
       f0 = lo.x; f1 = lo.y; f2 = hi.x; f3 = hi.y;
     }
-    out[2 * d] = pack_rne<DT>(f0, f1);
-    out[2 * d + 1] = pack_rne<DT>(f2, f3);
+    out[2 * d] = pack_exact<DT>(f0, f1);
+    out[2 * d + 1] = pack_exact<DT>(f2, f3);
   }
   c0 = make_uint4(out[0], out[1], out[2], out[3]);
   c1 = make_uint4(out[4], out[5], out[6], out[7]);
@@ -174,6 +188,7 @@ struct Args {
   int S;
   float* partials;
   uint32_t khw_magic, kw_magic;  // ceil(2^32 / (KH KW)), ceil(2^32 / KW); 0 when the divisor is 1 (fill_ktab)
+  uint32_t kh_magic;             // ceil(2^32 / KH) (row form)
 };
 static uint32_t div_magic(int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
 
@@ -523,6 +538,248 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
   store_tile<DT, PL>(a, acc, m0, nt, wm, wn, lane);
 }
 
+// ---- ROW form (r5): windows three taps wide, stride 1 and dilation 1 along the width, even OW ---------------------------------------------------
+// The gather above pays ~3.4 VALU instructions and half a load per gathered element, and the kernel is bound by exactly that instruction stream
+// (DESIGN 4.8).  For the layers that dominate convolutional networks - 3 x 3 (any KH x 3) windows walked at stride 1 - the taps (c, i, 0..2) of
+// two neighbouring output pixels are FOUR neighbouring input elements: one 8-byte load per (pixel pair, window row r = c KH + i) brings six
+// operand elements.  A K-tile is 32 window rows = 96 k; inside a tile k is ordered [tap j][row] (any order both operands share is a GEMM), so
+// the staging is a 4 x 4 transposition of 16-bit elements:
+//   * wave w, lane p: pixel pair (m0 + 2p, + 1), rows 4w .. 4w + 3 of the tile.  Everything that depends on the row - channel, tap row, byte
+//     offset, "behind the last row" - is wave-uniform and computed on the SCALAR unit (no table in LDS, no wave filling it while seven wait);
+//     per row the vector unit adds the pixel's base, extracts the row's padding bit (v_bfe_i32) and ors both into the offset: a row over the
+//     top / bottom padding becomes offset 0xFFFFFFFF of a range-checked buffer load and reads zeros;
+//   * left / right padding is per PIXEL PAIR, not per tap: the 8-byte window is clamped into the image row and two per-thread v_perm selectors
+//     realign it and zero the elements over the padding (N0 = e0 e1, N1 = e2 e3: first pixel e0 e1 e2, second pixel e1 e2 e3);
+//   * eight v_perm with literal selectors transpose the four rows x four elements into P0 .. P3 (element q of rows 4w .. 4w + 3, 8 bytes each);
+//     the first pixel stores P0 P1 P2 into the tap blocks of its LDS row, the second P1 P2 P3: 16 VALU + 6 ds_write_b64 for 24 elements.
+//   * weights: thread (channel tid >> 2, part tid & 3) loads 24 contiguous bytes = rows 8 part .. + 7 x 3 taps, converts them during the MFMA
+//     phase (any byte of a register is a free operand select) and stores 16 bytes per tap block.
+// LDS: [128 rows][224 bytes] per operand (96 k = 192 bytes + 32 of padding; 16-byte slot c of row r at c ^ (r >> 2 & 3): conflict-free
+// ds_read_b128 fragments, two-way staging stores - scripts/models/conv_rows_lds_model.py), ONE buffer and two barriers per K-tile: 56 KiB, two
+// workgroups per CU.  Needs K = 3 cin KH to be a multiple of 8 (8-byte weight pieces never straddle a row's end), KH <= 31, W >= 4.
+namespace rows {
+constexpr int RT = 32, BKR = 3 * RT;  // window rows / k per K-tile
+constexpr int RS = 224;               // LDS bytes per operand row
+constexpr int OP_BYTES = BM * RS;
+constexpr int LDS_BYTES = 2 * OP_BYTES;
+}  // namespace rows
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <int FMT>
+__device__ __forceinline__ float byte_to_f32(uint32_t d, int b) {  // b: a literal after unrolling
+  if constexpr (FMT == W_I8) {
+    return (float)(int8_t)((d >> (8 * b)) & 0xFFu);
+  } else if constexpr (FMT == W_F8E4M3) {
+    switch (b) {
+      case 0: return __builtin_amdgcn_cvt_f32_fp8((int)d, 0);
+      case 1: return __builtin_amdgcn_cvt_f32_fp8((int)d, 1);
+      case 2: return __builtin_amdgcn_cvt_f32_fp8((int)d, 2);
+      default: return __builtin_amdgcn_cvt_f32_fp8((int)d, 3);
+    }
+  } else {
+    switch (b) {
+      case 0: return __builtin_amdgcn_cvt_f32_bf8((int)d, 0);
+      case 1: return __builtin_amdgcn_cvt_f32_bf8((int)d, 1);
+      case 2: return __builtin_amdgcn_cvt_f32_bf8((int)d, 2);
+      default: return __builtin_amdgcn_cvt_f32_bf8((int)d, 3);
+    }
+  }
+}
+
+template <int DT, int FMT, bool BUF>
+__global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
+  using namespace rows;
+  using V8 = typename Mma<DT>::V8;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // [A tile | B tile]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // 64 pixels x 32 channels per wave
+  const int m0 = blockIdx.y * BM, nt = blockIdx.x;
+  const int M = a.M, N = a.N, K = a.K;
+  const int R = a.cin * a.KH;  // window rows
+  const int S = a.S, sp = blockIdx.z;
+  const int nk_all = (R + RT - 1) / RT;
+  const int kt_lo = (int)((long)sp * nk_all / S), nk = (int)((long)(sp + 1) * nk_all / S) - kt_lo;  // >= 1 (the launcher keeps S <= nk_all)
+  const uint8_t* xb = reinterpret_cast<const uint8_t*>(a.x);
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)(((long)M / (a.OH * a.OW)) * a.cin * a.H * a.W * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.w), 0, N * K, 0x00020000);
+
+  // ---- the lane's pixel pair (the same in every wave) ------------------------------------------------------------------------------------------
+  int px_base;            // byte offset of element (b, 0, oh sh - ph, ws): the window's first row, clamped first column
+  uint32_t nok = 0x80000000u;  // bit i: tap row i of the pair lies over the top / bottom padding; bit 31 (KH <= 31): rows behind the last one
+  uint32_t selN0, selN1;  // v_perm selectors: the clamped window -> (e0, e1) and (e2, e3), elements over the left / right padding zeroed
+  {
+    const int L = a.OH * a.OW;
+    int m = m0 + 2 * lane;
+    m = m < M ? m : M - 2;  // (M is even: OW is)
+    const int b = m / L, l = m - b * L, oh = l / a.OW, ow = l - oh * a.OW;
+    const int iw0 = ow - a.pw;  // column of e0; e_j at iw0 + j, the first pixel takes e0 e1 e2, the second e1 e2 e3
+    int ws = iw0 < 0 ? 0 : iw0;
+    ws = ws > a.W - 4 ? a.W - 4 : ws;  // an element inside the image is inside the clamped window (W >= 4)
+    const int delta = iw0 - ws;
+    px_base = 2 * ((b * a.cin * a.H + (oh * a.sh - a.ph)) * a.W + ws);
+    for (int i = 0; i < a.KH; ++i) {
+      const int ih = oh * a.sh - a.ph + i * a.dh;
+      if (ih < 0 || ih >= a.H) nok |= 1u << i;
+    }
+    auto half_sel = [&](int j) -> uint32_t {  // window position q = bytes 2q, 2q + 1 of {D1, D0}
+      const int iw = iw0 + j, q = j + delta;
+      return iw >= 0 && iw < a.W ? (uint32_t)(((2 * q + 1) << 8) | (2 * q)) : 0x0c0cu;
+    };
+    selN0 = half_sel(0) | (half_sel(1) << 16);
+    selN1 = half_sel(2) | (half_sel(3) << 16);
+  }
+
+  // ---- LDS addresses (constant over the K loop: one buffer) --------------------------------------------------------------------------------------
+  // rows 2 lane and 2 lane + 1 share their swizzle; tap block j at + 64 j (the swizzle only touches the slot inside a block)
+  const uint32_t awr = (uint32_t)((2 * lane) * RS + (((wave >> 1) ^ ((lane >> 1) & 3)) << 4) + (wave & 1) * 8);
+  const uint32_t bwr = (uint32_t)(OP_BYTES + (tid >> 2) * RS + (((tid & 3) ^ ((tid >> 4) & 3)) << 4));
+  const uint32_t frag_slot = (uint32_t)((((lane >> 4) ^ ((lane >> 2) & 3)) << 4));
+  const uint32_t ard = (uint32_t)((wm * 64 + (lane & 15)) * RS) + frag_slot;
+  const uint32_t brd = (uint32_t)(OP_BYTES + (wn * 32 + (lane & 15)) * RS) + frag_slot;
+
+  // ---- weights: channel tid >> 2, bytes 24 (tid & 3) .. + 23 of the K-tile's 96 ---------------------------------------------------------------------
+  int wn_row = nt * BN + (tid >> 2);
+  wn_row = wn_row < N ? wn_row : N - 1;
+  const uint32_t woff = (uint32_t)(wn_row * K + 24 * (tid & 3));
+  const int wk = 24 * (tid & 3);
+
+  u32x2 D[4], wq[3];  // gathered windows / weight bytes of the K-tile in flight
+  uint4 cw[3];        // its converted weights, one 16-byte piece per tap block
+  auto issue = [&](int t) {
+    const int T = kt_lo + t;
+    const int krem = K - T * BKR;  // bytes of this tile inside the weight row (>= 96 except in a ragged last tile)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const uint32_t off = wk + 8 * j < krem ? woff + (uint32_t)(T * BKR + 8 * j) : 0xFFFFFFFFu;
+      wq[j] = (QH_CONV_ABLATE & 4) ? u32x2{off, off} : __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, (int)off, 0, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      // scalar: row -> (channel, tap row) -> byte offset; behind the last row: -1
+      const uint32_t r = (uint32_t)(T * RT + 4 * wave + u);
+      const uint32_t c = __umulhi(r, a.kh_magic) + (a.kh_magic ? 0u : r);  // (magic 0: KH = 1)
+      const uint32_t i = r - c * (uint32_t)a.KH;
+      const uint32_t roff = 2u * ((c * (uint32_t)a.H + i * (uint32_t)a.dh) * (uint32_t)a.W);
+      const uint32_t pad = (uint32_t)__builtin_amdgcn_sbfe(nok, (int)r < R ? i : 31u, 1);  // -1: over the padding, or behind the last row (bit 31)
+      constexpr uint32_t gone = 0u;
+      if constexpr (BUF) {
+        const uint32_t addr = ((uint32_t)px_base + roff) | pad | gone;
+        D[u] = (QH_CONV_ABLATE & 1) ? u32x2{addr, addr} : __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)addr, 0, 0));
+      } else {  // global loads (experiments): element 0 for a row that is not there, zeroed afterwards
+        const uint32_t keep = ~(pad | gone);
+        const U2u v = *reinterpret_cast<const U2u*>(xb + (((uint32_t)px_base + roff) & keep));
+        D[u] = u32x2{v.x & keep, v.y & keep};
+      }
+    }
+  };
+  // 24 weight bytes in (row, tap) order -> per tap block j the eight rows' values, in the activation dtype (exact)
+  auto convert = [&](int j) {
+    const uint32_t in[6] = {wq[0].x, wq[0].y, wq[1].x, wq[1].y, wq[2].x, wq[2].y};
+    if (QH_CONV_ABLATE & 64) {
+      cw[j] = make_uint4(in[j], in[j + 1], in[j + 2], in[j + 3]);
+      return;
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int e0 = 3 * (2 * h) + j, e1 = 3 * (2 * h + 1) + j;
+      o[h] = pack_exact<DT>(byte_to_f32<FMT>(in[e0 >> 2], e0 & 3), byte_to_f32<FMT>(in[e1 >> 2], e1 & 3));
+    }
+    cw[j] = make_uint4(o[0], o[1], o[2], o[3]);
+  };
+  auto write = [&]() {
+    if (QH_CONV_ABLATE & 16) {  // keep the loaded registers alive
+      uint32_t t = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t ^= D[u].x ^ D[u].y;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) t ^= cw[j].x ^ cw[j].y ^ cw[j].z ^ cw[j].w;
+      if (t == 0x12345678u) smem[tid] = 1;
+      return;
+    }
+    uint32_t n0[4], n1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      n0[u] = __builtin_amdgcn_perm(D[u].y, D[u].x, selN0);
+      n1[u] = __builtin_amdgcn_perm(D[u].y, D[u].x, selN1);
+    }
+    constexpr uint32_t LO = 0x05040100u, HI = 0x07060302u;  // the low / high halves of two registers
+    const uint2 p0 = make_uint2(__builtin_amdgcn_perm(n0[1], n0[0], LO), __builtin_amdgcn_perm(n0[3], n0[2], LO));
+    const uint2 p1 = make_uint2(__builtin_amdgcn_perm(n0[1], n0[0], HI), __builtin_amdgcn_perm(n0[3], n0[2], HI));
+    const uint2 p2 = make_uint2(__builtin_amdgcn_perm(n1[1], n1[0], LO), __builtin_amdgcn_perm(n1[3], n1[2], LO));
+    const uint2 p3 = make_uint2(__builtin_amdgcn_perm(n1[1], n1[0], HI), __builtin_amdgcn_perm(n1[3], n1[2], HI));
+    uint8_t* sa = smem + awr;
+    *reinterpret_cast<uint2*>(sa) = p0;
+    *reinterpret_cast<uint2*>(sa + 64) = p1;
+    *reinterpret_cast<uint2*>(sa + 128) = p2;
+    *reinterpret_cast<uint2*>(sa + RS) = p1;
+    *reinterpret_cast<uint2*>(sa + RS + 64) = p2;
+    *reinterpret_cast<uint2*>(sa + RS + 128) = p3;
+    uint8_t* sb = smem + bwr;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) *reinterpret_cast<uint4*>(sb + 64 * j) = cw[j];
+  };
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma_step = [&](int kk) {
+    if (QH_CONV_ABLATE & 2) return;
+    V8 fa[4], fb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const V8*>(smem + ard + i * 16 * RS + kk * 64);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const V8*>(smem + brd + j * 16 * RS + kk * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = Mma<DT>::run(fa[i], fb[j], acc[i][j]);
+  };
+
+  issue(0);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) convert(j);
+  write();
+  __syncthreads();
+  for (int t = 0; t + 1 < nk; ++t) {
+    issue(t + 1);
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {  // the next tile's weights are converted in the shadow of this tile's MFMAs
+      mma_step(kk);
+      convert(kk);
+    }
+    __syncthreads();  // every wave has read tile t
+    write();
+    __syncthreads();
+  }
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) mma_step(kk);
+
+  if (S > 1) {
+    f32x4* mine = reinterpret_cast<f32x4*>(a.partials) + ((size_t)(sp * gridDim.y + blockIdx.y) * gridDim.x + nt) * (8 * 8 * 64) + (wave * 8) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) mine[(i * 2 + j) * 64] = acc[i][j];
+    return;
+  }
+  if (QH_CONV_ABLATE & 128) {  // no epilogue (the accumulators stay alive)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t != 1.2345e30f) return;
+  }
+  store_tile<DT, 1>(a, acc, m0, nt, wm, wn, lane);
+}
+
 // split-K tail: one WAVE per (output tile, wave slot of the tile kernel) adds that slot's eight fragments over the S partial tiles in split order
 // (deterministic), four splits' loads in flight together, and runs the epilogue.  (First form: one 512-thread workgroup per tile with one split per
 // loop iteration - 14 workgroups each waiting 12 times for a round trip cost more than the convolution itself.)
@@ -559,6 +816,8 @@ __global__ void __launch_bounds__(64) qconv2d_reduce_kernel(const Args a) {
 // K split: the tile kernel is bound by its gather per K-tile (~1.9 us per workgroup and K-tile whatever M is), so what matters is how many
 // workgroups run at once: split until the grid reaches ~2 workgroups per CU, keeping at least 4 K-tiles per split (r5, after the gather and the
 // epilogue got cheaper: profiles/r05_qconv2d_split_sweep.jsonl - 3 per split over-split 26-49-tile grids by 10-14 %).  1 = no split (and no workspace).
+static thread_local bool g_last_rows = false;  // the last launch of this thread took the row form (last_kernel() name, tests)
+
 static int pick_split(int64_t M, int64_t N, int64_t K) {
   const int forced = env_int("QUANTO_HIP_CONV_SPLIT", 0);  // experiments
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nk = (K + BK - 1) / BK;
@@ -582,10 +841,29 @@ template <int DT, int FMT, bool INT_SHIFT, bool WIDE>
 static int launch_w(Args a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   constexpr int PL = planes_of(FMT);
   const int ntiles = PL > 1 ? (a.N / PL + BN / PL - 1) / (BN / PL) : (a.N + BN - 1) / BN, mtiles = (a.M + BM - 1) / BM;
+  g_last_rows = false;
   int S = pick_split(a.M, a.N, a.K);
   if (S > 1 && (!workspace || workspace_bytes < split_workspace(a.M, a.N, S) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
   a.S = S;
   a.partials = reinterpret_cast<float*>(workspace);
+  if constexpr (PL == 1 && !WIDE) {
+    // row form: three taps wide, stride 1 / dilation 1 along the width, even OW (QUANTO_HIP_CONV_ROWS=0: the tap gather, 2: global loads - experiments)
+    const int rows_mode = env_int("QUANTO_HIP_CONV_ROWS", 1);
+    if (rows_mode != 0 && a.KW == 3 && a.sw == 1 && a.dw == 1 && a.OW % 2 == 0 && a.W >= 4 && a.KH <= 31 && (a.cin * a.KH) % 8 == 0) {
+      g_last_rows = true;
+      const int nk_rows = (a.cin * a.KH + rows::RT - 1) / rows::RT;
+      a.S = S < nk_rows ? S : nk_rows;
+      if (rows_mode == 2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
+        hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, false>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
+      } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
+        hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, true>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
+      }
+      if (a.S > 1) hipLaunchKernelGGL((qconv2d_reduce_kernel<DT, PL>), dim3(ntiles, mtiles, 8), dim3(64), 0, stream, a);
+      return launch_status();
+    }
+  }
   // two output pixels per load wherever the geometry allows it (QUANTO_HIP_CONV_PAIR=0: experiments)
   const bool pair = a.sw == 1 && a.OW % 2 == 0 && a.W >= 2 && env_int("QUANTO_HIP_CONV_PAIR", 1) != 0;
   if (pair)
@@ -610,6 +888,8 @@ static bool geometry_ok(int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC
 
 }  // namespace conv
 
+bool conv2d_last_was_rows() { return conv::g_last_rows; }
+
 bool qbytes_conv2d_supported(int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int a_dtype,
                              int b_dtype, int out_dtype) {
   const bool bd = b_dtype == QUANTO_HIP_I8 || b_dtype == QUANTO_HIP_F8_E4M3FN || b_dtype == QUANTO_HIP_F8_E5M2;
@@ -624,7 +904,7 @@ int qbytes_conv2d_mfma(const void* x, const void* w, const void* s, const void* 
                        int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbytes_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
   const conv::Args a{x, reinterpret_cast<const uint8_t*>(w), s, nullptr, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), 0, 0,
-                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr, conv::div_magic((int)(KH * KW)), conv::div_magic((int)KW)};
+                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr, conv::div_magic((int)(KH * KW)), conv::div_magic((int)KW), conv::div_magic((int)KH)};
   using namespace conv;
 #define QH_CASE(DT, FMT) return launch<DT, FMT, false>(a, workspace, workspace_bytes, stream)
   if (out_dtype == QUANTO_HIP_BF16) {
@@ -652,7 +932,7 @@ int qbits_conv2d_mfma(const void* x, const uint8_t* packed, const void* scale, c
                       const PackedGeom& g, int dtype, bool int_shift, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbits_conv2d_supported(B, cin, H, W, OC, KH, KW, OH, OW, g, dtype)) return QUANTO_HIP_ENOTSUP;
   const conv::Args a{x, packed, scale, shift, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), (int)g.C, (int)g.G,
-                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr, conv::div_magic((int)(KH * KW)), conv::div_magic((int)KW)};
+                     (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr, conv::div_magic((int)(KH * KW)), conv::div_magic((int)KW), conv::div_magic((int)KH)};
   using namespace conv;
 #define QH_CASE(DT, FMT) return int_shift ? launch<DT, FMT, true>(a, workspace, workspace_bytes, stream) : launch<DT, FMT, false>(a, workspace, workspace_bytes, stream)
   if (g.bits == 4) {

@@ -6,7 +6,8 @@
 #include "../../optimum_quanto_amd/csrc/qconv_mfma.hip"
 namespace qh { int launch_status() { return hipGetLastError() == hipSuccess ? 0 : -3; } }
 int main() {
-  struct Shape { int B, C, H, OC; } shapes[] = {{8, 128, 56, 128}, {8, 256, 56, 256}, {8, 128, 28, 128}};
+  struct Shape { int B, C, H, OC; } shapes[] = {{8, 128, 56, 128}, {8, 256, 56, 256}, {8, 128, 28, 128},
+                                               {8, 32, 56, 128}, {8, 64, 56, 128}, {8, 256, 56, 128}, {8, 512, 56, 128}};  // (K scaling: run with QUANTO_HIP_CONV_SPLIT=1)
   for (const Shape& s : shapes) {
     const int K = s.C * 9, OH = s.H, OW = s.H;
     std::vector<uint16_t> hx((size_t)s.B * s.C * s.H * s.H);

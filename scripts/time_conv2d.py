@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import optimum_quanto_amd as Q  # noqa: E402
 from auto_vs_best import _time_graph  # noqa: E402
+from optimum_quanto_amd.library.hip import quanto_hip  # noqa: E402
 from optimum_quanto_amd.tensor.weights import conv2d_as_gemm  # noqa: E402
 
 WEIGHTS = sys.argv[1] if len(sys.argv) > 1 else "qint8"
@@ -48,7 +49,8 @@ for (B, C, H, OC, k, s, p) in SHAPES:
         with torch.no_grad():
             t_dir = _time_graph(direct, 5)
         print(json.dumps({"weights": WEIGHTS, "B": B, "C": C, "H": H, "OC": OC, "k": k, "stride": s, "K": C * k * k, "conv_kernel_direct_us": round(t_dir, 1),
-                          "pair": os.environ.get("QUANTO_HIP_CONV_PAIR", "auto"), "split": os.environ.get("QUANTO_HIP_CONV_SPLIT", "auto")}), flush=True)
+                          "pair": os.environ.get("QUANTO_HIP_CONV_PAIR", "auto"), "split": os.environ.get("QUANTO_HIP_CONV_SPLIT", "auto"),
+                          "rows": os.environ.get("QUANTO_HIP_CONV_ROWS", "auto"), "kernel": quanto_hip.lib.last_kernel()}), flush=True)
         continue
     with torch.no_grad():
         t_dir = _time_graph(direct, 5)

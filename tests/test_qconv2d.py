@@ -50,6 +50,21 @@ def _check_inner_tensors(golden, key, tag, qw):
     np.testing.assert_array_equal(to_numpy(qw.dequantize()), golden[key + "/wdq"])
 
 
+def _row_form(cin, k, s, d, w_in, p, wq="qint8"):
+    """True where the 8-bit convolution takes the ROW form (r5): three taps wide, stride 1 / dilation 1 along the width, even OW, W >= 4, KH <= 31,
+    cin KH a multiple of 8 (csrc/qconv_mfma.hip::launch_w)."""
+    kh, kw = (k, k) if isinstance(k, int) else k
+    sw = s if isinstance(s, int) else s[1]
+    dw = d if isinstance(d, int) else d[1]
+    pw = p if isinstance(p, int) else p[1]
+    ow = (w_in + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    return wq in ("qint8", "qfloat8_e4m3fn", "qfloat8_e5m2") and kw == 3 and sw == 1 and dw == 1 and ow % 2 == 0 and w_in >= 4 and kh <= 31 and (cin * kh) % 8 == 0
+
+
+def _conv_kernel_name(cin, k, s, d, w_in, p, wq="qint8"):
+    return {"qint4": "conv2d_mfma_int4", "qint2": "conv2d_mfma_int2"}.get(wq, "conv2d_mfma_rows" if _row_form(cin, k, s, d, w_in, p, wq) else "conv2d_mfma")
+
+
 def _oracle_dequantized(w, dt):
     """The dense weight the reference would materialise for the packed int4 weight ``w`` - computed by the numpy oracle on the HOST from the
     packed bytes, scale and shift, so that the convolution gate does not lean on this library's own device dequantize kernel."""
@@ -144,7 +159,7 @@ def test_qconv2d_fused_gemm_gpu(golden, tag, cname, dt):
     with torch.no_grad():
         y = q(x)
     kernel = quanto_hip.lib.last_kernel()
-    assert kernel in ("gemv", "skinny", "mfma", "mfma_large", "dequant_mfma", "naive", "conv2d_mfma", "conv2d_mfma_int4"), kernel
+    assert kernel in ("gemv", "skinny", "mfma", "mfma_large", "dequant_mfma", "naive", "conv2d_mfma", "conv2d_mfma_rows", "conv2d_mfma_int4"), kernel
     assert y.is_cuda and y.dtype == TORCH_DT[dt] and tuple(y.shape) == golden[key + "/y"].shape
     # exact math on the reference's integers: float64 convolution, product rounded, bias added, rounded again
     cin, cout, ksz, stride, pad = CONVS[cname]
@@ -190,7 +205,7 @@ def test_qconv2d_implicit_gemm_gpu(dt, wq, cin, cout, k, s, p, d):
     x = torch.randn(3, cin, 13, 11).to(TORCH_DT[dt])
     with torch.no_grad():
         y = q(x.cuda())
-        assert quanto_hip.lib.last_kernel() == "conv2d_mfma"
+        assert quanto_hip.lib.last_kernel() == _conv_kernel_name(cin, k, s, d, 11, p, wq)
         w64 = q.weight._data.cpu().double() if wq == "qint8" else q.weight._data.cpu().float().double()
         prod = torch.nn.functional.conv2d(x.double(), w64, None, conv.stride, conv.padding, conv.dilation)
         prod = prod * q.weight._scale.cpu().double().reshape(1, -1, 1, 1)
@@ -380,6 +395,7 @@ def test_qconv2d_pair_gather_gpu(monkeypatch, dt, wq, cin, cout, k, s, p, d, hw)
     q = q.cuda()
     x = torch.randn(3, cin, *hw).to(TORCH_DT[dt])
     sub = wq in ("qint4", "qint2")
+    monkeypatch.setenv("QUANTO_HIP_CONV_ROWS", "0")  # the tap gather's two forms (three-tap windows otherwise take the row form)
     with torch.no_grad():
         y = q(x.cuda())
         assert quanto_hip.lib.last_kernel() == {"qint4": "conv2d_mfma_int4", "qint2": "conv2d_mfma_int2"}.get(wq, "conv2d_mfma")
@@ -395,6 +411,110 @@ def test_qconv2d_pair_gather_gpu(monkeypatch, dt, wq, cin, cout, k, s, p, d, hw)
     assert torch.equal(y, y1), f"pair gather differs from the one-pixel gather: {(y != y1).sum().item()} of {y.numel()} elements"
     bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
     assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), dt, f"pair gather {wq} {cin}->{cout} k{k}")
+
+
+@pytest.mark.parametrize("case", range(7))
+def test_conv_row_form_model(case):
+    """CPU model of the row form (scripts/models/conv_rows_model.py): clamped 8-byte windows, selectors, scalar row arithmetic, the 4 x 4 v_perm
+    transposition, the LDS image and the fragment reads, the weight bytes' regrouping, the K split - index for index against a direct convolution
+    in exact integer arithmetic; and the LDS bank model (conflict-free fragment reads, two-way staging stores)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("conv_rows_model", os.path.join(ROOT, "scripts", "models", "conv_rows_model.py"))
+    model = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(model)
+    assert model.run_case(model.CASES[case], seed=case)
+    if case == 0:
+        assert model.lds_bank_model() == (1, 2, 2)
+
+
+ROW_FORM_GEOMETRIES = [(64, 96, 3, 1, 1, 1, (13, 12)),              # "same": both borders of every row, ragged M (3 x 13 x 12 pixels)
+                       (64, 40, 3, (2, 1), (0, 2), 1, (9, 10)),        # two columns of padding (windows with two elements outside), stride 2 down
+                       (32, 48, (5, 3), 1, (2, 1), (2, 1), (12, 8)),   # five tap rows, dilation 2 along the height
+                       (16, 24, 3, 1, 0, 1, (6, 6)),                  # "valid": no padding at all, OW = 4
+                       (8, 40, (1, 3), 1, (0, 1), 1, (5, 4)),          # 1 x 3 window, W = 4: the clamped window is the whole row
+                       (24, 136, 3, 1, 1, 1, (9, 10)),                # 72 window rows: a ragged last K-tile; two channel tiles, the second ragged
+                       (128, 128, 3, 1, 1, 1, (28, 28))]              # a ResNet layer: 12 K-tiles, 19 pixel tiles
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("wq", ["qint8", "qfloat8_e4m3fn", "qfloat8_e5m2"])
+@pytest.mark.parametrize("cin,cout,k,s,p,d,hw", ROW_FORM_GEOMETRIES)
+@pytest.mark.parametrize("loads", ["buffer", "global"])
+def test_qconv2d_row_form_gpu(monkeypatch, loads, dt, wq, cin, cout, k, s, p, d, hw):
+    """r5: windows three taps wide at stride 1 along the width take the ROW form - one 8-byte range-checked load per (pixel pair, window row),
+    K ordered [tap][row] inside a tile.  Gate: the float64 convolution on the stored integers / fp8 values (with and without bias); the variant
+    with plain global loads (QUANTO_HIP_CONV_ROWS=2) stages the same operands, so it must agree bit for bit."""
+    torch.manual_seed(cin * 5 + cout)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, dilation=d).to(TORCH_DT[dt])
+    q = Q.QConv2d.from_module(conv, weights=getattr(Q, wq))
+    Q.freeze(q)
+    q = q.cuda()
+    x = torch.randn(3, cin, *hw).to(TORCH_DT[dt])
+    assert _row_form(cin, k, s, d, hw[1], p, wq)
+    with torch.no_grad():
+        y2 = q(x.cuda())  # the product's form: range-checked buffer loads
+        assert quanto_hip.lib.last_kernel() == "conv2d_mfma_rows"
+        if loads == "global":
+            monkeypatch.setenv("QUANTO_HIP_CONV_ROWS", "2")
+        y = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == "conv2d_mfma_rows"
+        w64 = q.weight._data.cpu().double() if wq == "qint8" else q.weight._data.cpu().float().double()
+        prod = torch.nn.functional.conv2d(x.double(), w64, None, conv.stride, conv.padding, conv.dilation) * q.weight._scale.cpu().double().reshape(1, -1, 1, 1)
+    assert y.shape == prod.shape and y.dtype == TORCH_DT[dt] and torch.isfinite(y.float()).all()
+    bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
+    assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), dt, f"row form {wq} {cin}->{cout} k{k}")
+    if loads == "global":
+        assert torch.equal(y, y2), f"buffer-load and global-load variants differ: {(y != y2).sum().item()} of {y.numel()} elements"
+    q.bias = None
+    with torch.no_grad():
+        y0 = q(x.cuda())
+    assert_close_to_exact(to_numpy(y0), prod.numpy(), dt, f"row form {wq} {cin}->{cout} k{k}, no bias")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [1, 2, 5, 64])
+def test_qconv2d_row_form_k_split_gpu(monkeypatch, split):
+    """The row form under the K split (12 K-tiles of 32 window rows: 5 is ragged, 64 is clamped to 12) and against the tap gather on the same call."""
+    monkeypatch.setenv("QUANTO_HIP_CONV_SPLIT", str(split))
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(128, 200, 3, padding=1).to(torch.bfloat16)
+    q = Q.QConv2d.from_module(conv, weights=Q.qint8)
+    Q.freeze(q)
+    q = q.cuda()
+    x = torch.randn(2, 128, 17, 10).to(torch.bfloat16)
+    with torch.no_grad():
+        y = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == "conv2d_mfma_rows"
+        y_again = q(x.cuda())
+        monkeypatch.setenv("QUANTO_HIP_CONV_ROWS", "0")
+        y_taps = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == "conv2d_mfma"
+        prod = torch.nn.functional.conv2d(x.double(), q.weight._data.cpu().double(), None, 1, 1) * q.weight._scale.cpu().double().reshape(1, -1, 1, 1)
+    bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
+    assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), "bf16", f"row form, K split {split}")
+    assert torch.equal(y, y_again)  # (the reduce kernel adds in split order)
+    # two summation orders of the same exact products: at most an ulp apart after the rounding to bf16
+    diff = (y.float() - y_taps.float()).abs().cpu().double()
+    assert (diff <= 2.0 ** -7 * (prod.abs() + y_taps.cpu().double().abs()) + 1e-9).all()
+
+
+@pytest.mark.gpu
+def test_qconv2d_row_form_at_bench_size_gpu():
+    """(8, 128, 56, 56) -> 128, the size the timings are quoted on: whole-output float64 gate."""
+    torch.manual_seed(11)
+    conv = torch.nn.Conv2d(128, 128, 3, padding=1).to(torch.bfloat16)
+    q = Q.QConv2d.from_module(conv, weights=Q.qint8)
+    Q.freeze(q)
+    q = q.cuda()
+    x = torch.randn(8, 128, 56, 56).to(torch.bfloat16)
+    with torch.no_grad():
+        y = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == "conv2d_mfma_rows"
+        prod = torch.nn.functional.conv2d(x.double(), q.weight._data.cpu().double(), None, 1, 1) * q.weight._scale.cpu().double().reshape(1, -1, 1, 1)
+    bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
+    assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), "bf16", "row form (8,128,56,56)->128")
 
 
 @pytest.mark.gpu
