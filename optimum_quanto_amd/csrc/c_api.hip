@@ -35,6 +35,10 @@ int qbits_conv2d_mfma(const void*, const uint8_t*, const void*, const void*, con
                       int64_t, int64_t, int, int, int, int, int, int, const PackedGeom&, int, bool, void*, size_t, hipStream_t);
 size_t conv2d_workspace(int64_t, int64_t, int64_t);
 bool conv2d_last_was_rows();
+size_t conv2d_dense_weight_bytes(int64_t, int64_t);
+bool conv2d_rows_eligible(int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int64_t);
+int qdense_conv2d_rows(const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int,
+                       int, int, int, int, int, void*, size_t, hipStream_t);
 int qbytes_conv2d_mfma(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
                        int64_t, int, int, int, int, int, int, int, int, int, void*, size_t, hipStream_t);
 int qbytes_mm_gemv_multi(const void*, int, const void* const*, const void* const*, const void* const*, void* const*, const int64_t*, int64_t,
@@ -608,6 +612,13 @@ int64_t quanto_hip_conv2d_workspace_size(int64_t B, int64_t OH, int64_t OW, int6
   return (int64_t)conv2d_workspace(B * OH * OW, OC, K);
 }
 
+int64_t quanto_hip_qbits_conv2d_workspace_size(int64_t B, int64_t OH, int64_t OW, int64_t OC, int64_t K) {
+  const int64_t split = quanto_hip_conv2d_workspace_size(B, OH, OW, OC, K);
+  if (split < 0) return split;
+  if (B == 0 || OH == 0 || OW == 0) return 0;
+  return split + (int64_t)conv2d_dense_weight_bytes(OC, K);
+}
+
 int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, const void* bias, void* y, int64_t B, int64_t cin, int64_t H,
                              int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,
                              int pad_w, int dil_h, int dil_w, int a_dtype, int b_dtype, int out_dtype, void* workspace, size_t workspace_bytes,
@@ -638,6 +649,21 @@ int quanto_hip_qbits_conv2d(const void* x, const uint8_t* packed, const void* sc
   if (B == 0 || OH == 0 || OW == 0) return QUANTO_HIP_OK;
   if (!x || !packed || !scale || !shift || !y) return QUANTO_HIP_EINVAL;
   const PackedGeom g = make_geom(OC, K, bits, group_size);
+  hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  const size_t dense = conv2d_dense_weight_bytes(OC, K);
+  if (conv2d_rows_eligible(cin, KH, KW, W, OW, stride_w, dil_w, OC) && workspace && workspace_bytes >= dense && reinterpret_cast<uintptr_t>(workspace) % 16 == 0 &&
+      is_float_dtype(dtype) && dtype != QUANTO_HIP_F32) {
+    // three-tap-wide windows at stride 1: dequantize once (the reference's own dense weight), then the row form of the convolution on it
+    int r = dequantize_qbits_dispatch(packed, scale, shift, workspace, g, dtype, int_shift, hs);
+    if (r == QUANTO_HIP_OK)
+      r = qdense_conv2d_rows(x, workspace, bias, y, B, cin, H, W, OC, KH, KW, OH, OW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, dtype,
+                             reinterpret_cast<uint8_t*>(workspace) + dense, workspace_bytes - dense, hs);
+    if (r == QUANTO_HIP_OK) {
+      set_last_kernel(bits == 4 ? "conv2d_rows_dequant_int4" : "conv2d_rows_dequant_int2");
+      return r;
+    }
+    if (r != QUANTO_HIP_ENOTSUP) return r;
+  }
   const int r = qbits_conv2d_mfma(x, packed, scale, shift, bias, y, B, cin, H, W, OC, KH, KW, OH, OW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, g, dtype,
                                   int_shift, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
   if (r == QUANTO_HIP_OK) set_last_kernel(bits == 4 ? "conv2d_mfma_int4" : "conv2d_mfma_int2");

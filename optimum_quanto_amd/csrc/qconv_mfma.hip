@@ -33,7 +33,7 @@
 
 #ifndef QH_CONV_ABLATE
 #define QH_CONV_ABLATE 0  // timing experiments only (scripts/probes/conv_ablate.hip; WRONG results): 1 no gather loads, 2 no MFMAs / fragment reads, 4 no weight
-#endif                      // loads, 8 no gather address arithmetic either, 16 no staging writes, 32 no tap-table fill, 64 (row form) no weight conversion, 128 (row form) no epilogue
+#endif                      // loads, 8 no gather address arithmetic either, 16 no staging writes, 32 no tap-table fill, 64 (row form) no weight conversion, 128 (row form) no epilogue, 256 / 512 (row form) gather windows 4-byte aligned / one dword per lane
 
 
 namespace qh {
@@ -43,7 +43,7 @@ constexpr int BM = 128, BN = 128, BK = 64, NT = 512;
 constexpr int TILE_BYTES = BM * BK * 2;  // one operand tile in LDS (16 KiB)
 constexpr int LDS_BYTES = 2 * 2 * TILE_BYTES + 2 * BK * 8;
 
-enum WFmt { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2, W_I4R = 3, W_I2R = 4 };
+enum WFmt { W_I8 = 0, W_F8E4M3 = 1, W_F8E5M2 = 2, W_I4R = 3, W_I2R = 4, W_DENSE16 = 5 };  // W_DENSE16 (row form only): a weight already in the activation dtype
 constexpr int planes_of(int fmt) { return fmt == W_I4R ? 2 : (fmt == W_I2R ? 4 : 1); }  // values per packed byte
 
 // byte-aligned 8- and 16-byte loads (K = cin KH KW need not be a multiple of anything: an RGB stem has K = 27 or 147): hipcc lowers them to
@@ -233,7 +233,7 @@ __device__ __forceinline__ void store_tile(const Args& a, const f32x4 (&acc)[4][
     }
     if (n < 0) continue;
     float sc = 1.f;
-    if constexpr (PL == 1) sc = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
+    if (PL == 1 && a.scale != nullptr) sc = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);  // (no scale: a dense weight)
     const bool has_bias = a.bias != nullptr;
     const float bv = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
 #pragma unroll
@@ -266,6 +266,74 @@ __device__ __forceinline__ void store_tile(const Args& a, const f32x4 (&acc)[4][
     }
   }
 }
+
+// The same epilogue through LDS (r5): store_tile's lanes hold four pixels of ONE channel each - a wave's store touches 16 channel planes with 32
+// bytes apiece.  Here the tile is first laid out [channel][pixel] in LDS (rows of 272 bytes), then 16 neighbouring lanes store the 256 contiguous
+// bytes a channel plane gets from this tile: four full lines per wave-store.  Needs planes of a multiple of 8 pixels (a thread's 8 pixels lie in one
+// image, 16-byte aligned) and a 16-byte aligned y; values identical to store_tile's.  All 512 threads; `stage` >= 34816 bytes, free to overwrite.
+constexpr int EPI_ROW = 272;
+template <int DT, int PL>
+__device__ __forceinline__ void store_tile_lds(const Args& a, const f32x4 (&acc)[4][2], int m0, int nt, int wm, int wn, int lane, int tid, uint8_t* stage) {
+  using E = Elem<DT>;
+  using T = typename E::T;
+  const int M = a.M, N = a.N, P = N / (PL > 1 ? PL : 2), L = a.OH * a.OW;
+  auto channel_of = [&](int tc) -> int {  // tile column -> output channel (-1: none)
+    if constexpr (PL > 1) {
+      constexpr int RPT = BN / PL;
+      const int p = nt * RPT + (tc % RPT);
+      return p < P ? p + (tc / RPT) * P : -1;
+    } else {
+      const int n = nt * BN + tc;
+      return n < N ? n : -1;
+    }
+  };
+  __syncthreads();  // the K loop's last fragment reads
+  const bool has_bias = a.bias != nullptr;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int tc = wn * 32 + j * 16 + (lane & 15);
+    const int n = channel_of(tc);
+    float sc = 1.f, bv = 0.f;
+    if (n >= 0) {
+      if (PL == 1 && a.scale != nullptr) sc = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
+      if (has_bias) bv = E::to_f32(reinterpret_cast<const T*>(a.bias)[n]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      T out[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] * sc;
+        asm volatile("" : "+v"(v));  // (store_tile: the product rounded to fp32 first)
+        if (has_bias) v = E::to_f32(E::from_f32(v)) + bv;
+        out[r] = E::from_f32(v);
+      }
+      *reinterpret_cast<uint2*>(stage + tc * EPI_ROW + (wm * 64 + i * 16 + (lane >> 4) * 4) * 2) = *reinterpret_cast<const uint2*>(out);
+    }
+  }
+  __syncthreads();
+  // thread -> 8 pixels (piece tid & 15) of channel pass * 32 + (tid >> 4)
+  const int m = m0 + (tid & 15) * 8;
+  if (m >= M) return;
+  const int b = m / L, l = m - b * L;
+  T* yg = reinterpret_cast<T*>(a.y);
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int tc = pass * 32 + (tid >> 4);
+    const int n = channel_of(tc);
+    if (n < 0) continue;
+    const uint4 v = *reinterpret_cast<const uint4*>(stage + tc * EPI_ROW + (tid & 15) * 16);
+    T* dst = yg + ((size_t)b * N + n) * L + l;
+    if (m + 7 < M) {
+      *reinterpret_cast<uint4*>(dst) = v;
+    } else {  // (M is a multiple of L, L of 8: never taken; kept for safety)
+      const T* e = reinterpret_cast<const T*>(&v);
+      for (int r = 0; r < 8; ++r)
+        if (m + r < M) dst[r] = e[r];
+    }
+  }
+}
+__device__ __forceinline__ bool epilogue_through_lds(const Args& a) { return ((a.OH * a.OW) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0; }
 
 // WIDE: windows of 32 .. 127 taps (two 64-bit mask words); the narrow form keeps bit 31 (WIDE: bit 127) of the mask free as the "no such k" tap of
 // a ragged last K-tile.
@@ -535,7 +603,10 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
       for (int j = 0; j < 2; ++j) mine[(i * 2 + j) * 64] = acc[i][j];
     return;
   }
-  store_tile<DT, PL>(a, acc, m0, nt, wm, wn, lane);
+  if (epilogue_through_lds(a))
+    store_tile_lds<DT, PL>(a, acc, m0, nt, wm, wn, lane, tid, smem);
+  else
+    store_tile<DT, PL>(a, acc, m0, nt, wm, wn, lane);
 }
 
 // ---- ROW form (r5): windows three taps wide, stride 1 and dilation 1 along the width, even OW ---------------------------------------------------
@@ -605,7 +676,8 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
   const uint8_t* xb = reinterpret_cast<const uint8_t*>(a.x);
   const __amdgpu_buffer_rsrc_t xrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)(((long)M / (a.OH * a.OW)) * a.cin * a.H * a.W * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.w), 0, N * K, 0x00020000);
+  constexpr int WB = FMT == W_DENSE16 ? 2 : 1;  // bytes per weight
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.w), 0, N * K * WB, 0x00020000);
 
   // ---- the lane's pixel pair (the same in every wave) ------------------------------------------------------------------------------------------
   int px_base;            // byte offset of element (b, 0, oh sh - ph, ws): the window's first row, clamped first column
@@ -644,18 +716,25 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
   // ---- weights: channel tid >> 2, bytes 24 (tid & 3) .. + 23 of the K-tile's 96 ---------------------------------------------------------------------
   int wn_row = nt * BN + (tid >> 2);
   wn_row = wn_row < N ? wn_row : N - 1;
-  const uint32_t woff = (uint32_t)(wn_row * K + 24 * (tid & 3));
+  const uint32_t woff = (uint32_t)(wn_row * K + 24 * (tid & 3)) * WB;
   const int wk = 24 * (tid & 3);
 
   u32x2 D[4], wq[3];  // gathered windows / weight bytes of the K-tile in flight
+  uint4 wd[3];        // (dense weight: its 24 elements)
   uint4 cw[3];        // its converted weights, one 16-byte piece per tap block
   auto issue = [&](int t) {
     const int T = kt_lo + t;
     const int krem = K - T * BKR;  // bytes of this tile inside the weight row (>= 96 except in a ragged last tile)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const uint32_t off = wk + 8 * j < krem ? woff + (uint32_t)(T * BKR + 8 * j) : 0xFFFFFFFFu;
-      wq[j] = (QH_CONV_ABLATE & 4) ? u32x2{off, off} : __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, (int)off, 0, 0));
+      const uint32_t off = wk + 8 * j < krem ? woff + (uint32_t)(T * BKR + 8 * j) * WB : 0xFFFFFFFFu;
+      if constexpr (FMT == W_DENSE16) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (int)off, 0, 0));
+        wd[j] = make_uint4(v.x, v.y, v.z, v.w);
+      } else {
+        wq[j] = (QH_CONV_ABLATE & 4) ? u32x2{off, off} : __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(wrsrc, (int)off, 0, 0));
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -668,7 +747,14 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
       constexpr uint32_t gone = 0u;
       if constexpr (BUF) {
         const uint32_t addr = ((uint32_t)px_base + roff) | pad | gone;
-        D[u] = (QH_CONV_ABLATE & 1) ? u32x2{addr, addr} : __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)addr, 0, 0));
+        if (QH_CONV_ABLATE & 1)
+          D[u] = u32x2{addr, addr};
+        else if (QH_CONV_ABLATE & 256)  // 4-byte aligned windows (wrong elements, same lines)
+          D[u] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)(addr & ~3u), 0, 0));
+        else if (QH_CONV_ABLATE & 512)  // one dword per lane
+          D[u] = u32x2{(uint32_t)__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)(addr & ~3u), 0, 0), addr};
+        else
+          D[u] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, (int)addr, 0, 0));
       } else {  // global loads (experiments): element 0 for a row that is not there, zeroed afterwards
         const uint32_t keep = ~(pad | gone);
         const U2u v = *reinterpret_cast<const U2u*>(xb + (((uint32_t)px_base + roff) & keep));
@@ -678,6 +764,18 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
   };
   // 24 weight bytes in (row, tap) order -> per tap block j the eight rows' values, in the activation dtype (exact)
   auto convert = [&](int j) {
+    if constexpr (FMT == W_DENSE16) {  // 24 sixteen-bit elements in (row, tap) order: element 3 rl + j of each of the eight rows, two per v_perm
+      const uint32_t in[12] = {wd[0].x, wd[0].y, wd[0].z, wd[0].w, wd[1].x, wd[1].y, wd[1].z, wd[1].w, wd[2].x, wd[2].y, wd[2].z, wd[2].w};
+      uint32_t o[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int e0 = 3 * (2 * h) + j, e1 = 3 * (2 * h + 1) + j;
+        const uint32_t sel = ((e0 & 1) ? 0x0302u : 0x0100u) | ((e1 & 1) ? 0x07060000u : 0x05040000u);
+        o[h] = __builtin_amdgcn_perm(in[e1 >> 1], in[e0 >> 1], sel);
+      }
+      cw[j] = make_uint4(o[0], o[1], o[2], o[3]);
+      return;
+    }
     const uint32_t in[6] = {wq[0].x, wq[0].y, wq[1].x, wq[1].y, wq[2].x, wq[2].y};
     if (QH_CONV_ABLATE & 64) {
       cw[j] = make_uint4(in[j], in[j + 1], in[j + 2], in[j + 3]);
@@ -729,17 +827,28 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mma_step = [&](int kk) {
+  // the MFMA phase, scheduled by hand (hipcc left to itself sinks the loads of the next tile behind the MFMAs or hoists the weight conversion -
+  // and its vmcnt wait - in front of them): the fragments of k-step kk + 1 are read while the MFMAs of k-step kk run, fences between the steps
+  V8 fa[2][4], fb[2][2];
+  auto read_frags = [&](int kk) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[kk & 1][i] = *reinterpret_cast<const V8*>(smem + ard + i * 16 * RS + kk * 64);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[kk & 1][j] = *reinterpret_cast<const V8*>(smem + brd + j * 16 * RS + kk * 64);
+  };
+  auto mma_phase = [&]() {
     if (QH_CONV_ABLATE & 2) return;
-    V8 fa[4], fb[2];
+    read_frags(0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const V8*>(smem + ard + i * 16 * RS + kk * 64);
+    for (int kk = 0; kk < 3; ++kk) {
+      if (kk < 2) read_frags(kk + 1);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const V8*>(smem + brd + j * 16 * RS + kk * 64);
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = Mma<DT>::run(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mma<DT>::run(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
 
   issue(0);
@@ -748,18 +857,19 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
   write();
   __syncthreads();
   for (int t = 0; t + 1 < nk; ++t) {
+    // the next tile's loads first; its weights are converted AFTER the MFMAs (a conversion between them puts a vmcnt wait on loads issued a
+    // moment ago in front of the MFMAs: in the first form of this loop every load's address-unit time showed up in the tile time)
     issue(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_phase();
 #pragma unroll
-    for (int kk = 0; kk < 3; ++kk) {  // the next tile's weights are converted in the shadow of this tile's MFMAs
-      mma_step(kk);
-      convert(kk);
-    }
+    for (int j = 0; j < 3; ++j) convert(j);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // every wave has read tile t
     write();
     __syncthreads();
   }
-#pragma unroll
-  for (int kk = 0; kk < 3; ++kk) mma_step(kk);
+  mma_phase();
 
   if (S > 1) {
     f32x4* mine = reinterpret_cast<f32x4*>(a.partials) + ((size_t)(sp * gridDim.y + blockIdx.y) * gridDim.x + nt) * (8 * 8 * 64) + (wave * 8) * 64 + lane;
@@ -777,7 +887,10 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
       for (int j = 0; j < 2; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (t != 1.2345e30f) return;
   }
-  store_tile<DT, 1>(a, acc, m0, nt, wm, wn, lane);
+  if (epilogue_through_lds(a))
+    store_tile_lds<DT, 1>(a, acc, m0, nt, wm, wn, lane, tid, smem);
+  else
+    store_tile<DT, 1>(a, acc, m0, nt, wm, wn, lane);
 }
 
 // split-K tail: one WAVE per (output tile, wave slot of the tile kernel) adds that slot's eight fragments over the S partial tiles in split order
@@ -832,6 +945,26 @@ static int pick_split(int64_t M, int64_t N, int64_t K) {
 }
 static size_t split_workspace(int64_t M, int64_t N, int S) { return S <= 1 ? 0 : (size_t)S * ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (BM * BN * 4); }
 
+// row form: three taps wide, stride 1 / dilation 1 along the width, even OW (QUANTO_HIP_CONV_ROWS=0: the tap gather, 2: global loads - experiments)
+static bool rows_eligible(int64_t cin, int64_t KH, int64_t KW, int64_t W, int64_t OW, int sw, int dw) {
+  return env_int("QUANTO_HIP_CONV_ROWS", 1) != 0 && KW == 3 && sw == 1 && dw == 1 && OW % 2 == 0 && W >= 4 && KH <= 31 && (cin * KH) % 8 == 0;
+}
+template <int DT, int FMT>
+static int launch_rows(Args a, int ntiles, int mtiles, hipStream_t stream) {  // a.S: the split the workspace allows; a.partials set
+  g_last_rows = true;
+  const int nk_rows = (a.cin * a.KH + rows::RT - 1) / rows::RT;
+  a.S = a.S < nk_rows ? a.S : nk_rows;
+  if (env_int("QUANTO_HIP_CONV_ROWS", 1) == 2) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
+    hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, false>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
+    hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, true>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
+  }
+  if (a.S > 1) hipLaunchKernelGGL((qconv2d_reduce_kernel<DT, 1>), dim3(ntiles, mtiles, 8), dim3(64), 0, stream, a);
+  return launch_status();
+}
+
 template <int DT, int FMT, bool INT_SHIFT, bool WIDE, bool PAIR>
 static void launch_k(const Args& a, int ntiles, int mtiles, hipStream_t stream) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_mfma_kernel<DT, FMT, INT_SHIFT, WIDE, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -847,21 +980,9 @@ static int launch_w(Args a, void* workspace, size_t workspace_bytes, hipStream_t
   a.S = S;
   a.partials = reinterpret_cast<float*>(workspace);
   if constexpr (PL == 1 && !WIDE) {
-    // row form: three taps wide, stride 1 / dilation 1 along the width, even OW (QUANTO_HIP_CONV_ROWS=0: the tap gather, 2: global loads - experiments)
-    const int rows_mode = env_int("QUANTO_HIP_CONV_ROWS", 1);
-    if (rows_mode != 0 && a.KW == 3 && a.sw == 1 && a.dw == 1 && a.OW % 2 == 0 && a.W >= 4 && a.KH <= 31 && (a.cin * a.KH) % 8 == 0) {
-      g_last_rows = true;
-      const int nk_rows = (a.cin * a.KH + rows::RT - 1) / rows::RT;
-      a.S = S < nk_rows ? S : nk_rows;
-      if (rows_mode == 2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
-        hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, false>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
-      } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
-        hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, true>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
-      }
-      if (a.S > 1) hipLaunchKernelGGL((qconv2d_reduce_kernel<DT, PL>), dim3(ntiles, mtiles, 8), dim3(64), 0, stream, a);
-      return launch_status();
+    if (rows_eligible(a.cin, a.KH, a.KW, a.W, a.OW, a.sw, a.dw)) {
+      a.S = S;
+      return launch_rows<DT, FMT>(a, ntiles, mtiles, stream);
     }
   }
   // two output pixels per load wherever the geometry allows it (QUANTO_HIP_CONV_PAIR=0: experiments)
@@ -898,6 +1019,31 @@ bool qbytes_conv2d_supported(int64_t B, int64_t cin, int64_t H, int64_t W, int64
 
 // scratch bytes the K split of a convolution wants (0: not split); the same for every weight format (128 x 128 tiles either way)
 size_t conv2d_workspace(int64_t M, int64_t N, int64_t K) { return conv::split_workspace(M, N, conv::pick_split(M, N, K)); }
+
+// int4 / int2 weights in the row form (r5): the weight is tiny next to the activations and every pixel tile would dequantize all of it again
+// (196 times for (8,128,56,56) -> 128: the sub-byte tap kernel spends a third of its time there) - so it is dequantized ONCE into the caller's
+// workspace by the fused dequantize_qbits kernel (bit-identical to the reference's dequantize()) and the row form multiplies by that dense weight:
+// what the reference does, as two launches, without im2col.  Workspace: [dense weight, 256-byte multiple | K-split partials].
+size_t conv2d_dense_weight_bytes(int64_t N, int64_t K) { return ((size_t)N * K * 2 + 255) / 256 * 256; }
+bool conv2d_rows_eligible(int64_t cin, int64_t KH, int64_t KW, int64_t W, int64_t OW, int sw, int dw, int64_t OC) {
+  return conv::rows_eligible(cin, KH, KW, W, OW, sw, dw) && KH * KW <= 31 && OC * cin * KH * KW < (1ll << 30);
+}
+int qdense_conv2d_rows(const void* x, const void* wdense, const void* bias, void* y, int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC, int64_t KH,
+                       int64_t KW, int64_t OH, int64_t OW, int sh, int sw, int ph, int pw, int dh, int dw, int dtype, void* workspace, size_t workspace_bytes,
+                       hipStream_t stream) {
+  if (!conv2d_rows_eligible(cin, KH, KW, W, OW, sw, dw, OC) || !conv::geometry_ok(B, cin, H, W, OC, KH, KW, OH, OW) ||
+      (dtype != QUANTO_HIP_BF16 && dtype != QUANTO_HIP_F16))
+    return QUANTO_HIP_ENOTSUP;
+  conv::Args a{x, reinterpret_cast<const uint8_t*>(wdense), nullptr, nullptr, bias, y, (int)(B * OH * OW), (int)OC, (int)(cin * KH * KW), 0, 0,
+               (int)cin, (int)H, (int)W, (int)KH, (int)KW, (int)OH, (int)OW, sh, sw, ph, pw, dh, dw, 1, nullptr, conv::div_magic((int)(KH * KW)), conv::div_magic((int)KW), conv::div_magic((int)KH)};
+  using namespace conv;
+  int S = pick_split(a.M, a.N, a.K);
+  if (S > 1 && (!workspace || workspace_bytes < split_workspace(a.M, a.N, S) || reinterpret_cast<uintptr_t>(workspace) % 16)) S = 1;
+  a.S = S;
+  a.partials = reinterpret_cast<float*>(workspace);
+  const int ntiles = (a.N + BN - 1) / BN, mtiles = (a.M + BM - 1) / BM;
+  return dtype == QUANTO_HIP_BF16 ? launch_rows<QUANTO_HIP_BF16, W_DENSE16>(a, ntiles, mtiles, stream) : launch_rows<QUANTO_HIP_F16, W_DENSE16>(a, ntiles, mtiles, stream);
+}
 
 int qbytes_conv2d_mfma(const void* x, const void* w, const void* s, const void* bias, void* y, int64_t B, int64_t cin, int64_t H, int64_t W, int64_t OC,
                        int64_t KH, int64_t KW, int64_t OH, int64_t OW, int sh, int sw, int ph, int pw, int dh, int dw, int a_dtype, int b_dtype,

@@ -142,6 +142,8 @@ class _Bindings:
         c.quanto_hip_qbytes_conv2d.argtypes = [vp, vp, vp, vp, vp] + [i64] * 9 + [ci] * 9 + [vp, ctypes.c_size_t, vp]
         c.quanto_hip_conv2d_workspace_size.restype = i64
         c.quanto_hip_conv2d_workspace_size.argtypes = [i64] * 5
+        c.quanto_hip_qbits_conv2d_workspace_size.restype = i64
+        c.quanto_hip_qbits_conv2d_workspace_size.argtypes = [i64] * 5
         c.quanto_hip_qbits_conv2d.restype = ci
         c.quanto_hip_qbits_conv2d.argtypes = [vp] * 6 + [i64] * 9 + [ci] * 10 + [vp, ctypes.c_size_t, vp]
         self._c = c
@@ -282,9 +284,11 @@ class _Bindings:
     def conv2d_out_size(size, k, stride, pad, dil):
         return (size + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
-    def _conv2d_scratch(self, x, B, OH, OW, OC, K):
-        """(buffer, bytes) for the convolution kernels' K split - plain scratch, nothing to zero; (None, 0) when the problem is not split."""
-        nbytes = int(self._c.quanto_hip_conv2d_workspace_size(B, max(OH, 0), max(OW, 0), OC, K))
+    def _conv2d_scratch(self, x, B, OH, OW, OC, K, qbits=False):
+        """(buffer, bytes) for the convolution kernels' K split (sub-byte weights: plus the dense weight of the row form) - plain scratch, nothing
+        to zero; (None, 0) when the problem needs none."""
+        size = self._c.quanto_hip_qbits_conv2d_workspace_size if qbits else self._c.quanto_hip_conv2d_workspace_size
+        nbytes = int(size(B, max(OH, 0), max(OW, 0), OC, K))
         if nbytes <= 0:
             return None, 0
         return self._scratch(x.device, nbytes, self._stream(x).value), nbytes
@@ -344,7 +348,8 @@ class _Bindings:
 
     def qbits_conv2d(self, x, packed, scale, shift, bias, bits: int, group_size, weight_size, stride, padding, dilation):
         """Dense convolution with a generic packed int4 weight (its [OC, C, KH, KW] shape in ``weight_size``): im2col inside the staging loads,
-        the weight dequantized there with the reference's roundings."""
+        the weight dequantized there with the reference's roundings (r5: three-tap-wide windows at stride 1 dequantize the weight once into the
+        scratch buffer and take the row form of the kernel on it)."""
         self._require_cuda(x, packed, scale, shift, bias)
         if x.dtype != scale.dtype:
             x = x.to(scale.dtype)
@@ -357,7 +362,7 @@ class _Bindings:
             bias = bias.to(x.dtype).contiguous()
         y = torch.empty((B, OC, max(OH, 0), max(OW, 0)), dtype=x.dtype, device=x.device)
         with torch.cuda.device(x.device):
-            ws, ws_bytes = self._conv2d_scratch(x, B, OH, OW, OC, C * KH * KW)
+            ws, ws_bytes = self._conv2d_scratch(x, B, OH, OW, OC, C * KH * KW, qbits=True)
             st = self._c.quanto_hip_qbits_conv2d(_ptr(x), _ptr(packed), _ptr(scale), _ptr(shift), _ptr(bias), _ptr(y), B, C, H, W, OC, KH, KW, OH, OW,
                                                  stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], bits, group_size or 0, _dt(x),
                                                  _dt(shift), _ptr(ws), ws_bytes, self._stream(x))

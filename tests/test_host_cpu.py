@@ -156,6 +156,13 @@ def test_conv2d_k_split_plan_without_a_gpu():
     assert f(8, 112, 112, 64, 147) == 0                        # an RGB 7x7 stem: 3 K-tiles, 784 tiles
     assert f(0, 28, 28, 128, 1152) == 0                        # empty batch
     assert f(-1, 28, 28, 128, 1152) == -1 and f(8, 28, 28, 0, 1152) == -1
+    # sub-byte weights (r5): the same partial tiles plus room for the dense 16-bit weight of the row form, a multiple of 256 bytes
+    g = quanto_hip.cdll.quanto_hip_qbits_conv2d_workspace_size
+    g.restype, g.argtypes = ctypes.c_int64, [ctypes.c_int64] * 5
+    assert g(8, 28, 28, 128, 1152) == 4 * 49 * tile + 128 * 1152 * 2
+    assert g(8, 56, 56, 64, 576) == 64 * 576 * 2
+    assert g(8, 15, 13, 44, 180) == f(8, 15, 13, 44, 180) + (44 * 180 * 2 + 255) // 256 * 256
+    assert g(0, 28, 28, 128, 1152) == 0 and g(-1, 28, 28, 128, 1152) == -1
 
 
 def test_multi_linear_plans_without_a_gpu():

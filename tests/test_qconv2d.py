@@ -58,11 +58,16 @@ def _row_form(cin, k, s, d, w_in, p, wq="qint8"):
     dw = d if isinstance(d, int) else d[1]
     pw = p if isinstance(p, int) else p[1]
     ow = (w_in + 2 * pw - dw * (kw - 1) - 1) // sw + 1
-    return wq in ("qint8", "qfloat8_e4m3fn", "qfloat8_e5m2") and kw == 3 and sw == 1 and dw == 1 and ow % 2 == 0 and w_in >= 4 and kh <= 31 and (cin * kh) % 8 == 0
+    return kw == 3 and sw == 1 and dw == 1 and ow % 2 == 0 and w_in >= 4 and kh * kw <= 31 and (cin * kh) % 8 == 0
 
 
 def _conv_kernel_name(cin, k, s, d, w_in, p, wq="qint8"):
-    return {"qint4": "conv2d_mfma_int4", "qint2": "conv2d_mfma_int2"}.get(wq, "conv2d_mfma_rows" if _row_form(cin, k, s, d, w_in, p, wq) else "conv2d_mfma")
+    """8-bit weights: the row form or the tap gather; int4 / int2: dequantize once + the row form on the dense weight, or the tap gather that
+    dequantizes while staging (csrc/c_api.hip: quanto_hip_qbits_conv2d)."""
+    rows = _row_form(cin, k, s, d, w_in, p, wq)
+    if wq in ("qint4", "qint2"):
+        return ("conv2d_rows_dequant_" if rows else "conv2d_mfma_") + wq[1:]
+    return "conv2d_mfma_rows" if rows else "conv2d_mfma"
 
 
 def _oracle_dequantized(w, dt):
@@ -159,14 +164,14 @@ def test_qconv2d_fused_gemm_gpu(golden, tag, cname, dt):
     with torch.no_grad():
         y = q(x)
     kernel = quanto_hip.lib.last_kernel()
-    assert kernel in ("gemv", "skinny", "mfma", "mfma_large", "dequant_mfma", "naive", "conv2d_mfma", "conv2d_mfma_rows", "conv2d_mfma_int4"), kernel
+    assert kernel in ("gemv", "skinny", "mfma", "mfma_large", "dequant_mfma", "naive", "conv2d_mfma", "conv2d_mfma_rows", "conv2d_mfma_int4", "conv2d_rows_dequant_int4"), kernel
     assert y.is_cuda and y.dtype == TORCH_DT[dt] and tuple(y.shape) == golden[key + "/y"].shape
     # exact math on the reference's integers: float64 convolution, product rounded, bias added, rounded again
     cin, cout, ksz, stride, pad = CONVS[cname]
     x64 = torch.from_numpy(golden[key + "/x"]).double()
     a64, _, _ = conv2d_patches(x64, (ksz, ksz), stride, pad, 1)
     a64 = a64.numpy()
-    if tag == "int4" and kernel not in ("dequant_mfma", "conv2d_mfma_int4"):
+    if tag == "int4" and kernel not in ("dequant_mfma", "conv2d_mfma_int4", "conv2d_rows_dequant_int4"):
         # the fused int4 kernels use q * scale - shift unrounded (exact math on the reference's integers and scales)
         gs = int(golden[key + "/group_size"])
         w64 = O.dequantize_qbits_exact(golden[key + "/wpacked"], 4, golden[key + "/wscale"], golden[key + "/wshift"], 0,
@@ -244,7 +249,7 @@ def test_qconv2d_int4_implicit_gemm_gpu(dt, zp, cin, cout, k, s, p, d, gs):
     x = torch.randn(3, cin, 13, 11).to(TORCH_DT[dt])
     with torch.no_grad():
         y = q(x.cuda())
-        assert quanto_hip.lib.last_kernel() == "conv2d_mfma_int4"
+        assert quanto_hip.lib.last_kernel() == _conv_kernel_name(cin, k, s, d, 11, p, "qint4")
         wdq = _oracle_dequantized(q.weight, dt)
         assert torch.equal(q.weight.dequantize().cpu().double(), wdq)  # (and the device dequantize kernel agrees with the oracle bit for bit)
         prod = torch.nn.functional.conv2d(x.double(), wdq, None, conv.stride, conv.padding, conv.dilation)
@@ -471,6 +476,43 @@ def test_qconv2d_row_form_gpu(monkeypatch, loads, dt, wq, cin, cout, k, s, p, d,
     with torch.no_grad():
         y0 = q(x.cuda())
     assert_close_to_exact(to_numpy(y0), prod.numpy(), dt, f"row form {wq} {cin}->{cout} k{k}, no bias")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("bits,zp,gs", [(4, False, 64), (4, True, 128), (4, False, None), (2, False, 32), (2, True, None)])
+@pytest.mark.parametrize("cin,cout,k,s,p,d,hw", [ROW_FORM_GEOMETRIES[i] for i in (0, 1, 2, 5, 6)])
+def test_qconv2d_subbyte_row_form_gpu(monkeypatch, dt, bits, zp, gs, cin, cout, k, s, p, d, hw):
+    """r5: int4 / int2 weights on three-tap-wide windows - the weight is dequantized ONCE into the scratch buffer (the reference's dense weight,
+    bit for bit) and the row form multiplies by it; every pixel tile of the tap kernel dequantizes the whole weight again.  Gate: the float64
+    convolution with the weight the reference dequantizes; the tap kernel on the same call stays within an ulp of it."""
+    kh = k if isinstance(k, int) else k[0]
+    if gs is not None and (cin * kh * 3) % gs:
+        pytest.skip("group size does not divide K")
+    qt = Q.qint4 if bits == 4 else Q.qint2
+    cout -= cout % 4
+    torch.manual_seed(cin + cout + bits)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, dilation=d).to(TORCH_DT[dt])
+    q = Q.QConv2d.from_module(conv, weights=qt)
+    Q.freeze(q)
+    scale, shift = Q.MaxOptimizer()(conv.weight.detach(), qt, 0, gs, zeropoint=zp)
+    w = Q.quantize_weight(conv.weight.detach(), qt, 0, scale, shift, group_size=gs, optimized=False)
+    assert w._group_size == gs and (w._shift.dtype == torch.uint8) == zp
+    q.weight = torch.nn.Parameter(w, requires_grad=False)
+    q = q.cuda()
+    x = torch.randn(3, cin, *hw).to(TORCH_DT[dt])
+    with torch.no_grad():
+        y = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == f"conv2d_rows_dequant_int{bits}"
+        monkeypatch.setenv("QUANTO_HIP_CONV_ROWS", "0")
+        y_taps = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == f"conv2d_mfma_int{bits}"
+        prod = torch.nn.functional.conv2d(x.double(), _oracle_dequantized(q.weight, dt), None, conv.stride, conv.padding, conv.dilation)
+    bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
+    assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), dt, f"int{bits} row form {cin}->{cout} k{k} g{gs}")
+    eps = {"fp16": 2.0 ** -10, "bf16": 2.0 ** -7}[dt]
+    diff = (y.float() - y_taps.float()).abs().cpu().double()
+    assert (diff <= eps * (prod.abs() + y_taps.cpu().double().abs()) * 1.01 + 1e-9).all()
 
 
 @pytest.mark.gpu
