@@ -632,7 +632,7 @@ def run_qconv2d(args, device, steps=50):
             out[f"{wq[1:]}_frac_hbm"] = round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)
             el, _ = timed_replay(lambda: torch.nn.functional.conv2d(x, w.dequantize(), bias, c["stride"], c["pad"]), steps, args, None, device, warmup=3)
             out[f"ref_rocm_{wq[1:]}_us"] = round(el * 1e6 / steps, 2)
-    out["bound"] = "instruction issue of the gather (DESIGN 4.8): both roofline fractions given"
+    out["bound"] = "the serial phases of a K-tile inside a workgroup - gather / staging / MFMA (DESIGN 4.8): both roofline fractions given"
     out["ref_rocm"] = "dequantize + MIOpen conv; kernel_us / traffic: the int8 launch"
     return out
 

@@ -625,8 +625,13 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
 //     the first pixel stores P0 P1 P2 into the tap blocks of its LDS row, the second P1 P2 P3: 16 VALU + 6 ds_write_b64 for 24 elements.
 //   * weights: thread (channel tid >> 2, part tid & 3) loads 24 contiguous bytes = rows 8 part .. + 7 x 3 taps, converts them during the MFMA
 //     phase (any byte of a register is a free operand select) and stores 16 bytes per tap block.
+// What it costs (compile-time ablations on (8,C,56,56) -> 128, one workgroup per CU, profiles/r05_qconv2d_rows_ablations*.jsonl): ~1.27 us per
+// 96-deep K-tile at C = 128 (the tap gather: 1.43 per 64) - MFMAs + fragment reads 0.28, loads 0.17, staging stores 0.12, conversion 0.03, the bare
+// loop (two barriers, scalar row arithmetic, v_perm) 0.28, and ~0.4 that only shows with everything present: the phases of a tile run one after
+// the other inside a workgroup.  More waves do not change that (sixteen waves in two groups on alternating tiles, in step or one phase apart:
+// level at 196 tiles, 3-23 % slower elsewhere - profiles/r05_qconv2d_rows_two_groups_negative.jsonl); a second workgroup on the CU does (~0.8).
 // LDS: [128 rows][224 bytes] per operand (96 k = 192 bytes + 32 of padding; 16-byte slot c of row r at c ^ (r >> 2 & 3): conflict-free
-// ds_read_b128 fragments, two-way staging stores - scripts/models/conv_rows_lds_model.py), ONE buffer and two barriers per K-tile: 56 KiB, two
+// ds_read_b128 fragments, two-way staging stores - scripts/models/conv_rows_model.py), ONE buffer and two barriers per K-tile: 56 KiB, two
 // workgroups per CU.  Needs K = 3 cin KH to be a multiple of 8 (8-byte weight pieces never straddle a row's end), KH <= 31, W >= 4.
 namespace rows {
 constexpr int RT = 32, BKR = 3 * RT;  // window rows / k per K-tile
@@ -827,8 +832,8 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // the MFMA phase, scheduled by hand (hipcc left to itself sinks the loads of the next tile behind the MFMAs or hoists the weight conversion -
-  // and its vmcnt wait - in front of them): the fragments of k-step kk + 1 are read while the MFMAs of k-step kk run, fences between the steps
+  // the MFMA phase, ordered by hand (with a fence behind the loads hipcc otherwise serialises fragment read -> wait -> two MFMAs; without one it
+  // sinks the next tile's loads behind the MFMAs): the fragments of k-step kk + 1 are read while the MFMAs of k-step kk run, fences between the steps
   V8 fa[2][4], fb[2][2];
   auto read_frags = [&](int kk) {
 #pragma unroll
@@ -857,8 +862,9 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
   write();
   __syncthreads();
   for (int t = 0; t + 1 < nk; ++t) {
-    // the next tile's loads first; its weights are converted AFTER the MFMAs (a conversion between them puts a vmcnt wait on loads issued a
-    // moment ago in front of the MFMAs: in the first form of this loop every load's address-unit time showed up in the tile time)
+    // the next tile's loads first; its weights are converted AFTER the MFMAs, so that no vmcnt wait on loads issued a moment ago stands in front
+    // of them.  (Measured against hipcc's own order, which interleaved the conversion: the same time within 1-3 % either way,
+    // profiles/r05_qconv2d_rows_ablations*.jsonl - the hand-placed order is kept because it does not move with the compiler.)
     issue(t + 1);
     __builtin_amdgcn_sched_barrier(0);
     mma_phase();
