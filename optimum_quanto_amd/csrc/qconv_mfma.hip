@@ -663,9 +663,14 @@ __device__ __forceinline__ float byte_to_f32(uint32_t d, int b) {  // b: a liter
   }
 }
 
-template <int DT, int FMT, bool BUF>
+// SINGLE (r5): ONE output pixel per thread (tile row tid & 127) and EIGHT window rows (8 (tid >> 7) ..): any stride along the width and odd OW -
+// the downsampling 3 x 3 layers and 7 x 7 / 13 x 13 feature maps the pair form cannot take.  An 8-byte window still brings the pixel's three taps
+// of a row (twice the load instructions of the pair form per element, a third fewer than the tap gather), the transposition is 8 rows x 3 elements
+// into three 16-byte pieces.
+template <int DT, int FMT, bool BUF, bool SINGLE>
 __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
   using namespace rows;
+  constexpr int NR = SINGLE ? 8 : 4;  // window rows per thread and K-tile
   using V8 = typename Mma<DT>::V8;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // [A tile | B tile]
 
@@ -690,10 +695,10 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
   uint32_t selN0, selN1;  // v_perm selectors: the clamped window -> (e0, e1) and (e2, e3), elements over the left / right padding zeroed
   {
     const int L = a.OH * a.OW;
-    int m = m0 + 2 * lane;
-    m = m < M ? m : M - 2;  // (M is even: OW is)
+    int m = SINGLE ? m0 + (tid & 127) : m0 + 2 * lane;
+    m = m < M ? m : (SINGLE ? M - 1 : M - 2);  // (pairs: M is even, OW is)
     const int b = m / L, l = m - b * L, oh = l / a.OW, ow = l - oh * a.OW;
-    const int iw0 = ow - a.pw;  // column of e0; e_j at iw0 + j, the first pixel takes e0 e1 e2, the second e1 e2 e3
+    const int iw0 = ow * a.sw - a.pw;  // column of e0; e_j at iw0 + j: the (first) pixel takes e0 e1 e2, the second pixel of a pair (sw = 1) e1 e2 e3
     int ws = iw0 < 0 ? 0 : iw0;
     ws = ws > a.W - 4 ? a.W - 4 : ws;  // an element inside the image is inside the clamped window (W >= 4)
     const int delta = iw0 - ws;
@@ -707,12 +712,14 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
       return iw >= 0 && iw < a.W ? (uint32_t)(((2 * q + 1) << 8) | (2 * q)) : 0x0c0cu;
     };
     selN0 = half_sel(0) | (half_sel(1) << 16);
-    selN1 = half_sel(2) | (half_sel(3) << 16);
+    selN1 = half_sel(2) | ((SINGLE ? 0x0c0cu : half_sel(3)) << 16);
   }
 
   // ---- LDS addresses (constant over the K loop: one buffer) --------------------------------------------------------------------------------------
   // rows 2 lane and 2 lane + 1 share their swizzle; tap block j at + 64 j (the swizzle only touches the slot inside a block)
-  const uint32_t awr = (uint32_t)((2 * lane) * RS + (((wave >> 1) ^ ((lane >> 1) & 3)) << 4) + (wave & 1) * 8);
+  // (SINGLE: row tid & 127, eight rows = the 16-byte slot tid >> 7 of every tap block)
+  const uint32_t awr = SINGLE ? (uint32_t)((tid & 127) * RS + (((tid >> 7) ^ ((tid >> 2) & 3)) << 4))
+                              : (uint32_t)((2 * lane) * RS + (((wave >> 1) ^ ((lane >> 1) & 3)) << 4) + (wave & 1) * 8);
   const uint32_t bwr = (uint32_t)(OP_BYTES + (tid >> 2) * RS + (((tid & 3) ^ ((tid >> 4) & 3)) << 4));
   const uint32_t frag_slot = (uint32_t)((((lane >> 4) ^ ((lane >> 2) & 3)) << 4));
   const uint32_t ard = (uint32_t)((wm * 64 + (lane & 15)) * RS) + frag_slot;
@@ -724,7 +731,7 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
   const uint32_t woff = (uint32_t)(wn_row * K + 24 * (tid & 3)) * WB;
   const int wk = 24 * (tid & 3);
 
-  u32x2 D[4], wq[3];  // gathered windows / weight bytes of the K-tile in flight
+  u32x2 D[NR], wq[3];  // gathered windows / weight bytes of the K-tile in flight
   uint4 wd[3];        // (dense weight: its 24 elements)
   uint4 cw[3];        // its converted weights, one 16-byte piece per tap block
   auto issue = [&](int t) {
@@ -742,9 +749,9 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NR; ++u) {
       // scalar: row -> (channel, tap row) -> byte offset; behind the last row: -1
-      const uint32_t r = (uint32_t)(T * RT + 4 * wave + u);
+      const uint32_t r = (uint32_t)(T * RT + (SINGLE ? 8 * (wave >> 1) : 4 * wave) + u);
       const uint32_t c = __umulhi(r, a.kh_magic) + (a.kh_magic ? 0u : r);  // (magic 0: KH = 1)
       const uint32_t i = r - c * (uint32_t)a.KH;
       const uint32_t roff = 2u * ((c * (uint32_t)a.H + i * (uint32_t)a.dh) * (uint32_t)a.W);
@@ -798,19 +805,36 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
     if (QH_CONV_ABLATE & 16) {  // keep the loaded registers alive
       uint32_t t = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t ^= D[u].x ^ D[u].y;
+      for (int u = 0; u < NR; ++u) t ^= D[u].x ^ D[u].y;
 #pragma unroll
       for (int j = 0; j < 3; ++j) t ^= cw[j].x ^ cw[j].y ^ cw[j].z ^ cw[j].w;
       if (t == 0x12345678u) smem[tid] = 1;
       return;
     }
-    uint32_t n0[4], n1[4];
+    uint32_t n0[NR], n1[NR];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NR; ++u) {
       n0[u] = __builtin_amdgcn_perm(D[u].y, D[u].x, selN0);
       n1[u] = __builtin_amdgcn_perm(D[u].y, D[u].x, selN1);
     }
     constexpr uint32_t LO = 0x05040100u, HI = 0x07060302u;  // the low / high halves of two registers
+    if constexpr (SINGLE) {  // tap j of rows 0 .. 7: 16 bytes of tap block j
+      uint8_t* sa = smem + awr;
+      uint32_t t0[4], t1[4], t2[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        t0[h] = __builtin_amdgcn_perm(n0[2 * h + 1], n0[2 * h], LO);
+        t1[h] = __builtin_amdgcn_perm(n0[2 * h + 1], n0[2 * h], HI);
+        t2[h] = __builtin_amdgcn_perm(n1[2 * h + 1], n1[2 * h], LO);
+      }
+      *reinterpret_cast<uint4*>(sa) = make_uint4(t0[0], t0[1], t0[2], t0[3]);
+      *reinterpret_cast<uint4*>(sa + 64) = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+      *reinterpret_cast<uint4*>(sa + 128) = make_uint4(t2[0], t2[1], t2[2], t2[3]);
+      uint8_t* sb = smem + bwr;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) *reinterpret_cast<uint4*>(sb + 64 * j) = cw[j];
+      return;
+    }
     const uint2 p0 = make_uint2(__builtin_amdgcn_perm(n0[1], n0[0], LO), __builtin_amdgcn_perm(n0[3], n0[2], LO));
     const uint2 p1 = make_uint2(__builtin_amdgcn_perm(n0[1], n0[0], HI), __builtin_amdgcn_perm(n0[3], n0[2], HI));
     const uint2 p2 = make_uint2(__builtin_amdgcn_perm(n1[1], n1[0], LO), __builtin_amdgcn_perm(n1[3], n1[2], LO));
@@ -952,20 +976,25 @@ static int pick_split(int64_t M, int64_t N, int64_t K) {
 static size_t split_workspace(int64_t M, int64_t N, int S) { return S <= 1 ? 0 : (size_t)S * ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * (BM * BN * 4); }
 
 // row form: three taps wide, stride 1 / dilation 1 along the width, even OW (QUANTO_HIP_CONV_ROWS=0: the tap gather, 2: global loads - experiments)
+// (pixel pairs need stride 1 and an even OW; anything else three taps wide takes one pixel per thread; QUANTO_HIP_CONV_ROWS=3: one pixel per thread everywhere)
 static bool rows_eligible(int64_t cin, int64_t KH, int64_t KW, int64_t W, int64_t OW, int sw, int dw) {
-  return env_int("QUANTO_HIP_CONV_ROWS", 1) != 0 && KW == 3 && sw == 1 && dw == 1 && OW % 2 == 0 && W >= 4 && KH <= 31 && (cin * KH) % 8 == 0;
+  return env_int("QUANTO_HIP_CONV_ROWS", 1) != 0 && KW == 3 && dw == 1 && W >= 4 && KH <= 31 && (cin * KH) % 8 == 0;
 }
+static bool rows_pairs(int64_t OW, int sw) { return sw == 1 && OW % 2 == 0 && env_int("QUANTO_HIP_CONV_ROWS", 1) != 3; }
 template <int DT, int FMT>
 static int launch_rows(Args a, int ntiles, int mtiles, hipStream_t stream) {  // a.S: the split the workspace allows; a.partials set
   g_last_rows = true;
   const int nk_rows = (a.cin * a.KH + rows::RT - 1) / rows::RT;
   a.S = a.S < nk_rows ? a.S : nk_rows;
-  if (env_int("QUANTO_HIP_CONV_ROWS", 1) == 2) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
-    hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, false>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
+  if (!rows_pairs(a.OW, a.sw)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
+    hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, true, true>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
+  } else if (env_int("QUANTO_HIP_CONV_ROWS", 1) == 2) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
+    hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, false, false>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
-    hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, true>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
+    hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, true, false>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
   }
   if (a.S > 1) hipLaunchKernelGGL((qconv2d_reduce_kernel<DT, 1>), dim3(ntiles, mtiles, 8), dim3(64), 0, stream, a);
   return launch_status();

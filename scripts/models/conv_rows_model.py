@@ -39,15 +39,25 @@ def perm(src0, src1, sel):
 
 
 def rows_eligible(cin, KH, KW, W, OW, sw, dw):
-    return KW == 3 and sw == 1 and dw == 1 and OW % 2 == 0 and W >= 4 and KH <= 31 and (cin * KH) % 8 == 0
+    return KW == 3 and dw == 1 and W >= 4 and KH <= 31 and (cin * KH) % 8 == 0
 
 
-def conv_rows_model(x16, wq, B, cin, H, W, OC, KH, OH, OW, sh, ph, pw, dh, S=1):
+def rows_pairs(OW, sw):
+    """pixel pairs (one 8-byte window for two neighbouring output pixels) need stride 1 along the width and an even OW; else one pixel per thread"""
+    return sw == 1 and OW % 2 == 0
+
+
+def conv_rows_model(x16, wq, B, cin, H, W, OC, KH, OH, OW, sh, ph, pw, dh, S=1, sw=1, single=None):
     """x16: uint16 [B, cin, H, W] (any 16-bit payload), wq: int8 [OC, cin*KH*3].  Returns int64 [B, OC, OH, OW] sums of payload * weight with
     the payload read as a signed 16-bit integer (exact arithmetic: what matters is WHICH elements meet)."""
     KW = 3
     M, N, K, R = B * OH * OW, OC, cin * KH * KW, cin * KH
-    assert rows_eligible(cin, KH, KW, W, OW, 1, 1)
+    assert rows_eligible(cin, KH, KW, W, OW, sw, 1)
+    if single is None:
+        single = not rows_pairs(OW, sw)
+    assert single or rows_pairs(OW, sw)
+    NL = 128 if single else 64   # threads with distinct pixel state
+    NRW = 8 if single else 4     # window rows per thread
     xbytes = x16.reshape(-1).view(np.uint8)
     xlen = xbytes.size
     wbytes = wq.reshape(-1).view(np.uint8)
@@ -74,12 +84,12 @@ def conv_rows_model(x16, wq, B, cin, H, W, OC, KH, OH, OW, sh, ph, pw, dh, S=1):
         acc = np.zeros((8, 4, 2, 64, 4), dtype=np.int64)  # [wave][i][j][lane][r]
         # per-lane pixel-pair state (the same in every wave)
         px_base, nok, selN0, selN1 = [], [], [], []
-        for lane in range(64):
-            m = m0 + 2 * lane
-            m = m if m < M else M - 2
+        for lane in range(NL):  # (single: tid & 127)
+            m = m0 + lane if single else m0 + 2 * lane
+            m = m if m < M else (M - 1 if single else M - 2)
             b, l = divmod(m, L)
             oh, ow = divmod(l, OW)
-            iw0 = ow - pw
+            iw0 = ow * sw - pw
             ws = min(max(iw0, 0), W - 4)
             delta = iw0 - ws
             px_base.append(2 * ((b * cin * H + (oh * sh - ph)) * W + ws))
@@ -98,7 +108,7 @@ def conv_rows_model(x16, wq, B, cin, H, W, OC, KH, OH, OW, sh, ph, pw, dh, S=1):
                 return 0x0C0C
 
             selN0.append(half_sel(0) | (half_sel(1) << 16))
-            selN1.append(half_sel(2) | (half_sel(3) << 16))
+            selN1.append(half_sel(2) | ((0x0C0C if single else half_sel(3)) << 16))
 
         for t in range(nk):
             T = kt_lo + t
@@ -113,35 +123,45 @@ def conv_rows_model(x16, wq, B, cin, H, W, OC, KH, OH, OW, sh, ph, pw, dh, S=1):
             for wave in range(8):
                 # scalar row arithmetic
                 roffs, bits = [], []
-                for u in range(4):
-                    r = T * RT + 4 * wave + u
+                for u in range(NRW):
+                    r = T * RT + (8 * (wave >> 1) if single else 4 * wave) + u
                     c = ((r * kh_magic) >> 32) + (0 if kh_magic else r)
                     i = r - c * KH
                     assert r >= R or (0 <= i < KH and c < cin)
                     roffs.append((2 * ((c * H + i * dh) * W)) & 0xFFFFFFFF)
                     bits.append(i if r < R else 31)
                 for lane in range(64):
+                    tid = wave * 64 + lane
+                    ps = (tid & 127) if single else lane  # index of the thread's pixel state
                     D = []
-                    for u in range(4):
-                        pad = 0xFFFFFFFF if (nok[lane] >> (bits[u] & 31)) & 1 else 0
-                        addr = ((px_base[lane] + roffs[u]) & 0xFFFFFFFF) | pad
+                    for u in range(NRW):
+                        pad = 0xFFFFFFFF if (nok[ps] >> (bits[u] & 31)) & 1 else 0
+                        addr = ((px_base[ps] + roffs[u]) & 0xFFFFFFFF) | pad
                         D.append(buf_load8(xbytes, xlen, addr))
-                    n0 = [perm(D[u][1], D[u][0], selN0[lane]) for u in range(4)]
-                    n1 = [perm(D[u][1], D[u][0], selN1[lane]) for u in range(4)]
+                    n0 = [perm(D[u][1], D[u][0], selN0[ps]) for u in range(NRW)]
+                    n1 = [perm(D[u][1], D[u][0], selN1[ps]) for u in range(NRW)]
                     LO, HI = 0x05040100, 0x07060302
-                    p = [
+                    if single:  # tap j of the eight rows: 16 bytes of tap block j, LDS row tid & 127, slot tid >> 7 of the block
+                        awr = (tid & 127) * RS + (((tid >> 7) ^ ((tid >> 2) & 3)) << 4)
+                        taps = [[perm(n0[2 * h + 1], n0[2 * h], LO) for h in range(4)], [perm(n0[2 * h + 1], n0[2 * h], HI) for h in range(4)],
+                                [perm(n1[2 * h + 1], n1[2 * h], LO) for h in range(4)]]
+                        for j in range(3):
+                            v = 0
+                            for h in range(4):
+                                v |= taps[j][h] << (32 * h)
+                            st(awr + 64 * j, v, 16)
+                    p = [] if single else [
                         (perm(n0[1], n0[0], LO), perm(n0[3], n0[2], LO)),
                         (perm(n0[1], n0[0], HI), perm(n0[3], n0[2], HI)),
                         (perm(n1[1], n1[0], LO), perm(n1[3], n1[2], LO)),
                         (perm(n1[1], n1[0], HI), perm(n1[3], n1[2], HI)),
                     ]
                     awr = (2 * lane) * RS + (((wave >> 1) ^ ((lane >> 1) & 3)) << 4) + (wave & 1) * 8
-                    for px in range(2):
+                    for px in range(0 if single else 2):
                         for j in range(3):
                             lo, hi = p[j + px]
                             st(awr + px * RS + 64 * j, lo | (hi << 32), 8)
                     # weights
-                    tid = wave * 64 + lane
                     n = min(nt * BN + (tid >> 2), N - 1)
                     part = tid & 3
                     woff = n * K + 24 * part
@@ -197,7 +217,7 @@ def conv_rows_model(x16, wq, B, cin, H, W, OC, KH, OH, OW, sh, ph, pw, dh, S=1):
     return out
 
 
-def direct(x16, wq, B, cin, H, W, OC, KH, OH, OW, sh, ph, pw, dh):
+def direct(x16, wq, B, cin, H, W, OC, KH, OH, OW, sh, ph, pw, dh, sw=1):
     xs = x16.view(np.int16).astype(np.int64)
     w = wq.astype(np.int64).reshape(OC, cin, KH, 3)
     out = np.zeros((B, OC, OH, OW), dtype=np.int64)
@@ -205,7 +225,7 @@ def direct(x16, wq, B, cin, H, W, OC, KH, OH, OW, sh, ph, pw, dh):
     xp[:, :, ph:ph + H, pw:pw + W] = xs
     for i in range(KH):
         for j in range(3):
-            patch = xp[:, :, i * dh:i * dh + (OH - 1) * sh + 1:sh, j:j + OW]
+            patch = xp[:, :, i * dh:i * dh + (OH - 1) * sh + 1:sh, j:j + (OW - 1) * sw + 1:sw]
             out += np.einsum("bchw,nc->bnhw", patch, w[:, :, i, j])
     return out
 
@@ -219,6 +239,14 @@ CASES = [
     (1, 8, 9, 12, 8, 3, 2, 1, 2, 1, 1),     # stride 2 along the height, two columns of padding: OW = 14
     (1, 8, 10, 8, 8, 3, 1, 2, 1, 2, 1),     # dilation 2 along the height
     (3, 8, 5, 6, 136, 5, 1, 2, 1, 1, 1),    # 5 x 3, two channel tiles, M = 90 (tail)
+]
+# one pixel per thread: (B, cin, H, W, OC, KH, sh, ph, pw, dh, S, sw)
+SINGLE_CASES = [
+    (2, 8, 9, 9, 8, 3, 2, 1, 1, 1, 1, 2),     # the downsampling 3 x 3: stride 2 both ways, OW = 5
+    (1, 16, 7, 7, 12, 3, 1, 1, 1, 1, 1, 1),   # stride 1 with an odd OW = 7 (the 7 x 7 maps of a ResNet's last stage)
+    (1, 24, 6, 11, 8, 3, 1, 0, 2, 1, 2, 3),   # stride 3, two columns of padding, two splits, ragged last tile
+    (1, 8, 5, 4, 8, 1, 1, 0, 0, 1, 1, 1),     # 1 x 3 "valid" on W = 4: OW = 2 - forced onto the single form below
+    (2, 8, 6, 8, 8, 3, 1, 1, 1, 1, 1, 1),     # a pair-eligible geometry on the single form (QUANTO_HIP_CONV_ROWS=3)
 ]
 
 
@@ -243,22 +271,39 @@ def lds_bank_model():
     return worst_r, worst_a, worst_b
 
 
-def run_case(case, seed=0):
-    B, cin, H, W, OC, KH, sh, ph, pw, dh, S = case
+def lds_bank_model_single():
+    """ds_write_b128 of the one-pixel form: eight contiguous lanes per LDS cycle, 32 banks"""
+    worst = 0
+    for wave, j, g in itertools.product(range(8), range(3), range(8)):
+        tids = [wave * 64 + l for l in range(8 * g, 8 * g + 8)]
+        addrs = [(t & 127) * RS + (((t >> 7) ^ ((t >> 2) & 3)) << 4) + 64 * j for t in tids]
+        c = {}
+        for a in addrs:
+            for i in range(4):
+                c.setdefault(((a // 4) + i) % 32, set()).add(a)
+        worst = max(worst, max(len(v) for v in c.values()))
+    return worst
+
+
+def run_case(case, seed=0, single=None):
+    B, cin, H, W, OC, KH, sh, ph, pw, dh, S = case[:11]
+    sw = case[11] if len(case) > 11 else 1
     OH = (H + 2 * ph - dh * (KH - 1) - 1) // sh + 1
-    OW = W + 2 * pw - 2
+    OW = (W + 2 * pw - 3) // sw + 1
     rng = np.random.default_rng(seed)
     x16 = rng.integers(-300, 300, size=(B, cin, H, W), dtype=np.int16).view(np.uint16)
     wq = rng.integers(-128, 128, size=(OC, cin * KH * 3), dtype=np.int8)
-    got = conv_rows_model(x16, wq, B, cin, H, W, OC, KH, OH, OW, sh, ph, pw, dh, S)
-    want = direct(x16, wq, B, cin, H, W, OC, KH, OH, OW, sh, ph, pw, dh)
+    got = conv_rows_model(x16, wq, B, cin, H, W, OC, KH, OH, OW, sh, ph, pw, dh, S, sw, single)
+    want = direct(x16, wq, B, cin, H, W, OC, KH, OH, OW, sh, ph, pw, dh, sw)
     return np.array_equal(got, want)
 
 
 def main():
-    print("LDS conflict degree: fragment ds_read_b128 %d, pixel ds_write_b64 %d, weight ds_write_b128 %d" % lds_bank_model())
+    print("LDS conflict degree: fragment ds_read_b128 %d, pixel ds_write_b64 %d, weight ds_write_b128 %d" % lds_bank_model(), "; one-pixel form ds_write_b128", lds_bank_model_single())
     for case in CASES:
         print(case, "ok" if run_case(case) else "MISMATCH")
+    for case in SINGLE_CASES:
+        print("one pixel per thread", case, "ok" if run_case(case, single=True) else "MISMATCH")
 
 
 if __name__ == "__main__":

@@ -20,6 +20,8 @@ WEIGHTS = sys.argv[1] if len(sys.argv) > 1 else "qint8"
 SHAPES = [(8, 256, 56, 256, 3, 1, 1), (8, 128, 56, 128, 3, 1, 1), (32, 512, 14, 512, 3, 1, 1), (8, 64, 112, 128, 3, 2, 1), (8, 512, 28, 128, 1, 1, 0)]
 if len(sys.argv) > 2 and sys.argv[2] == "stems":  # r5: ragged K (RGB stems) and wide windows - shapes that fell back to F.unfold + GEMM until r5
     SHAPES = [(8, 3, 224, 64, 7, 2, 3), (32, 3, 224, 64, 7, 2, 3), (8, 3, 224, 32, 3, 2, 1), (8, 3, 32, 64, 3, 1, 1), (8, 16, 64, 64, 9, 1, 4), (8, 3, 227, 96, 11, 4, 0)]
+if len(sys.argv) > 2 and sys.argv[2] == "strided":  # r5: three-tap windows the pair form cannot take (stride 2, 7 x 7 maps): the one-pixel row form
+    SHAPES = [(8, 64, 112, 128, 3, 2, 1), (8, 128, 56, 256, 3, 2, 1), (8, 512, 7, 512, 3, 1, 1), (32, 512, 7, 512, 3, 1, 1)]
 if len(sys.argv) > 2 and sys.argv[2] == "grid":  # the sweep behind the dispatch rule of tensor/weights.py (_implicit_conv2d_wins)
     SHAPES = [(8, 64, 56, 64, 3, 1, 1), (32, 64, 56, 64, 3, 1, 1), (8, 128, 28, 128, 3, 1, 1), (32, 128, 28, 128, 3, 1, 1), (8, 192, 28, 192, 3, 1, 1),
               (8, 256, 14, 256, 3, 1, 1), (32, 256, 14, 256, 3, 1, 1), (8, 256, 28, 256, 3, 1, 1), (8, 320, 32, 320, 3, 1, 1), (8, 512, 7, 512, 3, 1, 1),

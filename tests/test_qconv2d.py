@@ -51,14 +51,15 @@ def _check_inner_tensors(golden, key, tag, qw):
 
 
 def _row_form(cin, k, s, d, w_in, p, wq="qint8"):
-    """True where the 8-bit convolution takes the ROW form (r5): three taps wide, stride 1 / dilation 1 along the width, even OW, W >= 4, KH <= 31,
-    cin KH a multiple of 8 (csrc/qconv_mfma.hip::launch_w)."""
+    """True where the convolution takes the ROW form (r5): three taps wide, dilation 1 along the width, W >= 4, KH * 3 <= 31, cin KH a multiple
+    of 8 (csrc/qconv_mfma.hip::rows_eligible)."""
     kh, kw = (k, k) if isinstance(k, int) else k
     sw = s if isinstance(s, int) else s[1]
     dw = d if isinstance(d, int) else d[1]
     pw = p if isinstance(p, int) else p[1]
     ow = (w_in + 2 * pw - dw * (kw - 1) - 1) // sw + 1
-    return kw == 3 and sw == 1 and dw == 1 and ow % 2 == 0 and w_in >= 4 and kh * kw <= 31 and (cin * kh) % 8 == 0
+    del ow, sw  # (stride 1 with an even OW: pixel pairs; any other stride / an odd OW: one pixel per thread - the row form either way)
+    return kw == 3 and dw == 1 and w_in >= 4 and kh * kw <= 31 and (cin * kh) % 8 == 0
 
 
 def _conv_kernel_name(cin, k, s, d, w_in, p, wq="qint8"):
@@ -319,7 +320,7 @@ def test_qconv2d_subbyte_implicit_gemm_ragged_k_and_qint2_gpu(dt, bits, zp, cin,
     with torch.no_grad():
         y = q(x.cuda())
         eligible = gs is None or gs % 8 == 0
-        assert (quanto_hip.lib.last_kernel() == f"conv2d_mfma_int{bits}") == eligible, quanto_hip.lib.last_kernel()
+        assert (quanto_hip.lib.last_kernel() == _conv_kernel_name(cin, k, s, d, 13, p, f"qint{bits}")) == eligible, quanto_hip.lib.last_kernel()
         prod = torch.nn.functional.conv2d(x.double(), _oracle_dequantized(q.weight, dt), None, conv.stride, conv.padding, conv.dilation)
     assert y.shape == prod.shape and y.dtype == TORCH_DT[dt]
     bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
@@ -336,6 +337,7 @@ def test_qconv2d_implicit_gemm_k_split_gpu(monkeypatch, wq, split):
     """The convolution kernel's K split (blockIdx.z + a reduce kernel that adds the fp32 partial tiles in split order): forced to 1 (no
     workspace use), 2 and 7 (ragged: 18 K-tiles), every result against the float64 gate; and a call WITHOUT a workspace runs unsplit."""
     monkeypatch.setenv("QUANTO_HIP_CONV_SPLIT", str(split))
+    monkeypatch.setenv("QUANTO_HIP_CONV_ROWS", "0")  # (the tap kernel's split; the row form has its own test)
     torch.manual_seed(3)
     conv = torch.nn.Conv2d(128, 200, 3, padding=1).to(torch.bfloat16)
     q = Q.QConv2d.from_module(conv, weights=getattr(Q, wq))
@@ -418,7 +420,7 @@ def test_qconv2d_pair_gather_gpu(monkeypatch, dt, wq, cin, cout, k, s, p, d, hw)
     assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), dt, f"pair gather {wq} {cin}->{cout} k{k}")
 
 
-@pytest.mark.parametrize("case", range(7))
+@pytest.mark.parametrize("case", range(12))
 def test_conv_row_form_model(case):
     """CPU model of the row form (scripts/models/conv_rows_model.py): clamped 8-byte windows, selectors, scalar row arithmetic, the 4 x 4 v_perm
     transposition, the LDS image and the fragment reads, the weight bytes' regrouping, the K split - index for index against a direct convolution
@@ -428,9 +430,12 @@ def test_conv_row_form_model(case):
     spec = importlib.util.spec_from_file_location("conv_rows_model", os.path.join(ROOT, "scripts", "models", "conv_rows_model.py"))
     model = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(model)
-    assert model.run_case(model.CASES[case], seed=case)
+    if case < 7:
+        assert model.run_case(model.CASES[case], seed=case)
+    else:  # one pixel per thread: strides 2 / 3 along the width, odd OW, a pair-eligible geometry forced onto it
+        assert model.run_case(model.SINGLE_CASES[case - 7], seed=case, single=True)
     if case == 0:
-        assert model.lds_bank_model() == (1, 2, 2)
+        assert model.lds_bank_model() == (1, 2, 2) and model.lds_bank_model_single() == 1
 
 
 ROW_FORM_GEOMETRIES = [(64, 96, 3, 1, 1, 1, (13, 12)),              # "same": both borders of every row, ragged M (3 x 13 x 12 pixels)
@@ -476,6 +481,64 @@ def test_qconv2d_row_form_gpu(monkeypatch, loads, dt, wq, cin, cout, k, s, p, d,
     with torch.no_grad():
         y0 = q(x.cuda())
     assert_close_to_exact(to_numpy(y0), prod.numpy(), dt, f"row form {wq} {cin}->{cout} k{k}, no bias")
+
+
+SINGLE_ROW_FORM_GEOMETRIES = [(64, 96, 3, 2, 1, 1, (13, 12)),                   # the downsampling 3 x 3: stride 2 both ways
+                              (64, 40, 3, 1, 1, 1, (9, 7)),                      # stride 1, OW = 7: no pixel pairs
+                              (32, 48, (5, 3), (1, 3), (2, 2), (2, 1), (12, 11)),  # stride 3 along the width, two columns of padding, five dilated tap rows
+                              (24, 136, 3, 2, 1, 1, (9, 9)),                     # 72 window rows (ragged last K-tile), two channel tiles
+                              (128, 128, 3, 2, 1, 1, (28, 28)),                  # a ResNet stage's first layer
+                              (16, 24, (1, 3), 1, 0, 1, (5, 5))]                 # 1 x 3 "valid", OW = 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("wq", ["qint8", "qfloat8_e4m3fn", "qint4", "qint2"])
+@pytest.mark.parametrize("cin,cout,k,s,p,d,hw", SINGLE_ROW_FORM_GEOMETRIES)
+def test_qconv2d_row_form_one_pixel_per_thread_gpu(dt, wq, cin, cout, k, s, p, d, hw):
+    """r5: three-tap-wide windows at ANY stride along the width / with an odd OW - the row form with one output pixel per thread and eight window
+    rows (int4 / int2: on the weight dequantized once).  Float64 gate as for the pair form."""
+    torch.manual_seed(cin * 11 + cout)
+    cout -= cout % 4
+    conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, dilation=d).to(TORCH_DT[dt])
+    q = Q.QConv2d.from_module(conv, weights=getattr(Q, wq))
+    Q.freeze(q)
+    q = q.cuda()
+    x = torch.randn(3, cin, *hw).to(TORCH_DT[dt])
+    sub = wq in ("qint4", "qint2")
+    with torch.no_grad():
+        y = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == _conv_kernel_name(cin, k, s, d, hw[1], p, wq) and "rows" in quanto_hip.lib.last_kernel()
+        if sub:
+            prod = torch.nn.functional.conv2d(x.double(), _oracle_dequantized(q.weight, dt), None, conv.stride, conv.padding, conv.dilation)
+        else:
+            w64 = q.weight._data.cpu().double() if wq == "qint8" else q.weight._data.cpu().float().double()
+            prod = torch.nn.functional.conv2d(x.double(), w64, None, conv.stride, conv.padding, conv.dilation) * q.weight._scale.cpu().double().reshape(1, -1, 1, 1)
+    assert y.shape == prod.shape and y.dtype == TORCH_DT[dt] and torch.isfinite(y.float()).all()
+    bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
+    assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), dt, f"row form, one pixel per thread, {wq} {cin}->{cout} k{k} s{s}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wq", ["qint8", "qint4"])
+@pytest.mark.parametrize("cin,cout,k,s,p,d,hw", [ROW_FORM_GEOMETRIES[i] for i in (0, 1, 2, 5)])
+def test_qconv2d_row_form_pairs_and_single_pixels_agree_gpu(monkeypatch, wq, cin, cout, k, s, p, d, hw):
+    """The two thread mappings of the row form stage the same LDS image and run the same MFMA sequence: on a geometry both can take
+    (QUANTO_HIP_CONV_ROWS=3 forces one pixel per thread) the outputs must be identical bit for bit."""
+    torch.manual_seed(cin + cout)
+    cout -= cout % 4
+    conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, dilation=d).to(torch.bfloat16)
+    q = Q.QConv2d.from_module(conv, weights=getattr(Q, wq))
+    Q.freeze(q)
+    q = q.cuda()
+    x = torch.randn(3, cin, *hw).to(torch.bfloat16)
+    with torch.no_grad():
+        y_pairs = q(x.cuda())
+        name = quanto_hip.lib.last_kernel()
+        monkeypatch.setenv("QUANTO_HIP_CONV_ROWS", "3")
+        y_single = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == name and "rows" in name
+    assert torch.equal(y_pairs, y_single), f"{(y_pairs != y_single).sum().item()} of {y_pairs.numel()} elements differ"
 
 
 @pytest.mark.gpu
