@@ -309,10 +309,10 @@ int64_t quanto_hip_conv2d_workspace_size(int64_t B, int64_t OH, int64_t OW, int6
  *   bias: dtype[OC] or NULL; y: dtype[B, OC, OH, OW].  dtype in {F16, BF16}; shift_dtype = dtype or U8 / I8.
  *   bits = 4 (OC even) or 2 (OC a multiple of 4; r5), group_size a multiple of 8 or 0, the geometry limits of quanto_hip_qbytes_conv2d;
  *   QUANTO_HIP_ENOTSUP otherwise (the caller then lowers the convolution to im2col + qbits_mm or keeps the reference's dequantize + float convolution).
- *   r5: windows three taps wide at stride 1 / dilation 1 along the width (even OW, W >= 4, cin * KH a multiple of 8, KH * KW <= 31) take another
- *   route when `workspace` holds quanto_hip_qbits_conv2d_workspace_size bytes: the weight is dequantized ONCE into the workspace (the reference's
- *   dense weight, tensor/qbits.py:27-49, bit for bit) and the row form of the implicit GEMM multiplies by it - every pixel tile of the tap kernel
- *   dequantizes the whole weight again.  With a smaller workspace the call keeps the tap kernel.
+ *   r5: windows three taps wide at dilation 1 along the width (any stride; W >= 4, cin * KH a multiple of 8, KH * KW <= 31) on at least 8 tiles
+ *   of 128 output pixels take another route when `workspace` holds quanto_hip_qbits_conv2d_workspace_size bytes: the weight is dequantized ONCE into
+ *   the workspace (the reference's dense weight, tensor/qbits.py:27-49, bit for bit) and the row form of the implicit GEMM multiplies by it - every
+ *   pixel tile of the tap kernel dequantizes the whole weight again.  With a smaller workspace (or fewer pixels) the call keeps the tap kernel.
  */
 int quanto_hip_qbits_conv2d(const void* x, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y, int64_t B, int64_t cin,
                             int64_t H, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,

@@ -651,8 +651,11 @@ int quanto_hip_qbits_conv2d(const void* x, const uint8_t* packed, const void* sc
   const PackedGeom g = make_geom(OC, K, bits, group_size);
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   const size_t dense = conv2d_dense_weight_bytes(OC, K);
-  if (conv2d_rows_eligible(cin, KH, KW, W, OW, stride_w, dil_w, OC) && workspace && workspace_bytes >= dense && reinterpret_cast<uintptr_t>(workspace) % 16 == 0 &&
-      is_float_dtype(dtype) && dtype != QUANTO_HIP_F32) {
+  // (the tap kernel dequantizes the whole weight once per 128-pixel tile; one dequantize launch pays from ~8 pixel tiles on: (8,512,7,7) -> 512, 4 of
+  // them, 28.8 us on the tap kernel against 30.2 this way, (32,512,7,7), 13 tiles, 44.3 against 40.3 - profiles/r05_qconv2d_rows_one_pixel_ab.jsonl)
+  const int64_t pixel_tiles = (B * OH * OW + 127) / 128;
+  if (conv2d_rows_eligible(cin, KH, KW, W, OW, stride_w, dil_w, OC) && pixel_tiles >= env_int("QUANTO_HIP_CONV_DENSE_MIN_TILES", 8) && workspace &&
+      workspace_bytes >= dense && reinterpret_cast<uintptr_t>(workspace) % 16 == 0 && is_float_dtype(dtype) && dtype != QUANTO_HIP_F32) {
     // three-tap-wide windows at stride 1: dequantize once (the reference's own dense weight), then the row form of the convolution on it
     int r = dequantize_qbits_dispatch(packed, scale, shift, workspace, g, dtype, int_shift, hs);
     if (r == QUANTO_HIP_OK)

@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
     store_tile<DT, PL>(a, acc, m0, nt, wm, wn, lane);
 }
 
-// ---- ROW form (r5): windows three taps wide, stride 1 and dilation 1 along the width, even OW ---------------------------------------------------
+// ---- ROW form (r5): windows three taps wide at dilation 1 along the width (pixel pairs: stride 1, even OW; else one pixel per thread) ------------
 // The gather above pays ~3.4 VALU instructions and half a load per gathered element, and the kernel is bound by exactly that instruction stream
 // (DESIGN 4.8).  For the layers that dominate convolutional networks - 3 x 3 (any KH x 3) windows walked at stride 1 - the taps (c, i, 0..2) of
 // two neighbouring output pixels are FOUR neighbouring input elements: one 8-byte load per (pixel pair, window row r = c KH + i) brings six
@@ -633,6 +633,7 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_mfma_kernel(const Args a) {
 // LDS: [128 rows][224 bytes] per operand (96 k = 192 bytes + 32 of padding; 16-byte slot c of row r at c ^ (r >> 2 & 3): conflict-free
 // ds_read_b128 fragments, two-way staging stores - scripts/models/conv_rows_model.py), ONE buffer and two barriers per K-tile: 56 KiB, two
 // workgroups per CU.  Needs K = 3 cin KH to be a multiple of 8 (8-byte weight pieces never straddle a row's end), KH <= 31, W >= 4.
+// (The description above is the pixel-PAIR mapping; the one-pixel mapping for other strides / an odd OW is described at the kernel.)
 namespace rows {
 constexpr int RT = 32, BKR = 3 * RT;  // window rows / k per K-tile
 constexpr int RS = 224;               // LDS bytes per operand row

@@ -62,12 +62,14 @@ def _row_form(cin, k, s, d, w_in, p, wq="qint8"):
     return kw == 3 and dw == 1 and w_in >= 4 and kh * kw <= 31 and (cin * kh) % 8 == 0
 
 
-def _conv_kernel_name(cin, k, s, d, w_in, p, wq="qint8"):
-    """8-bit weights: the row form or the tap gather; int4 / int2: dequantize once + the row form on the dense weight, or the tap gather that
-    dequantizes while staging (csrc/c_api.hip: quanto_hip_qbits_conv2d)."""
+def _conv_kernel_name(cin, k, s, d, w_in, p, wq="qint8", pixels=None, dense_min_tiles=8):
+    """8-bit weights: the row form or the tap gather; int4 / int2: dequantize once + the row form on the dense weight - from `dense_min_tiles`
+    128-pixel tiles on (`pixels` = B OH OW of the call; QUANTO_HIP_CONV_DENSE_MIN_TILES) -, or the tap gather that dequantizes while staging
+    (csrc/c_api.hip: quanto_hip_qbits_conv2d)."""
     rows = _row_form(cin, k, s, d, w_in, p, wq)
     if wq in ("qint4", "qint2"):
-        return ("conv2d_rows_dequant_" if rows else "conv2d_mfma_") + wq[1:]
+        dense = rows and pixels is not None and (pixels + 127) // 128 >= dense_min_tiles
+        return ("conv2d_rows_dequant_" if dense else "conv2d_mfma_") + wq[1:]
     return "conv2d_mfma_rows" if rows else "conv2d_mfma"
 
 
@@ -250,7 +252,7 @@ def test_qconv2d_int4_implicit_gemm_gpu(dt, zp, cin, cout, k, s, p, d, gs):
     x = torch.randn(3, cin, 13, 11).to(TORCH_DT[dt])
     with torch.no_grad():
         y = q(x.cuda())
-        assert quanto_hip.lib.last_kernel() == _conv_kernel_name(cin, k, s, d, 11, p, "qint4")
+        assert quanto_hip.lib.last_kernel() == _conv_kernel_name(cin, k, s, d, 11, p, "qint4", pixels=y.numel() // y.shape[1])
         wdq = _oracle_dequantized(q.weight, dt)
         assert torch.equal(q.weight.dequantize().cpu().double(), wdq)  # (and the device dequantize kernel agrees with the oracle bit for bit)
         prod = torch.nn.functional.conv2d(x.double(), wdq, None, conv.stride, conv.padding, conv.dilation)
@@ -320,7 +322,7 @@ def test_qconv2d_subbyte_implicit_gemm_ragged_k_and_qint2_gpu(dt, bits, zp, cin,
     with torch.no_grad():
         y = q(x.cuda())
         eligible = gs is None or gs % 8 == 0
-        assert (quanto_hip.lib.last_kernel() == _conv_kernel_name(cin, k, s, d, 13, p, f"qint{bits}")) == eligible, quanto_hip.lib.last_kernel()
+        assert (quanto_hip.lib.last_kernel() == _conv_kernel_name(cin, k, s, d, 13, p, f"qint{bits}", pixels=y.numel() // y.shape[1])) == eligible, quanto_hip.lib.last_kernel()
         prod = torch.nn.functional.conv2d(x.double(), _oracle_dequantized(q.weight, dt), None, conv.stride, conv.padding, conv.dilation)
     assert y.shape == prod.shape and y.dtype == TORCH_DT[dt]
     bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
@@ -495,9 +497,10 @@ SINGLE_ROW_FORM_GEOMETRIES = [(64, 96, 3, 2, 1, 1, (13, 12)),                   
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("wq", ["qint8", "qfloat8_e4m3fn", "qint4", "qint2"])
 @pytest.mark.parametrize("cin,cout,k,s,p,d,hw", SINGLE_ROW_FORM_GEOMETRIES)
-def test_qconv2d_row_form_one_pixel_per_thread_gpu(dt, wq, cin, cout, k, s, p, d, hw):
+def test_qconv2d_row_form_one_pixel_per_thread_gpu(monkeypatch, dt, wq, cin, cout, k, s, p, d, hw):
     """r5: three-tap-wide windows at ANY stride along the width / with an odd OW - the row form with one output pixel per thread and eight window
-    rows (int4 / int2: on the weight dequantized once).  Float64 gate as for the pair form."""
+    rows (int4 / int2: on the weight dequantized once - taken from 8 pixel tiles on; forced here for these small images).  Float64 gate as for the pair form."""
+    monkeypatch.setenv("QUANTO_HIP_CONV_DENSE_MIN_TILES", "1")
     torch.manual_seed(cin * 11 + cout)
     cout -= cout % 4
     conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, dilation=d).to(TORCH_DT[dt])
@@ -508,7 +511,7 @@ def test_qconv2d_row_form_one_pixel_per_thread_gpu(dt, wq, cin, cout, k, s, p, d
     sub = wq in ("qint4", "qint2")
     with torch.no_grad():
         y = q(x.cuda())
-        assert quanto_hip.lib.last_kernel() == _conv_kernel_name(cin, k, s, d, hw[1], p, wq) and "rows" in quanto_hip.lib.last_kernel()
+        assert quanto_hip.lib.last_kernel() == _conv_kernel_name(cin, k, s, d, hw[1], p, wq, pixels=y.numel() // y.shape[1], dense_min_tiles=1) and "rows" in quanto_hip.lib.last_kernel()
         if sub:
             prod = torch.nn.functional.conv2d(x.double(), _oracle_dequantized(q.weight, dt), None, conv.stride, conv.padding, conv.dilation)
         else:
@@ -525,6 +528,7 @@ def test_qconv2d_row_form_one_pixel_per_thread_gpu(dt, wq, cin, cout, k, s, p, d
 def test_qconv2d_row_form_pairs_and_single_pixels_agree_gpu(monkeypatch, wq, cin, cout, k, s, p, d, hw):
     """The two thread mappings of the row form stage the same LDS image and run the same MFMA sequence: on a geometry both can take
     (QUANTO_HIP_CONV_ROWS=3 forces one pixel per thread) the outputs must be identical bit for bit."""
+    monkeypatch.setenv("QUANTO_HIP_CONV_DENSE_MIN_TILES", "1")
     torch.manual_seed(cin + cout)
     cout -= cout % 4
     conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p, dilation=d).to(torch.bfloat16)
@@ -552,6 +556,7 @@ def test_qconv2d_subbyte_row_form_gpu(monkeypatch, dt, bits, zp, gs, cin, cout, 
     kh = k if isinstance(k, int) else k[0]
     if gs is not None and (cin * kh * 3) % gs:
         pytest.skip("group size does not divide K")
+    monkeypatch.setenv("QUANTO_HIP_CONV_DENSE_MIN_TILES", "1")  # (the product takes this route from 8 pixel tiles on; these images have 2 .. 19)
     qt = Q.qint4 if bits == 4 else Q.qint2
     cout -= cout % 4
     torch.manual_seed(cin + cout + bits)
