@@ -138,6 +138,29 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.quanto_hip_qbytes_mm_pick(4096, 4096, 4096, 3, 3, 2) == 6                         # int8 activations: native8
 
 
+def test_conv2d_entries_reject_bad_arguments_without_a_gpu():
+    """quanto_hip_q{bytes,bits}_conv2d check their geometry and pointers before anything is launched: inconsistent output sizes, zero strides,
+    null tensors -> EINVAL; non-float outputs -> ENOTSUP; an empty batch is a no-op."""
+    lib = quanto_hip.cdll
+    vp, i64, ci, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+    f = lib.quanto_hip_qbytes_conv2d
+    f.restype, f.argtypes = ci, [vp] * 5 + [i64] * 9 + [ci] * 9 + [vp, sz, vp]
+    geom = (1, 8, 8, 8, 8, 3, 3, 8, 8)  # B cin H W OC KH KW OH OW: 3 x 3, padding 1
+    assert f(None, None, None, None, None, *geom, 1, 1, 1, 1, 1, 1, 2, 3, 2, None, 0, None) == -1           # null tensors
+    assert f(None, None, None, None, None, 1, 8, 8, 8, 8, 3, 3, 7, 8, 1, 1, 1, 1, 1, 1, 2, 3, 2, None, 0, None) == -1  # OH does not follow from the geometry
+    assert f(None, None, None, None, None, *geom, 0, 1, 1, 1, 1, 1, 2, 3, 2, None, 0, None) == -1           # stride 0
+    assert f(None, None, None, None, None, *geom, 1, 1, 1, 1, 1, 0, 2, 3, 2, None, 0, None) == -1           # dilation 0
+    assert f(None, None, None, None, None, *geom, 1, 1, 1, 1, 1, 1, 2, 3, 3, None, 0, None) == -2           # int8 output
+    assert f(None, None, None, None, None, 0, 8, 8, 8, 8, 3, 3, 8, 8, 1, 1, 1, 1, 1, 1, 2, 3, 2, None, 0, None) == 0   # empty batch
+    g = lib.quanto_hip_qbits_conv2d
+    g.restype, g.argtypes = ci, [vp] * 6 + [i64] * 9 + [ci] * 10 + [vp, sz, vp]
+    assert g(None, None, None, None, None, None, *geom, 1, 1, 1, 1, 1, 1, 4, 0, 2, 2, None, 0, None) == -1  # null tensors
+    assert g(None, None, None, None, None, None, *geom, 1, 1, 1, 1, 1, 1, 3, 0, 2, 2, None, 0, None) == -1  # bits
+    assert g(None, None, None, None, None, None, *geom, 1, 1, 1, 1, 1, 1, 4, 50, 2, 2, None, 0, None) == -1  # K = 72 is not a multiple of the group size
+    assert g(None, None, None, None, None, None, 1, 8, 8, 8, 8, 3, 3, 8, 9, 1, 1, 1, 1, 1, 1, 4, 0, 2, 2, None, 0, None) == -1  # OW
+    assert g(None, None, None, None, None, None, 0, 8, 8, 8, 8, 3, 3, 8, 8, 1, 1, 1, 1, 1, 1, 4, 0, 2, 2, None, 0, None) == 0   # empty batch
+
+
 def test_conv2d_k_split_plan_without_a_gpu():
     """quanto_hip_conv2d_workspace_size is the host-side statement of the convolution kernel's K split (csrc/qconv_mfma.hip: pick_split): up to
     ~2 workgroups per CU, at least 4 K-tiles per split (r5; 3 until the gather got cheaper), no split beyond 128 output tiles; one 128 x 128 fp32 tile per (split, tile)."""
