@@ -440,6 +440,33 @@ def test_conv_row_form_model(case):
         assert model.lds_bank_model() == (1, 2, 2) and model.lds_bank_model_single() == 1
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_conv_row_form_model_random_geometries(seed):
+    """The row form's CPU model over random corner geometries: paddings up to 3 columns / rows, strides and height dilations up to 3, 1 .. 10 tap
+    rows, ragged pixel / channel / K tiles, up to 7 splits - both thread mappings wherever the geometry allows pixel pairs.  Besides the result the
+    model asserts that every in-range window lies inside the tensor and every selector picks a byte of the window."""
+    import importlib.util
+    import random
+
+    spec = importlib.util.spec_from_file_location("conv_rows_model", os.path.join(ROOT, "scripts", "models", "conv_rows_model.py"))
+    model = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(model)
+    rnd = random.Random(1000 + seed)
+    done = 0
+    while done < 6:
+        KH = rnd.choice([1, 2, 3, 3, 4, 5, 7, 10])
+        cin = rnd.choice([c for c in range(1, 41) if (c * KH) % 8 == 0][:4])
+        B, H, W, OC = rnd.choice([1, 2, 3]), rnd.randint(max(1, KH - 2), 8), rnd.randint(4, 12), rnd.choice([4, 12, 132])
+        sh, sw, ph, pw, dh, S = rnd.choice([1, 2, 3]), rnd.choice([1, 1, 2, 3]), rnd.randint(0, 3), rnd.randint(0, 3), rnd.choice([1, 2, 3]), rnd.choice([1, 2, 7])
+        OH, OW = (H + 2 * ph - dh * (KH - 1) - 1) // sh + 1, (W + 2 * pw - 3) // sw + 1
+        if OH < 1 or OW < 1:
+            continue
+        case = (B, cin, H, W, OC, KH, sh, ph, pw, dh, S, sw)
+        for single in ([False, True] if model.rows_pairs(OW, sw) else [True]):
+            assert model.run_case(case, seed=seed, single=single), (case, single)
+        done += 1
+
+
 ROW_FORM_GEOMETRIES = [(64, 96, 3, 1, 1, 1, (13, 12)),              # "same": both borders of every row, ragged M (3 x 13 x 12 pixels)
                        (64, 40, 3, (2, 1), (0, 2), 1, (9, 10)),        # two columns of padding (windows with two elements outside), stride 2 down
                        (32, 48, (5, 3), 1, (2, 1), (2, 1), (12, 8)),   # five tap rows, dilation 2 along the height
