@@ -36,7 +36,9 @@ Round 4 additions to the default line (all measured in the same process / on the
   * ``kernel_us`` / ``kernel_us_min``: kernel-only duration from a ``rocprofv3 --kernel-trace`` pass of this same file (a child
     process, ``--trace-child``; r5: one steady-state hipGraph replay), next to the launch-inclusive ``us_per_step``.  The profiler stamps a
     dispatch from the start of its set-up, which an unprofiled replay overlaps with the tail of the previous kernel (~0.5 us): for kernels
-    of a few us the average can therefore exceed ``us_per_step`` (north-star 4.7 vs 4.2); ``kernel_us_min`` (3.2) does not; ``traffic`` = fabric bytes per step from two more child
+    of a few us BOTH figures can therefore exceed ``us_per_step`` (r5 driver line, north-star: kernel_us_min 4.52 vs us_per_step 4.23; r6: no claim
+    is made for us-scale rows, and ``trace_floor_us`` = the shortest marker dispatch of the same trace - a 3-byte kernel - shows what the profiler
+    stamps for a kernel that does nothing); ``traffic`` = fabric bytes per step from two more child
     passes (``--pmc FETCH_SIZE`` / ``--pmc WRITE_SIZE``, corrected as MI355X_MICROARCH.md prescribes); when rocprofv3 is not usable the
     committed ``profiles/pmc_*.json`` figure is reported with ``traffic_stale: true``;
   * ``ref_rocm_us``: the op sequence the UNMODIFIED reference issues for the same call on a ROCm device (elementwise dequantize +
@@ -685,6 +687,24 @@ def run_cfg5(args, device, batches=(1, 32), prompt=512, new=512):
                 out[f"b{b}_ms_per_token"] = round(ms / new, 3)
             except Exception as e:
                 out[f"b{b}_error"] = repr(e)[:160]
+        # r6: the same model with the Python decode loop out of the way - the single-token forward on a static KV cache captured ONCE in a hipGraph and
+        # replayed per token (scripts/bench_generate.py, driver "graph": decode only, prefill reported separately): what the library's kernels are worth
+        # once the transformers loop no longer sets the pace
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import bench_generate as BG
+
+            for b in batches:
+                try:
+                    prefill_ms, decode_ms = BG.run(model, cfg, b, prompt, new, "graph", device)
+                    out[f"graph_b{b}_tok_s"] = round(b * new / (decode_ms * 1e-3), 1)
+                    out[f"graph_b{b}_ms_per_token"] = round(decode_ms / new, 3)
+                    out[f"graph_b{b}_prefill_warmup_capture_ms"] = round(prefill_ms, 1)
+                except Exception as e:
+                    out[f"graph_b{b}_error"] = repr(e)[:160]
+                torch.cuda.empty_cache()
+        except Exception as e:
+            out["graph_error"] = repr(e)[:160]
         # the binding's own share of a decode step: host time per eager QLinear.forward at the decode shape (2000 back-to-back calls: the
         # loop is host-bound, so wall time / calls = host cost per call), split by layer of the Python stack (scripts/host_overhead.py)
         try:
@@ -862,6 +882,10 @@ def collect_profiles(names, timeout_s=300):
     res = {}
     trace = _rocprof_pass(names, "trace", timeout_s)
     segs = _segments(trace, names) if trace else None
+    if trace:
+        marks = [(b - a) / 1e3 for k, a, b, _ in trace if MARKER in k]
+        if marks:
+            res["_trace_floor_us"] = round(min(marks), 3)  # what the profiler stamps for a kernel that does nothing (3-byte unpack launch)
     if segs:
         for n, seg in segs.items():
             per_step = len(seg) // TRACE_STEPS
@@ -920,14 +944,19 @@ def compact(r):
 # ------------------------------------------------------------------------------------------------------------------------
 # Batched decode: where the time of the split-K streaming kernel goes (its built-in ablation switches, csrc/qbits_skinny.hip)
 # ------------------------------------------------------------------------------------------------------------------------
-ABLATIONS = (("full", 0), ("no_tail", 1), ("no_tail_no_mfma", 3), ("no_tail_no_mfma_no_hbm", 31))
+# r6: bits 4 / 8 (DMA re-reads the first tile: L2 hits, no HBM) now reach the two-wave-set form the (32,4096,4096) call takes - r5's "no_hbm" rung still
+# streamed the weights - and the skeleton is taken apart further: 32 / 64 drop the activation / weight DMA instructions altogether, 128 returns at entry
+ABLATIONS = (("full", 0), ("no_tail", 1), ("no_tail_no_mfma", 3), ("no_tail_no_mfma_no_table", 19), ("no_tail_no_mfma_no_table_no_hbm", 31),
+             ("skeleton_no_x_dma", 31 + 32), ("skeleton_no_dma", 31 + 32 + 64), ("launch_only", 128))
 
 
 def ablate_child(name, args, device):
     """``--ablate-child``: a child process with the library's experiment knobs on (they are read only behind QUANTO_HIP_EXPERIMENT, which the
     parent - and the driver's command - does not set).  Times the same hipGraph replay with QUANTO_HIP_SKINNY_ABLATE = 0 (the product), 1 (no
     partial-sum store / arrival counter / reduce: every block but split 0 returns after its K loop), 3 (+ no MFMA / LDS-read work: the DMA stream
-    alone), 31 (+ every DMA re-reads tile 0: no HBM traffic, the launch + instruction-issue floor).  Results are WRONG by construction."""
+    alone), 19 (+ no scale / shift table), 31 (+ every DMA re-reads tile 0: L2 hits, no HBM traffic), 63 (+ no activation DMA instruction), 127 (+ no
+    weight DMA either: prologue, barriers and loop control only), 128 (the kernel returns at entry: launch + grid dispatch).  Differences between
+    neighbouring rungs = the ``skeleton_breakdown`` the r5 review asked for.  Results are WRONG by construction."""
     kind, M, K, N, _ = WORKLOADS[name]
     Nt = sum(N) if isinstance(N, tuple) else N
     n_weights = max(1, -(-(512 << 20) // (Nt * K // 2)))
@@ -1081,8 +1110,8 @@ def main():
             apply_profile(out, prof.get(args.workload), compacted=False)
             for sr in sub_results:
                 apply_profile(sr, prof.get(sr["name"]), compacted=True)
-            out["profile_passes"] = {"ok": bool(prof), "seconds": round(time.perf_counter() - t_prof, 1),
-                                     "what": "rocprofv3 child runs of this file: --kernel-trace of one steady-state hipGraph replay (kernel_us = begin-to-end per dispatch as the profiler stamps it, ~0.5 us of dispatch set-up included that an unprofiled replay overlaps with the previous kernel: on us-scale kernels it can exceed us_per_step, kernel_us_min does not), --pmc FETCH_SIZE / WRITE_SIZE (traffic, FETCH x2: gfx950)"}
+            out["profile_passes"] = {"ok": bool(prof), "seconds": round(time.perf_counter() - t_prof, 1), "trace_floor_us": prof.get("_trace_floor_us"),
+                                     "what": "rocprofv3 child runs of this file: --kernel-trace of one steady-state hipGraph replay (kernel_us / kernel_us_min = begin-to-end per dispatch as the profiler stamps it, dispatch set-up included that an unprofiled replay overlaps with the previous kernel: on us-scale kernels both can exceed us_per_step; trace_floor_us = the shortest marker dispatch, a kernel that does nothing), --pmc FETCH_SIZE / WRITE_SIZE (traffic, FETCH x2: gfx950)"}
         if world == 1 and rank == 0 and default_run and not args.no_cfg5 and out is not None:
             try:
                 rec = run_cfg5(args, device)

@@ -82,6 +82,7 @@ typedef enum {
 #define QUANTO_HIP_GEMV_MAX_M 8         /* qbytes_mm: rows of x the GEMV kernel accepts                    */
 #define QUANTO_HIP_SKINNY_MAX_M 256      /* qbits_mm: rows of x the streaming MFMA kernel accepts (passes of 64) */
 #define QUANTO_HIP_GEMV_MAX_M_QBITS 64  /* qbits_mm: ditto (passes of up to 8 rows; weights re-read from MALL) */
+#define QUANTO_HIP_GEMV_F32_MAX_M 8     /* fp32 activations (r6, csrc/qmm_f32.hip): rows the fp32 weight-streaming kernel takes (passes of 4); beyond: fp32 MFMA tiles */
 #define QUANTO_HIP_GEMV_MAX_M_OTHER 24  /* qbits_mm, formats / shapes the streaming kernel's 64-feature blocks do not fit (group sizes 96 / 64 / 32, per-channel, qint2): passes of 4 rows */
 
 int quanto_hip_abi_version(void);
@@ -324,6 +325,15 @@ int quanto_hip_qbits_conv2d(const void* x, const uint8_t* packed, const void* sc
  * activation dtype for the dense weight of the row form, rounded up to 256 bytes.  Plain scratch, nothing to zero.  -1 on invalid arguments.
  */
 int64_t quanto_hip_qbits_conv2d_workspace_size(int64_t B, int64_t OH, int64_t OW, int64_t OC, int64_t K);
+
+/*
+ * The same with the window geometry (r6): the dense-weight bytes are counted only when quanto_hip_qbits_conv2d can take the row form for this
+ * convolution (three taps wide at dilation 1 along the width, W >= 4, cin * KH a multiple of 8, at least 8 tiles of 128 output pixels) - a
+ * caller that sizes its scratch with quanto_hip_qbits_conv2d_workspace_size reserves OC * K elements for every int4 / int2 convolution,
+ * including the ones that can only run the tap kernel.  -1 on invalid arguments.
+ */
+int64_t quanto_hip_qbits_conv2d_workspace_size_geom(int64_t B, int64_t cin, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW,
+                                                    int stride_w, int dil_w);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,16 @@ int qbits_mm_mfma_fused(const void*, const uint8_t*, const void*, const void*, c
 bool qbits_mfma_large_supported(int64_t, const PackedGeom&, int);
 int qbits_mm_mfma_large(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, hipStream_t);
 
+// fp32 activations (r6, qmm_f32.hip)
+bool qbits_gemv_f32_supported(int64_t, const PackedGeom&, int);
+bool qbits_mm_f32_supported(int64_t, const PackedGeom&, int);
+int qbits_mm_gemv_f32(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, hipStream_t);
+int qbits_mm_f32(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, bool, hipStream_t);
+bool qbytes_gemv_f32_supported(int64_t, int64_t, int64_t, int, int, int);
+bool qbytes_mm_f32_supported(int64_t, int64_t, int64_t, int, int, int);
+int qbytes_mm_gemv_f32(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
+int qbytes_mm_f32(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
+
 static bool is_float_dtype(int dt) { return dt == QUANTO_HIP_F32 || dt == QUANTO_HIP_F16 || dt == QUANTO_HIP_BF16; }
 
 static int check_qbits(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype, int shift_dtype, bool* int_shift) {
@@ -155,6 +165,13 @@ static bool large4_wins(int64_t M, const PackedGeom& g, bool have_workspace) {
 }
 
 static int pick_qbits_kernel(int64_t M, const PackedGeom& g, int dtype, bool have_workspace) {
+  if (dtype == QUANTO_HIP_F32) {
+    // fp32 activations (r6): the weight stream with fp32 arithmetic up to 8 rows, fp32 MFMA tiles beyond (qmm_f32.hip); K % 16 / % 32 != 0
+    // and group sizes that are not a multiple of 16 keep the one-thread-per-output kernel
+    if (qbits_gemv_f32_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
+    if (qbits_mm_f32_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MFMA;
+    return QUANTO_HIP_KERNEL_NAIVE;
+  }
   if (M <= env_int("QUANTO_HIP_GEMV_MAX_M", 4) && qbits_gemv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_GEMV;
   if (mmv_wins(M, g) && qbits_mmv_supported(M, g, dtype)) return QUANTO_HIP_KERNEL_MMV;
   if (fused4_wins(M, g) && qbits_mfma_fused_supported(M, g, dtype) && (have_workspace || !qbits_mfma_fused_needs_workspace(g)))
@@ -289,7 +306,7 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
     kernel = pick_qbits_kernel(M, g, dtype, workspace != nullptr);
     if (kernel == QUANTO_HIP_KERNEL_DEQUANT_MFMA && workspace_bytes < dequant_mfma_workspace(g))
       kernel = qbits_mfma_supported(M, g, dtype) ? QUANTO_HIP_KERNEL_MFMA : QUANTO_HIP_KERNEL_NAIVE;
-    if (kernel == QUANTO_HIP_KERNEL_MFMA && workspace_bytes < qbits_mfma_workspace(M, g)) kernel = QUANTO_HIP_KERNEL_NAIVE;
+    if (kernel == QUANTO_HIP_KERNEL_MFMA && dtype != QUANTO_HIP_F32 && workspace_bytes < qbits_mfma_workspace(M, g)) kernel = QUANTO_HIP_KERNEL_NAIVE;
   }
   int r;
   switch (kernel) {
@@ -298,10 +315,20 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
       if (r == QUANTO_HIP_OK) set_last_kernel("naive");
       return r;
     case QUANTO_HIP_KERNEL_GEMV:
+      if (dtype == QUANTO_HIP_F32) {
+        r = qbits_mm_gemv_f32(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, stream);
+        if (r == QUANTO_HIP_OK) set_last_kernel("gemv_f32");
+        return r;
+      }
       r = qbits_mm_gemv(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("gemv");
       return r;
     case QUANTO_HIP_KERNEL_MFMA:
+      if (dtype == QUANTO_HIP_F32) {  // fp32 MFMA tiles: no workspace
+        r = qbits_mm_f32(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, stream);
+        if (r == QUANTO_HIP_OK) set_last_kernel("mfma_f32");
+        return r;
+      }
       r = qbits_mm_mfma(x, packed, scale, shift, bias, y, M, g, dtype, int_shift, workspace, workspace_bytes, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("mfma");
       return r;
@@ -421,6 +448,11 @@ int quanto_hip_qbits_mm_multi(const void* x, int count, const uint8_t* const* pa
 //   M <= 256  streaming kernel in passes of 64 rows (few, long tiles: (256, 4096, 14336) 107 us vs 127 us tiled);
 //   else the large-tile kernel whenever it applies, the register-staged 128x128 kernel, the naive kernel.
 static int pick_qbytes_kernel(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
+  if (a_dtype == QUANTO_HIP_F32 && out_dtype == QUANTO_HIP_F32) {  // fp32 activations (r6, qmm_f32.hip)
+    if (qbytes_gemv_f32_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_KERNEL_GEMV;
+    if (qbytes_mm_f32_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_KERNEL_MFMA;
+    return QUANTO_HIP_KERNEL_NAIVE;
+  }
   if (M <= 2 && qbytes_gemv_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_KERNEL_GEMV;
   if (qbytes_native8_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_KERNEL_NATIVE8;
   const bool skinny = qbytes_skinny_supported(M, N, K, a_dtype, b_dtype, out_dtype);
@@ -484,6 +516,11 @@ int quanto_hip_qbytes_mm_ws(const void* a, const void* b, const void* scales, co
       if (r == QUANTO_HIP_OK) set_last_kernel("naive");
       return r;
     case QUANTO_HIP_KERNEL_GEMV:
+      if (a_dtype == QUANTO_HIP_F32 && out_dtype == QUANTO_HIP_F32) {
+        r = qbytes_mm_gemv_f32(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
+        if (r == QUANTO_HIP_OK) set_last_kernel("gemv_f32");
+        return r;
+      }
       r = qbytes_mm_gemv(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("gemv");
       return r;
@@ -492,6 +529,11 @@ int quanto_hip_qbytes_mm_ws(const void* a, const void* b, const void* scales, co
       if (r == QUANTO_HIP_OK) set_last_kernel("skinny");
       return r;
     case QUANTO_HIP_KERNEL_MFMA:
+      if (a_dtype == QUANTO_HIP_F32 && out_dtype == QUANTO_HIP_F32) {
+        r = qbytes_mm_f32(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
+        if (r == QUANTO_HIP_OK) set_last_kernel("mfma_f32");
+        return r;
+      }
       r = qbytes_mm_mfma(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("mfma");
       return r;
@@ -619,6 +661,23 @@ int64_t quanto_hip_qbits_conv2d_workspace_size(int64_t B, int64_t OH, int64_t OW
   return split + (int64_t)conv2d_dense_weight_bytes(OC, K);
 }
 
+static bool qbits_conv2d_takes_rows(int64_t B, int64_t cin, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_w, int dil_w) {
+  // (the tap kernel dequantizes the whole weight once per 128-pixel tile; one dequantize launch pays from ~8 pixel tiles on: (8,512,7,7) -> 512, 4 of
+  // them, 28.8 us on the tap kernel against 30.2 this way, (32,512,7,7), 13 tiles, 44.3 against 40.3 - profiles/r05_qconv2d_rows_one_pixel_ab.jsonl)
+  const int64_t pixel_tiles = (B * OH * OW + 127) / 128;
+  return conv2d_rows_eligible(cin, KH, KW, W, OW, stride_w, dil_w, OC) && pixel_tiles >= env_int("QUANTO_HIP_CONV_DENSE_MIN_TILES", 8);
+}
+
+int64_t quanto_hip_qbits_conv2d_workspace_size_geom(int64_t B, int64_t cin, int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW,
+                                                    int stride_w, int dil_w) {
+  if (cin <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride_w <= 0 || dil_w <= 0) return -1;
+  const int64_t K = cin * KH * KW;
+  const int64_t split = quanto_hip_conv2d_workspace_size(B, OH, OW, OC, K);
+  if (split < 0) return split;
+  if (B == 0 || OH == 0 || OW == 0) return 0;
+  return split + (qbits_conv2d_takes_rows(B, cin, W, OC, KH, KW, OH, OW, stride_w, dil_w) ? (int64_t)conv2d_dense_weight_bytes(OC, K) : 0);
+}
+
 int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, const void* bias, void* y, int64_t B, int64_t cin, int64_t H,
                              int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,
                              int pad_w, int dil_h, int dil_w, int a_dtype, int b_dtype, int out_dtype, void* workspace, size_t workspace_bytes,
@@ -651,10 +710,7 @@ int quanto_hip_qbits_conv2d(const void* x, const uint8_t* packed, const void* sc
   const PackedGeom g = make_geom(OC, K, bits, group_size);
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   const size_t dense = conv2d_dense_weight_bytes(OC, K);
-  // (the tap kernel dequantizes the whole weight once per 128-pixel tile; one dequantize launch pays from ~8 pixel tiles on: (8,512,7,7) -> 512, 4 of
-  // them, 28.8 us on the tap kernel against 30.2 this way, (32,512,7,7), 13 tiles, 44.3 against 40.3 - profiles/r05_qconv2d_rows_one_pixel_ab.jsonl)
-  const int64_t pixel_tiles = (B * OH * OW + 127) / 128;
-  if (conv2d_rows_eligible(cin, KH, KW, W, OW, stride_w, dil_w, OC) && pixel_tiles >= env_int("QUANTO_HIP_CONV_DENSE_MIN_TILES", 8) && workspace &&
+  if (qbits_conv2d_takes_rows(B, cin, W, OC, KH, KW, OH, OW, stride_w, dil_w) && workspace &&
       workspace_bytes >= dense && reinterpret_cast<uintptr_t>(workspace) % 16 == 0 && is_float_dtype(dtype) && dtype != QUANTO_HIP_F32) {
     // three-tap-wide windows at stride 1: dequantize once (the reference's own dense weight), then the row form of the convolution on it
     int r = dequantize_qbits_dispatch(packed, scale, shift, workspace, g, dtype, int_shift, hs);

@@ -78,6 +78,14 @@ __device__ __forceinline__ float quad_bcast(float v) {
 
 constexpr int RR = 4;  // packed rows per wave pass
 
+// r6: the load-order / ablation variants (QUANTO_HIP_GEMV_VARIANT = 1, 3, 4, 6) and the 8-rows-per-pass form (QUANTO_HIP_GEMV_RR=8), measured in r2 / r3
+// and never the product choice, are compiled into probe builds only (-DQH_GEMV_EXPERIMENTS): 50 of this file's 258 instantiations
+#ifdef QH_GEMV_EXPERIMENTS
+constexpr bool QH_GEMV_EXPERIMENTS_ON = true;
+#else
+constexpr bool QH_GEMV_EXPERIMENTS_ON = false;
+#endif
+
 // Several Linears that share the same input (q/k/v, gate/up of a decoder layer) in ONE launch: a decode-shaped call lasts
 // 4-8 us of which ~3 us are launch + first-byte latency, so every launch that disappears is worth about one small Linear.
 // The weights stay separate allocations (the reference's modules are untouched): the kernel gets a table of segments and
@@ -451,7 +459,7 @@ static int gemv_launch_iters(const void* x, const GemvProblem& pb, int m0, int K
   const int gshift = pb.gs == 0 ? 30 : pb.gs == 96 ? -1 : pb.gs == 32 ? 5 : pb.gs == 64 ? 6 : 7;
 #define QH_LAUNCH_VM(IT, V, MULTI)                                                                                                     \
   do {                                                                                                                                \
-    if constexpr (MT <= 2 && IT == 1 && ((V) == 0 || (V) == 2)) {                                                                     \
+    if constexpr (QH_GEMV_EXPERIMENTS_ON && MT <= 2 && IT == 1 && ((V) == 0 || (V) == 2)) {                                            \
       if (rr == 8) {                                                                                                                  \
         hipLaunchKernelGGL((qbits_gemv_g128_kernel<DT, MT, IT, INT_SHIFT, V, MULTI, 8>), dim3(grid), dim3(256), 0, stream, xs, segs, K, \
                            wpr_log2, gshift);                                                                                         \
@@ -480,7 +488,7 @@ static int gemv_launch_iters(const void* x, const GemvProblem& pb, int m0, int K
       if constexpr (MT <= 4) QH_LAUNCH_VM(IT, 24, false); \
     } else if (pb.gs != 128) {                  \
       if constexpr (MT <= 4) QH_LAUNCH_VM(IT, 8, false); \
-    } else if constexpr (HAS_VARIANTS) {        \
+    } else if constexpr (HAS_VARIANTS && QH_GEMV_EXPERIMENTS_ON) { \
       switch (gemv_variant()) {                 \
         case 1: QH_LAUNCH_V(IT, 1); break;      \
         case 2: QH_LAUNCH_V(IT, 2); break;      \
@@ -489,6 +497,8 @@ static int gemv_launch_iters(const void* x, const GemvProblem& pb, int m0, int K
         case 6: QH_LAUNCH_V(IT, 6); break;      \
         default: QH_LAUNCH_V(IT, 0); break;     \
       }                                         \
+    } else if constexpr (HAS_VARIANTS) {        \
+      QH_LAUNCH_V(IT, QUANTO_HIP_GEMV_DEFAULT_VARIANT); /* non-temporal weight loads */ \
     } else {                                    \
       QH_LAUNCH_V(IT, 0);                       \
     }                                           \

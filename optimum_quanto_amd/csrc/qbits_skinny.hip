@@ -103,7 +103,8 @@ struct Args {
   int tk;           // k per tile: 128, or 96 (group size 96)
   int nt;           // non-temporal weight DMA (single-pass calls: M <= 64)
   // QUANTO_HIP_SKINNY_ABLATE (timing experiments, WRONG results): 1 no split-K reduction, 2 no MFMA/LDS-read work,
-  // 4 no activation DMA, 8 no weight DMA, 16 no scale/shift table
+  // 4 activation DMA re-reads tile 0 (L2 hits), 8 weight DMA re-reads tile 0 (no HBM traffic), 16 no scale/shift table;
+  // r6, the skeleton itself: 32 no activation DMA instruction at all, 64 no weight DMA instruction at all, 128 return at entry (launch floor)
   int ablate;
   // QUANTO_HIP_SKINNY_TIMELINE=<device address of 32 x uint64 per block>: thread 0 of every block stamps s_memtime at the
   // phase boundaries (scripts/skinny_timeline.py); null in production
@@ -168,6 +169,7 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   };
   probe(0);
   if (a.tl && tid == 0) a.tl[blockIdx.x * 32 + 30] = wall_clock64();
+  if (a.ablate & 128) return;
   const int S = a.S;
   const int fbg = S > 1 ? blockIdx.x / S : blockIdx.x, sp = S > 1 ? blockIdx.x - fbg * S : 0;  // global feature block
   int fb = fbg;
@@ -217,7 +219,7 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
     const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
     // ablations keep the instruction count per tile (vmcnt arithmetic) and re-read tile 0 instead: L2 hits
     const int ktw = (a.ablate & 8) ? 0 : kt, ktx = (a.ablate & 4) ? 0 : kt;
-    if (w_lane) {
+    if (w_lane && !(a.ablate & 64)) {
       if (a.nt)
         glds16_nt(wsrc + (size_t)ktw * TK, st + wave * (RPW * BK));
       else
@@ -225,7 +227,7 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
     }
 #pragma unroll
     for (int u = 0; u < XP; ++u)
-      if (TK == 128 || x_valid[u]) glds16(xsrc[u] + (size_t)ktx * (TK * 2), st + W_BYTES + (wave * XP + u) * 1024);
+      if ((TK == 128 || x_valid[u]) && !(a.ablate & 32)) glds16(xsrc[u] + (size_t)ktx * (TK * 2), st + W_BYTES + (wave * XP + u) * 1024);
   };
   // SETS = 2: the pieces of a PAIR of tiles (even tile -> stage sa, odd tile -> stage sb) dealt over the eight waves: wave (set,
   // f) carries weight piece f of the tile of its set and the activation pieces q = wave_id * TF + j of the 8 TF of the pair
@@ -247,17 +249,19 @@ __global__ void __launch_bounds__(WAVES * SETS * 64) qbits_skinny_kernel(Args a,
   auto issue_pair = [&](int kt, int sa, int sb) {  // kt even; the odd tile exists when kt + 1 < nk
     const uint32_t sta = __builtin_amdgcn_readfirstlane(lds_base + sa * STAGE_BYTES), stb = __builtin_amdgcn_readfirstlane(lds_base + sb * STAGE_BYTES);
     const bool has_odd = kt + 1 < nk;
-    if ((set == 0 || has_odd) && w_lane) {
+    const int ktw = (a.ablate & 8) ? 0 : kt + set, ktx = (a.ablate & 4) ? 0 : kt;  // ablations: re-read the first tile (pair) instead: L2 hits
+    if ((set == 0 || has_odd) && w_lane && !(a.ablate & 64)) {
       const uint32_t st = set == 0 ? sta : stb;
       if (a.nt)
-        glds16_nt(wsrc + (size_t)(kt + set) * TK, st + wave * (RPW * BK));
+        glds16_nt(wsrc + (size_t)ktw * TK, st + wave * (RPW * BK));
       else
-        glds16(wsrc + (size_t)(kt + set) * TK, st + wave * (RPW * BK));
+        glds16(wsrc + (size_t)ktw * TK, st + wave * (RPW * BK));
     }
 #pragma unroll
     for (int j = 0; j < (SETS == 2 ? TF : 0); ++j) {
       const bool odd = xdst2[j] >> 31;
-      if ((!odd || has_odd) && (TK == 128 || x_valid2[j])) glds16(xsrc2[j] + (size_t)kt * (TK * 2), (odd ? stb : sta) + (xdst2[j] & 0x7FFFFFFFu));
+      if ((!odd || has_odd) && (TK == 128 || x_valid2[j]) && !(a.ablate & 32))
+        glds16(xsrc2[j] + (size_t)ktx * (TK * 2), (odd ? stb : sta) + (xdst2[j] & 0x7FFFFFFFu));
     }
   };
   if constexpr (SETS == 2) {
@@ -558,11 +562,11 @@ static int launch_s(const Args& a, hipStream_t stream, const Segs* segs = nullpt
     // 17.6 -> 15.7, (32,14336,4096) 18.5 -> 17.7, gate+up M = 32 in one launch 29.5 -> 26.6; but one fragment, q/k/v M = 8:
     // 9.87 -> 10.52: too little work per tile to share; the 8-bit kernel of qbytes_skinny.hip gains nothing: int8 (32,4096,4096)
     // 10.95 -> 10.96, gate+up in one launch 26.5 -> 26.7 - four times the weight bytes per tile, no group fold)
-    const bool two_sets = env_int("QUANTO_HIP_SKINNY_SETS", TF >= 2 ? 2 : 1) == 2;
-    if (segs)
-      return two_sets ? launch_k<DT, TF, STAGES, INT_SHIFT, 4, true, 2>(a, stream, *segs, total_fb * a.S, lds)
-                      : launch_k<DT, TF, STAGES, INT_SHIFT, 4, true, 1>(a, stream, *segs, total_fb * a.S, lds);
-    if (two_sets) return launch_k<DT, TF, STAGES, INT_SHIFT, 4, false, 2>(a, stream, Segs{}, a.N / 64 * a.S, lds);
+    // r6: the choice is a compile-time one (the other wave-set count of each TF was reachable through QUANTO_HIP_SKINNY_SETS only and doubled
+    // the 64-feature-block instantiations of this file)
+    constexpr int SETS = TF >= 2 ? 2 : 1;
+    if (segs) return launch_k<DT, TF, STAGES, INT_SHIFT, 4, true, SETS>(a, stream, *segs, total_fb * a.S, lds);
+    if constexpr (SETS == 2) return launch_k<DT, TF, STAGES, INT_SHIFT, 4, false, 2>(a, stream, Segs{}, a.N / 64 * a.S, lds);
   }
   return launch_k<DT, TF, STAGES, INT_SHIFT, WAVES, false, 1>(a, stream, Segs{}, a.N / (16 * WAVES) * a.S, lds);
 }
@@ -587,7 +591,8 @@ static int launch(const Args& a, hipStream_t stream, const Segs* segs = nullptr,
 // not by the number of occupied CUs - what it lacks for N <= 4096 is K-parallelism.
 inline int pick_waves(int N, int tf = 1) {
   const int forced = env_int("QUANTO_HIP_SKINNY_WAVES", 0);  // experiments
-  if (forced == 8 && tf >= 2 && N % 128 == 0) return 8;  // 128 features per block: half the activation traffic per weight byte
+  // (r5 experiment, withdrawn in r6: forced == 8 -> 128 features per block - half the activation traffic per weight byte, twice the partial
+  //  sums: (32,4096,4096) 11.0 vs 9.5 us, profiles/r05_batched_decode_128_feature_blocks_ab.jsonl; patch: scripts/archive/experiments_r6/)
   if (forced == 1 || forced == 2 || forced == 4) return (N % (16 * forced)) == 0 ? forced : 1;
   return N % 64 == 0 ? 4 : (N % 32 == 0 ? 2 : 1);
 }
@@ -596,8 +601,6 @@ template <int DT, bool INT_SHIFT, int TF>
 static int launch_waves(const Args& a, hipStream_t stream, const Segs* segs = nullptr, int total_fb = 0) {
   if (segs) return launch<DT, TF, INT_SHIFT, 4>(a, stream, segs, total_fb);
   const int w = pick_waves(a.N, TF);
-  if constexpr (TF >= 2)
-    if (w == 8) return launch<DT, TF, INT_SHIFT, 8>(a, stream);
   if (w == 4) return launch<DT, TF, INT_SHIFT, 4>(a, stream);
   if (w == 2) return launch<DT, TF, INT_SHIFT, 2>(a, stream);
   return launch<DT, TF, INT_SHIFT, 1>(a, stream);

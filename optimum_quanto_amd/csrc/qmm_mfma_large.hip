@@ -547,9 +547,20 @@ static int launch(const Args& a, int cfg, hipStream_t stream) {
   //  r3: 128 tokens x 256 features as eight weights-direct waves of 128 x 32 - a third fewer fetched bytes per flop - with K split 2 ways
   //  so that cfg4 still covers 256 CUs: 68.2 us against 59.7 on the same box (unsplit on 128 CUs 86 us: 64 % MFMA utilisation instead
   //  of 50 %, but the partial-tile pass of 32 MB costs more than the better loop gains))
+  // r6: the product library carries what the dispatch can reach.  The 2 x 2 layout (four waves of 128 x 128, hipcc-allocated AGPR accumulators:
+  // 15-98 spilled VGPRs, 159.9 us on cfg2 against 102.4, profiles/r05_cfg2_wave_layouts_ab.jsonl) is built by probes only (-DQH_LT_EXPERIMENTS,
+  // scripts/probes/README.md); e4m3fnuz exists as 1 x 8 only - its patched-pattern converter spills 25-33 VGPRs in the 2 x 4 layout
+#ifdef QH_LT_EXPERIMENTS
   if (cfg == CFG_256_4W) return launch_cfg<DT, FMT, 256, 256, 2, 2>(a, stream);
-  if (cfg == CFG_256_1X8) return launch_cfg<DT, FMT, 256, 256, 1, 8>(a, stream);
-  return launch_cfg<DT, FMT, 256, 256, 2, 4>(a, stream);
+#else
+  if (cfg == CFG_256_4W) return QUANTO_HIP_ENOTSUP;
+#endif
+  if constexpr (FMT == W_F8E4M3FNUZ) {
+    return launch_cfg<DT, FMT, 256, 256, 1, 8>(a, stream);
+  } else {
+    if (cfg == CFG_256_1X8) return launch_cfg<DT, FMT, 256, 256, 1, 8>(a, stream);
+    return launch_cfg<DT, FMT, 256, 256, 2, 4>(a, stream);
+  }
 }
 
 }  // namespace lt

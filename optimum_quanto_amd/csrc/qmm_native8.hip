@@ -712,17 +712,19 @@ static int launch(const Args& a, hipStream_t stream) {
   // int8 (768,8192) 43 -> 44, (1024,8192) 50 -> 56; fp8 (768,8192) 51 -> 39, (1024,8192) 56 -> 47, (1280,8192) 56 -> 68
   const int small_env = env_int("QUANTO_HIP_NATIVE8_SMALL", -1);  // experiments
   const int64_t tiles256 = (int64_t)((a.N + 255) / 256) * ((a.M + 255) / 256), tiles128 = (int64_t)((a.N + 127) / 128) * ((a.M + 127) / 128);
-  // the paired loop pays off only where one instruction consumes both tiles (fp8); as two MFMAs per pair it measured
-  // slower than the per-tile loop (int8 4096^3: 72 vs 66 us; dense bf16: 135 vs 127 us) - QUANTO_HIP_PAIRED=1 forces it
   constexpr int ES = (KIND == K_BF16 || KIND == K_F16) ? 2 : 1;
   constexpr bool FP8 = KIND == K_F8E4M3 || KIND == K_F8E5M2;
-  const int paired_env = env_int("QUANTO_HIP_PAIRED", -1);  // experiments
-  const bool paired = (paired_env == 1 || (FP8 && paired_env != 0)) && (a.K * ES) % 128 == 0;
-  const bool small = small_env >= 0 ? small_env != 0 : (FP8 && paired ? tiles128 <= 512 : tiles256 < 96);
+  const bool small = small_env >= 0 ? small_env != 0 : (FP8 && (a.K * ES) % 128 == 0 ? tiles128 <= 512 : tiles256 < 96);
   // 128-byte rows (full-line vector-L1 fills, one barrier per 128 bytes of K) whenever K allows
   if ((a.K * ES) % 128 == 0 && env_int("QUANTO_HIP_NATIVE8_ROW128", 1) != 0)
     return small ? launch_r128<ODT, KIND, true>(a, stream) : launch_r128<ODT, KIND, false>(a, stream);
-  if (paired) return small ? launch_cfg<ODT, KIND, true, true>(a, stream) : launch_cfg<ODT, KIND, true, false>(a, stream);
+  // 64-byte rows: K * element size = 64 (mod 128).  (r6: the PAIRED instantiations of this kernel - two 64-byte tiles per K = 128 MX-format MFMA - were
+  // reachable only where the 128-byte-row kernel applies as well, i.e. through QUANTO_HIP_NATIVE8_ROW128=0, and left the product library; the
+  // loop stays in the source for probes built with -DQH_N8_EXPERIMENTS)
+#ifdef QH_N8_EXPERIMENTS
+  if (FP8 && (a.K * ES) % 128 == 0 && env_int("QUANTO_HIP_PAIRED", 1) != 0)
+    return small ? launch_cfg<ODT, KIND, true, true>(a, stream) : launch_cfg<ODT, KIND, true, false>(a, stream);
+#endif
   return small ? launch_cfg<ODT, KIND, false, true>(a, stream) : launch_cfg<ODT, KIND, false, false>(a, stream);
 }
 

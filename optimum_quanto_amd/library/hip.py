@@ -8,6 +8,7 @@ output with the input's options and return it by value - the reference's C++ con
 """
 import ctypes
 import os
+import re
 
 import torch
 
@@ -20,7 +21,14 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # quanto_hip_dtype (include/quanto_hip.h)
 F32, F16, BF16, I8, U8, F8_E4M3FN, F8_E5M2, F8_E4M3FNUZ = range(8)
 WS_COUNTER_BYTES = 4096  # QUANTO_HIP_WS_COUNTER_BYTES
-_EXPERIMENT = os.environ.get("QUANTO_HIP_EXPERIMENT", "0") not in ("", "0")  # the library's knobs are live: plans are not cached
+def _c_atoi(v: str) -> int:
+    """The value C's ``atoi`` reads from an environment string (csrc/qh_common.h parses the knobs with it): optional blanks, a sign, leading
+    digits; anything else is 0 - so that "01", "1 " or "true" mean the same thing on both sides of the binding."""
+    m = re.match(r"\s*([+-]?\d+)", v or "")
+    return int(m.group(1)) if m else 0
+
+
+_EXPERIMENT = _c_atoi(os.environ.get("QUANTO_HIP_EXPERIMENT", "0")) != 0  # the library's knobs are live: plans are not cached
 KERNEL_AUTO, KERNEL_NAIVE, KERNEL_GEMV, KERNEL_MFMA, KERNEL_MFMA_LARGE, KERNEL_SKINNY, KERNEL_NATIVE8, KERNEL_DEQUANT_MFMA, KERNEL_MFMA_FUSED4, KERNEL_MMV, KERNEL_MFMA_LARGE4 = range(11)
 KERNELS = {"auto": KERNEL_AUTO, "naive": KERNEL_NAIVE, "gemv": KERNEL_GEMV, "mfma": KERNEL_MFMA, "mfma_large": KERNEL_MFMA_LARGE, "skinny": KERNEL_SKINNY,
            "mfma_native8": KERNEL_NATIVE8, "dequant_mfma": KERNEL_DEQUANT_MFMA, "mfma_fused4": KERNEL_MFMA_FUSED4, "mmv": KERNEL_MMV, "mfma_large4": KERNEL_MFMA_LARGE4}
@@ -144,6 +152,8 @@ class _Bindings:
         c.quanto_hip_conv2d_workspace_size.argtypes = [i64] * 5
         c.quanto_hip_qbits_conv2d_workspace_size.restype = i64
         c.quanto_hip_qbits_conv2d_workspace_size.argtypes = [i64] * 5
+        c.quanto_hip_qbits_conv2d_workspace_size_geom.restype = i64
+        c.quanto_hip_qbits_conv2d_workspace_size_geom.argtypes = [i64] * 8 + [ci] * 2
         c.quanto_hip_qbits_conv2d.restype = ci
         c.quanto_hip_qbits_conv2d.argtypes = [vp] * 6 + [i64] * 9 + [ci] * 10 + [vp, ctypes.c_size_t, vp]
         self._c = c
@@ -284,11 +294,14 @@ class _Bindings:
     def conv2d_out_size(size, k, stride, pad, dil):
         return (size + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
-    def _conv2d_scratch(self, x, B, OH, OW, OC, K, qbits=False):
-        """(buffer, bytes) for the convolution kernels' K split (sub-byte weights: plus the dense weight of the row form) - plain scratch, nothing
-        to zero; (None, 0) when the problem needs none."""
-        size = self._c.quanto_hip_qbits_conv2d_workspace_size if qbits else self._c.quanto_hip_conv2d_workspace_size
-        nbytes = int(size(B, max(OH, 0), max(OW, 0), OC, K))
+    def _conv2d_scratch(self, x, B, OH, OW, OC, K, geom=None):
+        """(buffer, bytes) for the convolution kernels' K split - plain scratch, nothing to zero; (None, 0) when the problem needs none.  ``geom`` =
+        (cin, W, KH, KW, stride_w, dil_w) of a sub-byte weight: plus the dense weight of the row form, when THIS geometry can take it."""
+        if geom is None:
+            nbytes = int(self._c.quanto_hip_conv2d_workspace_size(B, max(OH, 0), max(OW, 0), OC, K))
+        else:
+            cin, W, KH, KW, sw, dw = geom
+            nbytes = int(self._c.quanto_hip_qbits_conv2d_workspace_size_geom(B, cin, W, OC, KH, KW, max(OH, 0), max(OW, 0), sw, dw))
         if nbytes <= 0:
             return None, 0
         return self._scratch(x.device, nbytes, self._stream(x).value), nbytes
@@ -362,7 +375,7 @@ class _Bindings:
             bias = bias.to(x.dtype).contiguous()
         y = torch.empty((B, OC, max(OH, 0), max(OW, 0)), dtype=x.dtype, device=x.device)
         with torch.cuda.device(x.device):
-            ws, ws_bytes = self._conv2d_scratch(x, B, OH, OW, OC, C * KH * KW, qbits=True)
+            ws, ws_bytes = self._conv2d_scratch(x, B, OH, OW, OC, C * KH * KW, geom=(C, W, KH, KW, stride[1], dilation[1]))
             st = self._c.quanto_hip_qbits_conv2d(_ptr(x), _ptr(packed), _ptr(scale), _ptr(shift), _ptr(bias), _ptr(y), B, C, H, W, OC, KH, KW, OH, OW,
                                                  stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], bits, group_size or 0, _dt(x),
                                                  _dt(shift), _ptr(ws), ws_bytes, self._stream(x))
@@ -420,6 +433,8 @@ class _Bindings:
                  kernel: str = "auto"):
         if not (x.is_cuda and packed.is_cuda and scale.is_cuda and shift.is_cuda and (bias is None or bias.is_cuda)):
             raise QuantoHipError("quanto_hip kernels only accept tensors on a ROCm device")
+        if x.dim() == 0 or x.shape[-1] != in_features:  # the kernel reads M * in_features elements: never from a smaller buffer
+            raise QuantoHipError(f"qbits_mm: input of shape {tuple(x.shape)} does not end in in_features = {in_features}")
         sdt = scale.dtype
         if x.dtype != sdt:
             x = x.to(sdt)
@@ -553,6 +568,8 @@ class _Bindings:
         N, K = b.shape
         if scales.numel() != N:
             raise QuantoHipError(f"qbytes_mm expects one scale per output feature ({N}), got {tuple(scales.shape)}")
+        if a.dim() == 0 or a.shape[-1] != K:  # torch.matmul's shape error in the reference; here the kernel would read past the buffer
+            raise QuantoHipError(f"qbytes_mm: input of shape {tuple(a.shape)} does not end in in_features = {K}")
         sdt = scales.dtype
         if a.dtype.is_floating_point and a.dtype.itemsize > 1 and a.dtype != sdt:
             a = a.to(sdt)  # library/qbytes_mm.py:26
@@ -593,7 +610,7 @@ class QuantoHipExtension(NativeLibrary):
             "quanto_hip",
             root_dir=csrc,
             lib_path=os.path.join(_PKG_DIR, "lib", "libquanto_hip.so"),
-            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qconv_mfma.hip", "qmm_mfma_large.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbits_mfma_large.hip", "qbytes_skinny.hip", "qmm_native8.hip", "quantize.hip",
+            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qconv_mfma.hip", "qmm_mfma_large.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbits_mfma_large.hip", "qbytes_skinny.hip", "qmm_native8.hip", "qmm_f32.hip", "quantize.hip",
                      "qh_common.h", os.path.join("..", "..", "include", "quanto_hip.h")],
         )
         self._bindings = None

@@ -5,6 +5,7 @@ Mirrors the reference wrapper (optimum/quanto/models/transformers_models.py:35-1
 ``save_pretrained`` (safetensors of the flattened QTensors + ``quanto_qmap.json``) and ``from_pretrained`` (empty model on
 the meta device -> ``requantize``).  Hub download/upload is out of scope (no network on the build or GPU boxes).
 """
+import copy
 import json
 import os
 from typing import Any, List, Optional, Union
@@ -65,22 +66,24 @@ class QuantizedTransformersModel:
         # record the dtype the model computes in (transformers' own save_pretrained does; config.save_pretrained alone does not): from_pretrained
         # builds its skeleton in it, so the quantized scales come back as saved
         first = next((p for p in model.parameters() if type(p.data) is torch.Tensor and p.is_floating_point()), None)
+        # (the stamp goes on a COPY: the live config keeps its attributes - a str where transformers expects a torch.dtype breaks model.to(config.dtype))
+        cfg = copy.deepcopy(model.config)
         stamped = None
-        if first is not None and getattr(model.config, "dtype", None) is None and getattr(model.config, "torch_dtype", None) is None:
+        if first is not None and getattr(cfg, "dtype", None) is None and getattr(cfg, "torch_dtype", None) is None:
             # transformers >= 4.56 serialises config.dtype; older ones only know torch_dtype (and would fail to JSON-dump a raw torch.dtype
             # stored under an attribute they do not know): set the one this version has
-            stamped = "dtype" if "dtype" in getattr(type(model.config), "__dict__", {}) or hasattr(model.config, "dtype") else "torch_dtype"
+            stamped = "dtype" if "dtype" in getattr(type(cfg), "__dict__", {}) or hasattr(cfg, "dtype") else "torch_dtype"
             try:
-                setattr(model.config, stamped, first.dtype)
+                setattr(cfg, stamped, first.dtype)
             except Exception:  # a config class without either attribute: the loader falls back to from_config's default
                 stamped = None
         try:
-            model.config.save_pretrained(save_directory)
+            cfg.save_pretrained(save_directory)
         except TypeError:  # the attribute is not one this transformers version serialises: store the name instead ("bfloat16")
             if stamped is None:
                 raise
-            setattr(model.config, stamped, str(first.dtype).split(".")[-1])
-            model.config.save_pretrained(save_directory)
+            setattr(cfg, stamped, str(first.dtype).split(".")[-1])
+            cfg.save_pretrained(save_directory)
         state = {k: v.contiguous().cpu() for k, v in model.state_dict().items()}
         if getattr(model.config, "tie_word_embeddings", False) and model.get_output_embeddings() is not None:
             state.pop("lm_head.weight", None)  # shared storage: safetensors refuses aliases
