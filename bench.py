@@ -93,6 +93,11 @@ WORKLOADS = {
     "fp8a8": ("qbytes_f8f8", 4096, 4096, 4096, "fp8-e4m3fn x fp8-e4m3fn qbytes_mm (quantized activations), (M,K,N)=(4096,4096,4096)"),
     "cfg4_fp8a8": ("qbytes_f8f8", 512, 8192, 8192, "fp8-e4m3fn x fp8-e4m3fn qbytes_mm on the native fp8 MFMA (BASELINE configs[3] with quantized activations), (M,K,N)=(512,8192,8192)"),
     "cfg4_w8a8": ("qbytes_i8i8", 512, 8192, 8192, "int8 x int8 qbytes_mm (quantized activations), (M,K,N)=(512,8192,8192)"),
+    # r6: int4 weights x quantized activations on the 8-bit matrix instructions (quanto::qbits_mm_a8, csrc/qbits_a8_fused.hip)
+    "w4a8": ("qbits_i4_a8i", 4096, 4096, 4096, "int8 activations x int4 qbits_mm_a8, group_size=128 scale+shift, (M,K,N)=(4096,4096,4096)"),
+    "w4a8_512": ("qbits_i4_a8i", 512, 4096, 4096, "int8 activations x int4 qbits_mm_a8, group_size=128 scale+shift, (M,K,N)=(512,4096,4096)"),
+    "w4afp8": ("qbits_i4_a8f", 4096, 4096, 4096, "fp8-e4m3fn activations x int4 qbits_mm_a8, group_size=128 scale+shift, (M,K,N)=(4096,4096,4096)"),
+    "w4afp8_512": ("qbits_i4_a8f", 512, 4096, 4096, "fp8-e4m3fn activations x int4 qbits_mm_a8, group_size=128 scale+shift, (M,K,N)=(512,4096,4096)"),
     "int4_prefill": ("qbits_i4", 4096, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, prefill (M,K,N)=(4096,4096,4096)"),
     "int4_prefill512": ("qbits_i4", 512, 4096, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, (M,K,N)=(512,4096,4096)"),
     "int8_8k": ("qbytes_i8", 8192, 8192, 8192, "bf16 x int8 qbytes_mm, per-channel scale, (M,K,N)=(8192,8192,8192)"),
@@ -118,7 +123,7 @@ WORKLOADS = {
     "int4_decode1_down": ("qbits_i4", 1, 14336, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, decode (M,K,N)=(1,14336,4096) (Llama-3-8B down_proj)"),
     "int4_decode32_up": ("qbits_i4", 32, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,14336)"),
 }
-DEFAULT_SUB = ["northstar", "cfg3", "cfg4", "cfg4_fp8a8", "w8a8", "fp8a8", "int4_prefill", "int4_prefill512", "gateup_fused", "int4_decode32",
+DEFAULT_SUB = ["northstar", "cfg3", "cfg4", "cfg4_fp8a8", "w8a8", "fp8a8", "w4a8", "w4a8_512", "int4_prefill", "int4_prefill512", "gateup_fused", "int4_decode32",
                "qkv_fused32", "layer_decode_b1", "layer_decode_b32"]  # (q/k/v at M = 1 and the int8 gate/up launch of r2-r4 are inside layer_decode_b1 / --sub)
 # printed ONCE per JSON line (r2's line repeated this prose in every sub-result, grew past the driver's 8 KB stdout tail and lost
 # its first two sub-results): what cpu_baseline.kind == "reference" and each cpu_baseline.path code stand for
@@ -132,7 +137,7 @@ CPU_BASELINE_NOTE = {
     "tinygemm": "TinyGemmWeightQBitsTensor (create()'s CPU choice for bf16 scales): torch._weight_int4pack_mm_for_cpu, "
                 "tensor/weights/tinygemm/qbits.py:51-58; lossy shift repack at load time",
 }
-ARITH_DTYPE = {"qbytes_i8": "bf16", "qbytes_f8": "bf16", "qbits_i4": "bf16", "qbits_i4_multi": "bf16", "qbytes_i8_multi": "bf16", "qbytes_i8i8": "int8", "qbytes_f8f8": "fp8"}
+ARITH_DTYPE = {"qbits_i4_a8i": "int8", "qbits_i4_a8f": "fp8", "qbytes_i8": "bf16", "qbytes_f8": "bf16", "qbits_i4": "bf16", "qbits_i4_multi": "bf16", "qbytes_i8_multi": "bf16", "qbytes_i8i8": "int8", "qbytes_f8f8": "fp8"}
 
 
 def algorithmic_work(kind, M, K, N):
@@ -141,7 +146,10 @@ def algorithmic_work(kind, M, K, N):
     Ns = N if isinstance(N, tuple) else (N,)
     Nt = sum(Ns)
     flops = 2.0 * M * Nt * K
-    if kind in ("qbits_i4", "qbits_i4_multi"):
+    if kind in ("qbits_i4_a8i", "qbits_i4_a8f"):
+        G = K // 128
+        nbytes = Nt * K // 2 + 2 * (Nt * G * 2) + M * K + M * Nt * 2
+    elif kind in ("qbits_i4", "qbits_i4_multi"):
         G = K // 128
         nbytes = Nt * K // 2 + 2 * (Nt * G * 2) + M * K * 2 + M * Nt * 2
     elif kind in ("qbytes_i8i8", "qbytes_f8f8"):
@@ -187,6 +195,12 @@ def build_inputs(kind, M, K, N, device, n_weights, seed):
         x, x_scale = absmax_quantize(x.float(), 127, torch.int8, axis_scale=False)
     elif kind == "qbytes_f8f8":
         x, x_scale = absmax_quantize(x.float(), 448, torch.float8_e4m3fn, axis_scale=False)
+    elif kind == "qbits_i4_a8i":
+        x, x_scale = absmax_quantize(x.float(), 127, torch.int8, axis_scale=False)
+        x = (x.contiguous(), x_scale.reshape(1))
+    elif kind == "qbits_i4_a8f":
+        x, x_scale = absmax_quantize(x.float(), 448, torch.float8_e4m3fn, axis_scale=False)
+        x = (x.contiguous(), x_scale.reshape(1))
     sets = []
     for _ in range(n_weights):
         if kind == "qbits_i4_multi":
@@ -196,7 +210,7 @@ def build_inputs(kind, M, K, N, device, n_weights, seed):
             sets.append([absmax_quantize((randn(n, K) * 0.02).to(torch.bfloat16).float(), 127, torch.int8) for n in N])
             continue
         w = (randn(N, K) * 0.02).to(torch.bfloat16).float()
-        if kind == "qbits_i4":
+        if kind in ("qbits_i4", "qbits_i4_a8i", "qbits_i4_a8f"):
             sets.append(quantize_int4(w))
         elif kind in ("qbytes_i8", "qbytes_i8i8"):
             q, scale = absmax_quantize(w, 127, torch.int8)
@@ -209,12 +223,19 @@ def build_inputs(kind, M, K, N, device, n_weights, seed):
                 scale = (scale.float() * x_scale.float()).to(torch.bfloat16)
             sets.append((q.contiguous(), scale))
         del w
-    return x.contiguous(), sets
+    return (x if isinstance(x, tuple) else x.contiguous()), sets
 
 
 def make_step(kind, x, sets, K, N):
     state = {"i": 0}
-    if kind == "qbits_i4":
+    if kind in ("qbits_i4_a8i", "qbits_i4_a8f"):
+        xq, xs = x
+
+        def step():
+            packed, scale, shift = sets[state["i"] % len(sets)]
+            state["i"] += 1
+            return torch.ops.quanto.qbits_mm_a8(xq, xs, packed, scale, shift, None, 4, 128, N, K)
+    elif kind == "qbits_i4":
         def step():
             packed, scale, shift = sets[state["i"] % len(sets)]
             state["i"] += 1
@@ -244,7 +265,7 @@ def make_step(kind, x, sets, K, N):
     return step
 
 
-REF_ROCM_FOR = ("cfg2", "cfg3", "northstar", "cfg4", "int4_prefill", "int4_prefill512", "w8a8", "fp8a8", "cfg4_fp8a8", "cfg4_w8a8")
+REF_ROCM_FOR = ("cfg2", "cfg3", "northstar", "cfg4", "int4_prefill", "int4_prefill512", "w8a8", "fp8a8", "cfg4_fp8a8", "cfg4_w8a8", "w4a8", "w4a8_512", "w4afp8", "w4afp8_512")
 
 
 def make_ref_rocm_step(kind, x, wset, K, N):
@@ -253,7 +274,19 @@ def make_ref_rocm_step(kind, x, wset, K, N):
     8-bit: library/qbytes_mm.py:25-33 (reached from :73-88 for float activations).  4-bit: quanto::unpack (library/unpack.py:21-54:
     mask, shift, cat - the reference's one-pass HIP unpack kernel yields the same tensor), ``scale * data``, ``-= shift``
     (tensor/qbits.py:41-45), ungroup = reshape for axis 0 (tensor/grouped.py:39-44), matmul (tensor/function.py:44)."""
-    if kind == "qbits_i4":
+    if kind in ("qbits_i4_a8i", "qbits_i4_a8f"):
+        # quantized activation x int4 weight in the reference: dequantize the activation (tensor/weights/qbits.py:262-287 -> qfallback), then the
+        # int4 sequence below
+        packed, scale, shift = wset
+        xq, xs = x
+
+        def step():
+            xd = xq.to(scale.dtype) * xs
+            data = torch.cat([packed & 0x0F, (packed & 0xF0) >> 4]).to(torch.uint8)
+            dqt = scale * data
+            dqt -= shift
+            return torch.matmul(xd, dqt.reshape(N, K).t())
+    elif kind == "qbits_i4":
         packed, scale, shift = wset
 
         def step():
@@ -393,10 +426,11 @@ def run_workload(name, args, device, rank, world, dist, steps, with_cpu):
     if compute_bound:
         value = flops * world / (elapsed / steps) / 1e12
         what = {"qbytes_i8": "bf16 x int8 qbytes_mm", "qbytes_f8": "bf16 x fp8 qbytes_mm", "qbits_i4": "bf16 x int4 qbits_mm",
-                "qbytes_i8i8": "int8 x int8 qbytes_mm", "qbytes_f8f8": "fp8 x fp8 qbytes_mm"}[kind]
+                "qbytes_i8i8": "int8 x int8 qbytes_mm", "qbytes_f8f8": "fp8 x fp8 qbytes_mm", "qbits_i4_a8i": "int8 x int4 qbits_mm_a8",
+                "qbits_i4_a8f": "fp8 x int4 qbits_mm_a8"}[kind]
         metric, unit = f"QLinear GEMM TFLOP/s ({what})", "TFLOP/s"
         achieved = flops / (launch_ms * 1e-3) / 1e12
-        peak = MFMA_PEAK_8BIT_TOPS if kind in ("qbytes_i8i8", "qbytes_f8f8") else MFMA_PEAK_TFLOPS
+        peak = MFMA_PEAK_8BIT_TOPS if kind in ("qbytes_i8i8", "qbytes_f8f8", "qbits_i4_a8i", "qbits_i4_a8f") else MFMA_PEAK_TFLOPS
         roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None}
     else:
         value = nbytes * world / (elapsed / steps) / 1e9
@@ -429,7 +463,7 @@ def run_workload(name, args, device, rank, world, dist, steps, with_cpu):
         except Exception as e:  # an ATen op the ROCm build lacks (torch._int_mm): say so instead of dropping the record
             out["ref_rocm_us"] = None
             out["ref_rocm_error"] = repr(e)[:120]
-    if with_cpu:
+    if with_cpu and not isinstance(x, tuple):  # (quantized activation x int4: the reference has no CPU path of its own for it - it dequantizes the activation and runs the int4 path timed above)
         out["cpu_baseline"] = cpu_baseline(kind, M, K, N, x, sets[0], args.cpu_budget)
     del sets
     torch.cuda.empty_cache()
@@ -663,7 +697,7 @@ def run_cfg5(args, device, batches=(1, 32), prompt=512, new=512):
     linked = Q.fuse_decode_projections(model)
     torch.cuda.synchronize()
     out = {"name": "cfg5", "model": "Llama-3-8B random-init bf16, qint4 g128, lm_head excluded", "prompt": prompt, "new_tokens": new,
-           "method": "generate(), greedy, eos off, prefill included (latency.py:24-105)", "fused_groups": linked,
+           "method": "generate() per latency.py:24-105; graph_* = static-cache decode step replayed from a hipGraph", "fused_groups": linked,
            "build_s": round(time.perf_counter() - t0, 1), "int4_bytes_per_token": 32 * sum((sum(N) if isinstance(N, tuple) else N) * (K // 2 + K // 128 * 4) for _, _, K, N in LAYER_LAUNCHES)}
     if getattr(model, "generation_config", None) is not None:
         model.generation_config.eos_token_id = None
@@ -946,8 +980,9 @@ def compact(r):
 # ------------------------------------------------------------------------------------------------------------------------
 # r6: bits 4 / 8 (DMA re-reads the first tile: L2 hits, no HBM) now reach the two-wave-set form the (32,4096,4096) call takes - r5's "no_hbm" rung still
 # streamed the weights - and the skeleton is taken apart further: 32 / 64 drop the activation / weight DMA instructions altogether, 128 returns at entry
-ABLATIONS = (("full", 0), ("no_tail", 1), ("no_tail_no_mfma", 3), ("no_tail_no_mfma_no_table", 19), ("no_tail_no_mfma_no_table_no_hbm", 31),
-             ("skeleton_no_x_dma", 31 + 32), ("skeleton_no_dma", 31 + 32 + 64), ("launch_only", 128))
+# (short keys: the line has to stay under the driver's 8 KB tail.  Each rung removes one more part: "-tail" = no split-K tail, "-mfma" = also no MFMA /
+# LDS-read work, "-table" = also no scale table, "-hbm" = also L2-resident DMA sources, "-xdma" / "-dma" = also no activation / no DMA instruction at all)
+ABLATIONS = (("full", 0), ("-tail", 1), ("-mfma", 3), ("-table", 19), ("-hbm", 31), ("-xdma", 31 + 32), ("-dma", 31 + 32 + 64), ("launch", 128))
 
 
 def ablate_child(name, args, device):
@@ -1111,7 +1146,7 @@ def main():
             for sr in sub_results:
                 apply_profile(sr, prof.get(sr["name"]), compacted=True)
             out["profile_passes"] = {"ok": bool(prof), "seconds": round(time.perf_counter() - t_prof, 1), "trace_floor_us": prof.get("_trace_floor_us"),
-                                     "what": "rocprofv3 child runs of this file: --kernel-trace of one steady-state hipGraph replay (kernel_us / kernel_us_min = begin-to-end per dispatch as the profiler stamps it, dispatch set-up included that an unprofiled replay overlaps with the previous kernel: on us-scale kernels both can exceed us_per_step; trace_floor_us = the shortest marker dispatch, a kernel that does nothing), --pmc FETCH_SIZE / WRITE_SIZE (traffic, FETCH x2: gfx950)"}
+                                     "what": "bench.py docstring (Round 4 additions): rocprofv3 child passes of this run"}
         if world == 1 and rank == 0 and default_run and not args.no_cfg5 and out is not None:
             try:
                 rec = run_cfg5(args, device)

@@ -275,6 +275,25 @@ int quanto_hip_quantize_affine_packed(const void* base, const void* scale, const
 int quanto_hip_pack(const uint8_t* unpacked, uint8_t* packed, int64_t rows, int64_t cols, int bits, void* stream);
 
 /*
+ * qbits_mm with QUANTIZED activations (W4A8, r6): F.linear(ActivationQBytesTensor, WeightQBitsTensor) - the combination the reference's
+ * tests/tensor/ops/test_linear_dispatch.py:22-42 exercises and every backend of the reference serves by dequantizing the activation first
+ * (tensor/weights/qbits.py:262-287 -> tensor/function.py:41-47; the CUDA subclasses: tensor/weights/awq/qbits.py:57-58).  Here the stored int8 / fp8-e4m3
+ * activation values meet the stored nibbles on the 8-bit matrix instructions (csrc/qbits_a8_fused.hip):
+ *   y[m, n] = a_scale * sum_g ( scale[n,g] * sum_{k in g} a[m,k] q[n,k] - z[n,g] * sum_{k in g} a[m,k] ) (+ bias[n]),  z = shift, or scale * zero_point
+ *   a: a_dtype[M, K] (I8 or F8_E4M3FN); a_scale: ONE element of `dtype` on the device (the per-tensor activation scale, tensor/activations/qbytes.py:28-43);
+ *   packed / scale / shift / bias / y as for quanto_hip_qbits_mm; dtype in {F16, BF16}; bits = 4, group_size = 128, N % 8 == 0, K % 128 == 0.
+ * QUANTO_HIP_ENOTSUP for every other format (the caller then dequantizes the activation and calls quanto_hip_qbits_mm, as the reference does).
+ * workspace: optional split-K scratch of quanto_hip_qbits_mm_a8_workspace_size bytes, counter region zero on entry (QUANTO_HIP_WS_COUNTER_BYTES) and left
+ * zero; without it the call runs unsplit.  For int8 activations the unsplit result is a pure function of the integers (fp32 fma chain over exact group sums).
+ */
+int quanto_hip_qbits_mm_a8(const void* a, const void* a_scale, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y,
+                           int64_t M, int64_t N, int64_t K, int bits, int group_size, int a_dtype, int dtype, int shift_dtype, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* Split-K scratch bytes of quanto_hip_qbits_mm_a8 (0: unsplit); QUANTO_HIP_ENOTSUP when the format is not served, QUANTO_HIP_EINVAL on bad arguments. */
+int64_t quanto_hip_qbits_mm_a8_workspace_size(int64_t M, int64_t N, int64_t K, int bits, int group_size, int a_dtype, int dtype);
+
+/*
  * F.conv2d with an int8 / fp8 weight - what QConv2d.forward (nn/qconv2d.py:54-55) reaches through WeightQBytesTensor's dispatch, where the
  * reference dequantizes the whole weight per call (qfallback) and runs a float convolution.  Dense convolution (groups = 1) as an IMPLICIT
  * GEMM: y[b, n, oh, ow] = scale[n] * sum_{c,i,j} x[b, c, oh*sh - ph + i*dh, ow*sw - pw + j*dw] * w[n, c, i, j] (+ bias[n]); the im2col operand

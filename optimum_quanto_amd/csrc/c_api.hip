@@ -90,6 +90,12 @@ bool qbytes_mm_f32_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_gemv_f32(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 int qbytes_mm_f32(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
 
+// quantized activations x int4 weights (r6, qbits_a8_fused.hip)
+bool qbits_a8_supported(int64_t, const PackedGeom&, int, int);
+size_t qbits_a8_workspace(int64_t, const PackedGeom&);
+int qbits_mm_a8(const void*, const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, const PackedGeom&, int, int, bool, void*, size_t,
+                hipStream_t);
+
 static bool is_float_dtype(int dt) { return dt == QUANTO_HIP_F32 || dt == QUANTO_HIP_F16 || dt == QUANTO_HIP_BF16; }
 
 static int check_qbits(int64_t M, int64_t N, int64_t K, int bits, int group_size, int dtype, int shift_dtype, bool* int_shift) {
@@ -359,6 +365,31 @@ int quanto_hip_qbits_mm(const void* x, const uint8_t* packed, const void* scale,
       return r;
   }
   return QUANTO_HIP_EINVAL;
+}
+
+int64_t quanto_hip_qbits_mm_a8_workspace_size(int64_t M, int64_t N, int64_t K, int bits, int group_size, int a_dtype, int dtype) {
+  bool int_shift = false;
+  const int st = check_qbits(M, N, K, bits, group_size, dtype, dtype, &int_shift);
+  if (st != QUANTO_HIP_OK) return st;
+  const PackedGeom g = make_geom(N, K, bits, group_size);
+  if (M == 0) return 0;
+  if (!qbits_a8_supported(M, g, a_dtype, dtype)) return QUANTO_HIP_ENOTSUP;
+  return (int64_t)qbits_a8_workspace(M, g);
+}
+
+int quanto_hip_qbits_mm_a8(const void* a, const void* a_scale, const uint8_t* packed, const void* scale, const void* shift, const void* bias, void* y,
+                           int64_t M, int64_t N, int64_t K, int bits, int group_size, int a_dtype, int dtype, int shift_dtype, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  bool int_shift = false;
+  const int st = check_qbits(M, N, K, bits, group_size, dtype, shift_dtype, &int_shift);
+  if (st != QUANTO_HIP_OK) return st;
+  if (M == 0) return QUANTO_HIP_OK;
+  if (!a || !a_scale || !packed || !scale || !shift || !y) return QUANTO_HIP_EINVAL;
+  const PackedGeom g = make_geom(N, K, bits, group_size);
+  const int r = qbits_mm_a8(a, a_scale, packed, scale, shift, bias, y, M, g, a_dtype, dtype, int_shift, workspace, workspace_bytes,
+                            reinterpret_cast<hipStream_t>(stream));
+  if (r == QUANTO_HIP_OK) set_last_kernel(a_dtype == QUANTO_HIP_I8 ? "a8_fused_int8" : "a8_fused_fp8");
+  return r;
 }
 
 // one streaming-MFMA launch for the whole group pays when the members are small enough to be dominated by per-call costs

@@ -132,6 +132,10 @@ class _Bindings:
         c.quanto_hip_qbits_mm_pick.argtypes = [i64, i64, i64, ci, ci, ci]
         c.quanto_hip_qbytes_mm.restype = ci
         c.quanto_hip_qbytes_mm.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, ci, ci, vp]
+        c.quanto_hip_qbits_mm_a8.restype = ci
+        c.quanto_hip_qbits_mm_a8.argtypes = [vp] * 7 + [i64] * 3 + [ci] * 5 + [vp, sz, vp]
+        c.quanto_hip_qbits_mm_a8_workspace_size.restype = i64
+        c.quanto_hip_qbits_mm_a8_workspace_size.argtypes = [i64] * 3 + [ci] * 4
         c.quanto_hip_qbytes_mm_ws.restype = ci
         c.quanto_hip_qbytes_mm_ws.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, ci, ci, ci, ci, vp, sz, vp]
         c.quanto_hip_qbytes_mm_workspace_size.restype = i64
@@ -474,6 +478,53 @@ class _Bindings:
             self._check(st, "qbits_mm")
         return y if x.dim() == 2 else y.reshape(*x.shape[:-1], out_features)
 
+    # -- quanto::qbits_mm_a8 (quantized activations x int4 weights) ---------------------------------------
+    A8_DTYPES = (torch.int8, torch.float8_e4m3fn)
+
+    def qbits_mm_a8_workspace(self, M: int, out_features: int, in_features: int, bits: int, group_size, a_dtype, dtype) -> int:
+        """Split-K scratch bytes of the W4A8 kernel for this call shape, or a negative status when the format is not served (the caller then
+        dequantizes the activation, as the reference does)."""
+        adt, dt = _DTYPES.get(a_dtype), _DTYPES.get(dtype)
+        if adt is None or dt is None:
+            return -2
+        return self._plan("qbits_mm_a8", (M, out_features, in_features, bits, group_size or 0, adt, dt),
+                          lambda ko, wo: self._a8_plan(M, out_features, in_features, bits, group_size or 0, adt, dt, ko, wo))[1]
+
+    def _a8_plan(self, M, N, K, bits, gs, adt, dt, kernel_out, ws_out):
+        ws_out._obj.value = int(self._c.quanto_hip_qbits_mm_a8_workspace_size(M, N, K, bits, gs, adt, dt))
+        return 0
+
+    def qbits_mm_a8(self, a, a_scale, packed, scale, shift, bias, bits: int, group_size, out_features: int, in_features: int):
+        """F.linear(quantized activation, int4 weight) on the 8-bit matrix instructions: ``a`` int8 / float8_e4m3fn [..., K], ``a_scale`` its
+        per-tensor scale (one element).  Raises QuantoHipError(ENOTSUP) for formats the kernel does not take."""
+        if not (a.is_cuda and a_scale.is_cuda and packed.is_cuda and scale.is_cuda and shift.is_cuda and (bias is None or bias.is_cuda)):
+            raise QuantoHipError("quanto_hip kernels only accept tensors on a ROCm device")
+        if a.dim() == 0 or a.shape[-1] != in_features:
+            raise QuantoHipError(f"qbits_mm_a8: input of shape {tuple(a.shape)} does not end in in_features = {in_features}")
+        if a_scale.numel() != 1:
+            raise QuantoHipError("qbits_mm_a8 expects a per-tensor activation scale")
+        sdt = scale.dtype
+        a2 = a if a.dim() == 2 and a.is_contiguous() else a.reshape(-1, in_features).contiguous()
+        a_scale = a_scale.reshape(1).to(sdt).contiguous()
+        packed, scale, shift = packed.contiguous(), scale.contiguous(), shift.contiguous()
+        if bias is not None:
+            bias = bias.to(sdt).contiguous()
+        M = a2.shape[0]
+        ws_bytes = self.qbits_mm_a8_workspace(M, out_features, in_features, bits, group_size, a2.dtype, sdt)
+        if ws_bytes < 0:
+            self._check(int(ws_bytes), "qbits_mm_a8")
+        y = torch.empty((M, out_features), dtype=sdt, device=a.device)
+        index = a.device.index
+        with _DeviceGuard(a.device):
+            stream = _raw_stream(index if index is not None else _current_device())
+            wp = self._zeroed_workspace(a.device, ws_bytes, stream).data_ptr() if ws_bytes > 0 else 0
+            st = self._c.quanto_hip_qbits_mm_a8(a2.data_ptr(), a_scale.data_ptr(), packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                0 if bias is None else bias.data_ptr(), y.data_ptr(), M, out_features, in_features, bits,
+                                                group_size or 0, _DTYPES[a2.dtype], _DTYPES[sdt], _dt(shift), wp, ws_bytes, stream)
+        if st != 0:
+            self._check(st, "qbits_mm_a8")
+        return y if a.dim() == 2 else y.reshape(*a.shape[:-1], out_features)
+
     # -- quanto::qbits_mm_multi ---------------------------------------------------------------------
     MAX_MULTI = 4  # QUANTO_HIP_MAX_MULTI
 
@@ -610,7 +661,7 @@ class QuantoHipExtension(NativeLibrary):
             "quanto_hip",
             root_dir=csrc,
             lib_path=os.path.join(_PKG_DIR, "lib", "libquanto_hip.so"),
-            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qconv_mfma.hip", "qmm_mfma_large.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbits_mfma_large.hip", "qbytes_skinny.hip", "qmm_native8.hip", "qmm_f32.hip", "quantize.hip",
+            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qconv_mfma.hip", "qmm_mfma_large.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbits_a8_fused.hip", "qbits_mfma_large.hip", "qbytes_skinny.hip", "qmm_native8.hip", "qmm_f32.hip", "quantize.hip",
                      "qh_common.h", os.path.join("..", "..", "include", "quanto_hip.h")],
         )
         self._bindings = None

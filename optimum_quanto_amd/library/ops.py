@@ -295,6 +295,33 @@ if _define("qbits_mm",
     _impl("qbits_mm", "CUDA", qbits_mm_hip, True)
 
 
+# ------------------------------------------------------------------------------------------------
+# quanto::qbits_mm_a8 (r6): F.linear(quantized activation, int4 weight) without dequantizing the activation
+# ------------------------------------------------------------------------------------------------
+def qbits_mm_a8_default(input, input_scale, packed, scale, shift, bias, bits: int, group_size: Optional[int], out_features: int, in_features: int):
+    """What the reference computes (tensor/weights/awq/qbits.py:57-58, tensor/function.py:41-47): dequantize the activation, then the float product."""
+    x = input.to(scale.dtype) * input_scale.to(scale.dtype)
+    return torch.ops.quanto.qbits_mm(x, packed, scale, shift, bias, bits, group_size, out_features, in_features)
+
+
+def qbits_mm_a8_hip(input, input_scale, packed, scale, shift, bias, bits: int, group_size: Optional[int], out_features: int, in_features: int):
+    lib = quanto_hip.lib
+    m = input.numel() // in_features if in_features else 0
+    # batched-decode sizes keep the weight-streaming kernels (the activation is dequantized: M x K elements, nothing next to the weight stream);
+    # from 64 rows on the stored integers / fp8 values go to the 8-bit matrix instructions
+    if (m > 64 and input.dtype in lib.A8_DTYPES and input_scale.numel() == 1
+            and lib.qbits_mm_a8_workspace(m, out_features, in_features, bits, group_size, input.dtype, scale.dtype) >= 0):
+        return lib.qbits_mm_a8(input, input_scale, packed, scale, shift, bias, bits, group_size, out_features, in_features)
+    return qbits_mm_a8_default(input, input_scale, packed, scale, shift, bias, bits, group_size, out_features, in_features)
+
+
+if _define("qbits_mm_a8",
+           "(Tensor input, Tensor input_scale, Tensor packed, Tensor scale, Tensor shift, Tensor? bias, int bits, int? group_size, "
+           "int out_features, int in_features) -> Tensor"):
+    _impl("qbits_mm_a8", "CompositeExplicitAutograd", qbits_mm_a8_default, True)
+    _impl("qbits_mm_a8", "CUDA", qbits_mm_a8_hip, True)
+
+
 def qbits_conv2d_default(input, packed, scale, shift, bias, bits: int, group_size: Optional[int], weight_size, stride, padding, dilation):
     """What the reference computes for F.conv2d on a WeightQBitsTensor (nn/qconv2d.py:54-55 -> qfallback): dequantize, float convolution."""
     oc, c, kh, kw = weight_size

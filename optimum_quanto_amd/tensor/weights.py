@@ -357,9 +357,14 @@ class WeightQBitsLinearFunction(QuantizedLinearFunction):
     @staticmethod
     def forward(ctx, input, other, bias=None):
         ctx.save_for_backward(input, other)
-        if type(input) is not torch.Tensor:
-            input = input.dequantize()
         n, k = other.shape
+        if type(input) is not torch.Tensor:
+            # r6: a per-tensor quantized activation meets the packed weight as stored (quanto::qbits_mm_a8: the 8-bit matrix instructions from 64
+            # rows on, the reference's dequantize-first sequence below that and for the formats the kernel does not take)
+            if isinstance(input, QBytesTensor) and input.axis is None and input._data.is_cuda and input._scale.numel() == 1:
+                return _op("qbits_mm_a8")(input._data, input._scale, other._data._data, other._scale, other._shift, bias, other._data.bits,
+                                          other._group_size, n, k)
+            input = input.dequantize()
         # the resolved overload: torch.ops.quanto.qbits_mm(...) looks the overload up on every call (~1 us of a 15 us decode call)
         output = _op("qbits_mm")(input, other._data._data, other._scale, other._shift, bias, other._data.bits, other._group_size, n, k)
         return output

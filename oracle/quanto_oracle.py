@@ -367,6 +367,48 @@ def qbits_mm_exact(x, packed, bits, scale, shift, group_size, out_features, in_f
     return y
 
 
+def qbits_mm_a8_exact(a_values, a_scale, packed, bits, scale, shift, group_size, out_features, in_features, bias=None):
+    """F.linear(quantized activation, int4 weight) in exact (float64) math on the stored values: ``a_values`` are the activation's stored
+    integers / decoded fp8 values, ``a_scale`` its per-tensor scale - the product the reference approximates after dequantizing both
+    operands (tensor/weights/qbits.py:262-287 -> tensor/function.py:41-47; tests/tensor/ops/test_linear_dispatch.py:22-42)."""
+    w = dequantize_qbits_exact(packed, bits, scale, shift, 0, group_size, (out_features, in_features))
+    y = np.matmul(np.asarray(a_values, np.float64), w.T) * float(np.asarray(a_scale, np.float64).reshape(-1)[0])
+    if bias is not None:
+        y = y + np.asarray(bias, np.float64)
+    return y
+
+
+def _fma32(a, b, c):
+    """fp32 fused multiply-add on arrays of fp32 values: the product of an 8-bit-mantissa scale and an integer below 2^24 is exact in float64,
+    and so is its sum with an fp32 addend of comparable magnitude (the spans met here stay far below 53 bits): one rounding, to fp32."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def qbits_mm_a8_chain(a_i8, a_scale, packed, bits, scale, shift, group_size, out_features, in_features, dtype: str, bias=None):
+    """The W4A8 kernel's arithmetic for int8 activations, restated operation by operation (csrc/qbits_a8_fused.hip, unsplit form):
+    per group g in order, acc = fma(s[n,g], fp32(P_g), acc); acc = fma(-z[n,g], fp32(A_g), acc) with the exact integers
+    P_g = sum_{k in g} a q and A_g = sum_{k in g} a, z = shift (float shift) or fp32(s * zero_point); then fp32(acc * a_scale) rounded to
+    ``dtype`` (+ bias: rounded product plus bias, rounded again - tensor/function.py:45-46).  Bit-exact gate of the int8 path."""
+    N, K = out_features, in_features
+    G = K // group_size
+    q = unpacked_rows(packed, bits, N * G).reshape(N, G, group_size).astype(np.float64)     # grouped rows n * G + g
+    a = np.asarray(a_i8).astype(np.float64).reshape(-1, G, group_size)
+    s = np.asarray(scale, np.float32).reshape(N, G)
+    sh = np.asarray(shift).reshape(N, G)
+    z = sh.astype(np.float32) if np.issubdtype(sh.dtype, np.floating) else (s * sh.astype(np.float32)).astype(np.float32)
+    acc = np.zeros((a.shape[0], N), np.float32)
+    for g in range(G):
+        P = np.matmul(a[:, g, :], q[:, g, :].T).astype(np.float32)          # exact integers below 2^24
+        A = a[:, g, :].sum(axis=1).astype(np.float32)
+        acc = _fma32(np.broadcast_to(s[:, g][None, :], acc.shape), P, acc)
+        acc = _fma32(np.broadcast_to(-z[:, g][None, :], acc.shape), np.broadcast_to(A[:, None], acc.shape), acc)
+    sx = np.float32(np.asarray(a_scale, np.float32).reshape(-1)[0])
+    y = round_to((acc * sx).astype(np.float32), dtype)
+    if bias is not None:
+        y = round_to(y + np.asarray(bias, np.float32), dtype)
+    return y
+
+
 # --------------------------------------------------------------------------
 # error metrics shared by the tests
 # --------------------------------------------------------------------------

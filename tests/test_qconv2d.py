@@ -167,7 +167,8 @@ def test_qconv2d_fused_gemm_gpu(golden, tag, cname, dt):
     with torch.no_grad():
         y = q(x)
     kernel = quanto_hip.lib.last_kernel()
-    assert kernel in ("gemv", "skinny", "mfma", "mfma_large", "dequant_mfma", "naive", "conv2d_mfma", "conv2d_mfma_rows", "conv2d_mfma_int4", "conv2d_rows_dequant_int4"), kernel
+    assert kernel in ("gemv", "skinny", "mfma", "mfma_large", "dequant_mfma", "naive", "conv2d_mfma", "conv2d_mfma_rows", "conv2d_mfma_int4", "conv2d_rows_dequant_int4",
+                      "mfma_f32", "gemv_f32"), kernel  # (r6: fp32 convolutions lowered to im2col reach the fp32 kernels of csrc/qmm_f32.hip)
     assert y.is_cuda and y.dtype == TORCH_DT[dt] and tuple(y.shape) == golden[key + "/y"].shape
     # exact math on the reference's integers: float64 convolution, product rounded, bias added, rounded again
     cin, cout, ksz, stride, pad = CONVS[cname]
