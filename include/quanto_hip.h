@@ -221,10 +221,11 @@ int quanto_hip_qbytes_mm_multi_plan(int count, const int64_t* N, int64_t M, int6
                                     int* kernel_out, int64_t* workspace_bytes_out);
 
 /*
- * Same, with a caller-provided scratch buffer.  Only the SKINNY kernel (float activations, 2 < M <= QUANTO_HIP_SKINNY_MAX_M)
- * uses it, to split K across workgroups when N alone cannot occupy the chip: the buffer starts with arrival counters that MUST
- * BE ZERO on entry (the kernel leaves them zero), followed by fp32 partial sums - the contract of quanto_hip_qbits_mm's SKINNY
- * kernel.  With workspace == NULL the call is quanto_hip_qbytes_mm.  quanto_hip_qbytes_mm_pick returns the kernel AUTO selects.
+ * Same, with a caller-provided scratch buffer.  The SKINNY kernel (float activations, 2 < M <= QUANTO_HIP_SKINNY_MAX_M), the
+ * MFMA_LARGE kernel and (r6) the NATIVE8 kernel use it to split K across workgroups when the output tiles alone cannot occupy the
+ * chip: the buffer starts with arrival counters that MUST BE ZERO on entry (the kernels leave them zero), followed by partial
+ * accumulators (fp32, int32 for int8 x int8: the split result of that product stays bit-identical to the unsplit one) - the
+ * contract of quanto_hip_qbits_mm's SKINNY kernel.  With workspace == NULL the call is quanto_hip_qbytes_mm.  quanto_hip_qbytes_mm_pick returns the kernel AUTO selects.
  */
 int quanto_hip_qbytes_mm_ws(const void* a, const void* b, const void* scales, const void* bias, void* y,
                             int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype, int kernel,

@@ -55,7 +55,8 @@ int dense_mm_large(const void*, const void*, const void*, void*, int64_t, int64_
 bool dense_mm_wd_supported(int64_t, int64_t, int64_t, int);
 int dense_mm_wd(const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, hipStream_t);
 bool qbytes_native8_supported(int64_t, int64_t, int64_t, int, int, int);
-int qbytes_mm_native8(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, hipStream_t);
+size_t qbytes_native8_workspace(int64_t, int64_t, int64_t, int, int, int);
+int qbytes_mm_native8(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, void*, size_t, hipStream_t);
 bool qbits_skinny_multi_supported(int, const int64_t*, int64_t, int64_t, int);
 size_t qbits_skinny_multi_workspace(int, const int64_t*, int64_t, int64_t);
 int qbits_mm_skinny_multi(const void*, int, const uint8_t* const*, const void* const*, const void* const*, const void* const*, void* const*,
@@ -511,6 +512,7 @@ int64_t quanto_hip_qbytes_mm_workspace_size(int64_t M, int64_t N, int64_t K, int
     return (int64_t)qbytes_skinny_workspace(M, N, K);
   if (kernel == QUANTO_HIP_KERNEL_MFMA_LARGE && qbytes_mfma_large_supported(M, N, K, a_dtype, b_dtype, out_dtype))
     return (int64_t)qbytes_mfma_large_workspace(M, N, K);
+  if (kernel == QUANTO_HIP_KERNEL_NATIVE8) return (int64_t)qbytes_native8_workspace(M, N, K, a_dtype, b_dtype, out_dtype);
   return 0;
 }
 
@@ -573,7 +575,7 @@ int quanto_hip_qbytes_mm_ws(const void* a, const void* b, const void* scales, co
       if (r == QUANTO_HIP_OK) set_last_kernel("mfma_large");
       return r;
     case QUANTO_HIP_KERNEL_NATIVE8:
-      r = qbytes_mm_native8(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, stream);
+      r = qbytes_mm_native8(a, b, scales, bias, y, M, N, K, a_dtype, b_dtype, out_dtype, workspace, workspace_bytes, stream);
       if (r == QUANTO_HIP_OK) set_last_kernel("mfma_native8");
       return r;
   }

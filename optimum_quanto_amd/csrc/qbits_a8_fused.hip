@@ -284,6 +284,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_a8_fused_kernel(const Arg
         const f32x4 cx = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, xa, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
         sum = cx[0];
       }
+      // the matrix instruction must run with all 64 lanes: without this barrier hipcc sinks it into the lane < 16 branch below (EXEC = 0xFFFF), where the
+      // K = 128 MX-format form returned wrong sums (r6 visit 3: profiles/r06_w4a8_fp8_exec_masked_mfma.md)
+      asm volatile("" : "+v"(sum));
       if (lane < 16) xs_slot[(kt & 1) * BM + my_xs * 16 + lane] = sum;  // every row of the product holds the sum: row 0 leaves it for the fold one tile later
     }
   };

@@ -68,6 +68,13 @@ struct Args {
   void* y;            // [M, N]
   int M, N, K;
   int gm;             // tile raster: consecutive workgroup ids walk down gm tile rows before moving to the next tile column (1 = row-major)
+  // split-K (r6, 128-byte-row kernel): S workgroups per tile, workgroup (tile, sp) multiplies the K range sp of S; the accumulators (int32 / fp32) travel
+  // fragment-major through `partials`, an arrival counter per tile elects the last workgroup, which adds in split order and runs the epilogue
+  // (protocol and workspace contract of qmm_mfma_large.hip / qbits_skinny.hip: counters zero on entry and on exit)
+  int S;
+  int* counters;      // [tiles]
+  void* partials;     // [tiles * S][NJ * 8][threads] 16-byte accumulator quads
+  int poll_ticks;     // how long a workgroup waits for its partners (s_memrealtime ticks of 10 ns) before it leaves its slice to the last arriver
 };
 
 // Tile raster.  The XCD remap in the kernels hands every XCD (its own 4 MiB L2, 32 CUs) one contiguous range of tile indices; all of an
@@ -88,9 +95,10 @@ __device__ __forceinline__ void tile_of(int bid, int tiles_m, int tiles_n, int g
 
 // ---- epilogue: (int32 | fp32) accumulator * scale[n] (+ bias), parked per wave in LDS, stored as full 128-byte lines ----
 // (shared by the 64-byte-row and the 128-byte-row kernels; every wave must be done with the operand stages: the barrier below)
-template <int ODT, int KIND, int NJ, int BM, int BN>
-__device__ __forceinline__ void epilogue(const Args& a, typename Acc<KIND>::V (&acc)[NJ][8], uint8_t* smem, int m0, int n0, int wm, int wn, int wave,
-                                         int lane) {
+// NI / i0: the token fragments acc[.][0 .. NI-1] are fragments i0 .. i0 + NI - 1 of the wave's 128 rows (the K split hands every workgroup 8 / S of them)
+template <int ODT, int KIND, int NJ, int BM, int BN, int NI = 8>
+__device__ __forceinline__ void epilogue(const Args& a, typename Acc<KIND>::V (&acc)[NJ][NI], uint8_t* smem, int m0, int n0, int wm, int wn, int wave,
+                                         int lane, int i0 = 0) {
   using E = Elem<ODT>;
   using T = typename E::T;
   const int M = a.M, N = a.N;
@@ -118,7 +126,7 @@ __device__ __forceinline__ void epilogue(const Args& a, typename Acc<KIND>::V (&
         bv[r] = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < NI; ++i) {
         T out[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -139,7 +147,7 @@ __device__ __forceinline__ void epilogue(const Args& a, typename Acc<KIND>::V (&
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int t = 0; t < 2 * LPR; ++t) {
+    for (int t = 0; t < 2 * LPR * NI / 8; ++t) {
       const int row = t * (64 / LPR) + lane / LPR;
       const int c16 = lane % LPR;
       uint4 v;
@@ -147,7 +155,7 @@ __device__ __forceinline__ void epilogue(const Args& a, typename Acc<KIND>::V (&
         v = *reinterpret_cast<const uint4*>(park + row * ROWB + (((c16 * 2) ^ ((row & (LPR - 1)) << 1)) * 8));
       else
         v = *reinterpret_cast<const uint4*>(park + row * ROWB + ((c16 ^ (row & (LPR - 1))) * 16));
-      const int m = m0 + wm * 128 + row;
+      const int m = m0 + wm * 128 + i0 * 16 + row;
       const int n = n0 + wn * (NJ * 16) + p * FP + c16 * (16 / (int)sizeof(T));
       if (full) {
         typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // non-temporal: see qmm_mfma_large.hip
@@ -161,6 +169,139 @@ __device__ __forceinline__ void epilogue(const Args& a, typename Acc<KIND>::V (&
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+}
+
+// ---- split-K tail (r6) ---------------------------------------------------------------------------------------------------------------
+// The S workgroups of a tile each hold a full partial accumulator tile (int32 / fp32).  Reducing it in ONE of them (the last arriver reads S x 256 KiB through
+// one CU: 1 MB at ~70 GB/s per workgroup, MI355X_MICROARCH.md "handoff-payload") cost more than the split saved (measured: (512,8192,8192) fp8 52 us against 44
+// unsplit).  Here every workgroup reduces and stores ONE slice of the tile - token fragments sp * 8 / S .. of every wave:
+//   1. store the partial tile write-through (sc0 sc1), drain, arrive on the tile's counter;
+//   2. poll (one lane, relaxed system-scope loads, s_sleep) until all S have arrived - the usual case, the S workgroups of a tile are dispatched together
+//      (launch plan: tiles * S <= the workgroups the chip holds at once);
+//   3. add the S partial slices in split order - the same sum whoever computes it: run-to-run identical bits - and run the epilogue on the slice.
+// Nothing depends on co-residency for CORRECTNESS: a workgroup whose poll times out (another stream holds the CUs its partners need) marks its slice
+// abandoned and leaves; the LAST arriver - for which every partial is in memory by construction - finishes the abandoned slices.  State words per tile
+// (zero on entry and on exit): [arrivals, completions, state of slice 0 .. S-1 (0 = owner still waiting, 1 = owner reduces it, 2 = abandoned)].
+// part 1, common to every S: the partial tile goes out.  (Kept out of the per-S code below on purpose: with the accumulators live into three inlined reductions hipcc
+// spilled 130 - 470 registers per lane; after this function they are dead.)
+template <int KIND, int NJ, int NWAVES>
+__device__ __forceinline__ void splitk_store(const Args& a, typename Acc<KIND>::V (&acc)[NJ][8], int S, int tile_lin, int sp, int tid) {
+  using AV = typename Acc<KIND>::V;
+  constexpr int NT = NWAVES * 64, NF = NJ * 8;
+  const uint8_t* part = reinterpret_cast<const uint8_t*>(a.partials) + ((size_t)tile_lin * S + sp) * NF * NT * 16;
+  const uint32_t lane_off = (uint32_t)tid * 16;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // every wave is done with the operand stages: the flag words of part 2 live there
+  asm volatile("" ::: "memory");
+  // the whole partial tile, the own slice included: whoever reduces a slice runs the same code on the same bytes, and no second copy of the own slice has to stay in
+  // registers next to the 32 quads a slice reduction has in flight
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint32_t t;  // (the add sits inside the asm: hipcc otherwise computes all 32 offsets ahead of the stores)
+      // s_nop: a store of more than 8 bytes reads its data registers for a few cycles after issue; they are dead here and the next asm's temporary may be one of them
+      // (the hazard recognizer does not look into inline asm: without the wait states the 128-tile kernel stored wrong first / last dwords, r6 visit 5)
+      asm volatile("v_add_u32_e32 %0, %3, %1\n\tglobal_store_dwordx4 %0, %2, %4 sc0 sc1\n\ts_nop 1" : "=&v"(t) : "v"(lane_off), "v"(acc[j][i]), "s"((j * 8 + i) * NT * 16), "s"(part) : "memory");
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+template <int ODT, int KIND, int NJ, int BM, int BN, int NWAVES, int SS>
+__device__ __forceinline__ void splitk_reduce(const Args& a, uint8_t* smem, int tile_lin, int sp, int m0, int n0, int wm, int wn, int wave, int lane, int tid) {
+  using AV = typename Acc<KIND>::V;
+  constexpr int NI = 8 / SS, NT = NWAVES * 64, NF = NJ * 8, CW = 2 + SS;
+  const unsigned long long POLL_LIMIT = (unsigned long long)a.poll_ticks;  // s_memrealtime ticks (100 MHz); 20000 = 200 us
+  int* cw = a.counters + tile_lin * CW;
+  // quad of (split q, fragment f) of this thread: ONE scalar base per tile + a 32-bit lane offset (tid + (q * NF + f) * NT quads): 64-bit lane addresses for the 32
+  // quads in flight would cost 64 registers next to the 128 they load into, a scalar base per quad runs the kernel out of SGPRs
+  const uint8_t* part = reinterpret_cast<const uint8_t*>(a.partials) + (size_t)tile_lin * SS * NF * NT * 16;
+  const uint32_t lane_off = (uint32_t)tid * 16;
+  auto ld = [&](AV& v, uint32_t base_off, int quads) __attribute__((always_inline)) {
+    uint32_t t;
+    asm volatile("v_add_u32_e32 %1, %3, %2\n\tglobal_load_dwordx4 %0, %1, %4 sc0 sc1" : "=&v"(v), "=&v"(t) : "v"(base_off), "s"(quads * NT * 16), "s"(part) : "memory");
+  };
+  volatile int* flag = reinterpret_cast<volatile int*>(smem);
+  if (tid == 0) flag[0] = __hip_atomic_fetch_add(cw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  const bool last = flag[0] == SS - 1;
+  if (!last) {
+    if (tid == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      int ok = 0;
+      for (;;) {
+        if (__hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == SS) {
+          ok = 1;
+          break;
+        }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > POLL_LIMIT) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      // 1 = this workgroup reduces its slice, 2 = abandoned (partners not on the chip): the last arriver takes it
+      __hip_atomic_store(cw + 2 + sp, ok ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      flag[1] = ok;
+    }
+    __syncthreads();
+    if (flag[1] == 0) return;
+  }
+  // slice s of the tile: the S partial slices added in split order
+  auto do_slice = [&](int s) __attribute__((always_inline)) {
+    AV L[SS][NJ][NI];
+    const uint32_t slice_off = lane_off + (uint32_t)s * (NI * NT * 16);
+#pragma unroll
+    for (int q = 0; q < SS; ++q)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii) ld(L[q][j][ii], slice_off, q * NF + j * 8 + ii);
+#pragma unroll
+    for (int q = 0; q < SS; ++q)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii) asm volatile("s_waitcnt vmcnt(0)" : "+v"(L[q][j][ii])::"memory");  // ties the uses below to the wait
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+        for (int q = 1; q < SS; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) L[0][j][ii][r] += L[q][j][ii][r];
+    // opaque zero: the epilogue's per-feature addresses and scale / bias values are common to the three split instantiations, the unsplit epilogue and the sweep
+    // loop below; hipcc otherwise computes them once ahead of all of them and carries ~150 registers through the reduction (measured: 130 - 470 spills)
+    int zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    epilogue<ODT, KIND, NJ, BM, BN, NI>(a, L[0], smem, m0, n0 + zero, wm, wn, wave, lane, s * NI);
+  };
+  // completion: S slices + the last arriver's sweep; whoever counts the last one leaves the state words as found
+  auto complete = [&]() {
+    __syncthreads();
+    if (tid == 0 && __hip_atomic_fetch_add(cw + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == SS) {
+#pragma unroll
+      for (int w = 0; w < CW; ++w) __hip_atomic_store(cw + w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  };
+  do_slice(sp);
+  complete();
+  if (!last) return;
+#pragma unroll 1
+  for (int s = 0; s < SS; ++s) {
+    if (s == sp) continue;
+    __syncthreads();  // the flag words sit in the parking area of the epilogue
+    if (tid == 0) {
+      int v;
+      while ((v = __hip_atomic_load(cw + 2 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == 0) __builtin_amdgcn_s_sleep(2);  // its owner is running: 1 or 2 follows
+      flag[2] = v;
+    }
+    __syncthreads();
+    if (flag[2] == 2) {
+      do_slice(s);
+      complete();
+    }
+  }
+  complete();
 }
 
 // PAIRED (fp8 kinds, K % 128 == 0): K-tiles are consumed two at a time by the K = 128 MX-format MFMA (unit scales), which runs
@@ -476,17 +617,21 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
   const int wm = SMALL ? 0 : wave >> 2, wn = wave & 3;
   constexpr int ES = (KIND == K_BF16 || KIND == K_F16) ? 2 : 1;
   const int M = a.M, N = a.N, K = a.K;
-  const int np = K * ES / RB;  // pairs (128-byte K-tiles)
+  const int S = a.S;
+  const int np = K * ES / RB / S;  // pairs (128-byte K-tiles) of this workgroup's K range
 
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-  const int nwg = tiles_n * tiles_m;
+  const int nwg = tiles_n * tiles_m * S;
   int bid = blockIdx.x;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // the S workgroups of a tile are neighbours in the remapped order: same XCD (they share the tile's operand panels' neighbours in L2)
+  const int tile_lin = S > 1 ? bid / S : bid, sp = S > 1 ? bid - tile_lin * S : 0;
+  const size_t kbase = (size_t)sp * np * RB;  // byte offset of this K range inside an operand row
   int tm, tn;
-  tile_of(bid, tiles_m, tiles_n, a.gm, tm, tn);
+  tile_of(tile_lin, tiles_m, tiles_n, a.gm, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- DMA: 4 + 4 pieces of 1 KiB per wave and pair; piece j of an operand covers tile rows (j * NWAVES + wave) * 8 .. + 7 ----
@@ -510,9 +655,9 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
       mdst[b][q] = __builtin_amdgcn_readfirstlane(lds_base + (q < PPW ? 0 : W_BASE) + b * OP_BYTES + ((q % PPW) * NWAVES + wave) * 1024);
   auto issue_piece = [&](int p, const uint32_t (&dst)[2 * PPW], int q) {  // piece q of pair p: q < 4 activations, else weights
     if (q < PPW)
-      glds16(a.a + (size_t)p * RB, asrc[q], dst[q]);
+      glds16(a.a + kbase + (size_t)p * RB, asrc[q], dst[q]);
     else
-      glds16(a.w + (size_t)p * RB, wsrc[q - PPW], dst[q]);
+      glds16(a.w + kbase + (size_t)p * RB, wsrc[q - PPW], dst[q]);
   };
 
   // ---- fragment reads: one ds_read_b128 per 16-row fragment and k-step; chunk 4 * half + (lane >> 4) of the lane's row ----
@@ -671,6 +816,16 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
   }
 
   QH_N8_STAMP(2);
+  if (S > 1) {
+    splitk_store<KIND, NJ, NWAVES>(a, acc, S, tile_lin, sp, tid);
+    if (S == 2)
+      splitk_reduce<ODT, KIND, NJ, BM, BN, NWAVES, 2>(a, smem, tile_lin, sp, m0, n0, wm, wn, wave, lane, tid);
+    else if (S == 4)
+      splitk_reduce<ODT, KIND, NJ, BM, BN, NWAVES, 4>(a, smem, tile_lin, sp, m0, n0, wm, wn, wave, lane, tid);
+    else
+      splitk_reduce<ODT, KIND, NJ, BM, BN, NWAVES, 8>(a, smem, tile_lin, sp, m0, n0, wm, wn, wave, lane, tid);
+    return;
+  }
   epilogue<ODT, KIND, NJ, BM, BN>(a, acc, smem, m0, n0, wm, wn, wave, lane);
 #ifdef QH_N8_STAMPS
   QH_N8_STAMP(3);
@@ -685,7 +840,7 @@ static int launch_r128(const Args& a, hipStream_t stream) {
   constexpr int need = 2 * 2 * T * 128;  // two buffers of 128-byte rows: 128 KiB (64 KiB for the 128-tile); the epilogue parks in it
   const int tiles = ((a.N + T - 1) / T) * ((a.M + T - 1) / T);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_r128_kernel<ODT, KIND, SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, need);
-  hipLaunchKernelGGL((qbytes_native8_r128_kernel<ODT, KIND, SMALL>), dim3(tiles), dim3(SMALL ? 256 : 512), need, stream, a);
+  hipLaunchKernelGGL((qbytes_native8_r128_kernel<ODT, KIND, SMALL>), dim3(tiles * a.S), dim3(SMALL ? 256 : 512), need, stream, a);
   return launch_status();
 }
 
@@ -705,16 +860,69 @@ static int launch_cfg(const Args& a, hipStream_t stream) {
   return launch_status();
 }
 
-template <int ODT, int KIND>
-static int launch(const Args& a, hipStream_t stream) {
-  // int8 / 16-bit: 256-tiles when they give every CU at least ~3/8 of a tile, otherwise 128-tiles.  fp8 (paired MX loop):
-  // 128-tiles as long as all of them are resident at once, two per CU.  Measured, K = 4096, us with 256- -> 128-tiles:
-  // int8 (768,8192) 43 -> 44, (1024,8192) 50 -> 56; fp8 (768,8192) 51 -> 39, (1024,8192) 56 -> 47, (1280,8192) 56 -> 68
-  const int small_env = env_int("QUANTO_HIP_NATIVE8_SMALL", -1);  // experiments
-  const int64_t tiles256 = (int64_t)((a.N + 255) / 256) * ((a.M + 255) / 256), tiles128 = (int64_t)((a.N + 127) / 128) * ((a.M + 127) / 128);
+// ---- launch plan: tile size and K split ------------------------------------------------------------------------------------------------
+// Measured on the 128-byte-row kernels (r6, profiles/r06_native8_split_k.md; us, int8 / fp8, hipGraph replay):
+//   * tile: 128-tiles win whenever all of them are resident at once (two per CU), for int8 as for fp8 - (2048,4096,4096) 42.6 -> 35.3 / 32.1,
+//     (512,14336,4096) 41.5 -> 32.2 / 30.3, (768,8192,4096) 41.4 -> 30.3 / 28.2, (1024,8192,8192) 75.2 -> 66.4 / 60.6 (r5's opposite finding for int8 was taken
+//     on the 64-byte-row kernel);
+//   * K split: every split workgroup sends its 64 KiB (256 KiB for a 256-tile) accumulator tile through memory and back - S x M x N x 8 bytes of fabric traffic
+//     next to (M + N) x K operand bytes.  It pays where K is long for the output it feeds and the unsplit grid leaves CUs or residency slots idle:
+//     (512,4096,14336) 68.5 / 70.2 -> 48.0 / 44.5, (256,8192,8192) 41 -> 32, (128,4096,4096) 18.1 / 21.6 -> 13.4 / 14.3, (32,4096,14336) 67 -> 28; it loses on
+//     everything squarer ((1024,4096,4096) 25 -> 38 with four-way split 256-tiles: 64 MB of partials for a 38 MB problem), and 256-tiles split S ways never beat
+//     128-tiles split S / 2 ways (their partial tile is four times the size).  QUANTO_HIP_NATIVE8_SMALL / _SPLIT force a configuration (tests, sweeps).
+struct Plan {
+  bool small;
+  int S;
+};
+template <int KIND>
+static Plan make_plan(const Args& a, bool have_ws) {
   constexpr int ES = (KIND == K_BF16 || KIND == K_F16) ? 2 : 1;
-  constexpr bool FP8 = KIND == K_F8E4M3 || KIND == K_F8E5M2;
-  const bool small = small_env >= 0 ? small_env != 0 : (FP8 && (a.K * ES) % 128 == 0 ? tiles128 <= 512 : tiles256 < 96);
+  constexpr bool BYTE = ES == 1;
+  const int small_env = env_int("QUANTO_HIP_NATIVE8_SMALL", -1), split_env = env_int("QUANTO_HIP_NATIVE8_SPLIT", 0);  // experiments / tests
+  const int64_t tiles256 = (int64_t)((a.N + 255) / 256) * ((a.M + 255) / 256), tiles128 = (int64_t)((a.N + 127) / 128) * ((a.M + 127) / 128);
+  const bool row128 = (a.K * ES) % 128 == 0 && env_int("QUANTO_HIP_NATIVE8_ROW128", 1) != 0;
+  // 8-bit operands from 128-byte rows: 128-tiles as long as all of them are resident at once; 16-bit operands (the dense GEMM behind int4 prefill) and the
+  // 64-byte-row kernel: 256-tiles when they give every CU at least ~3/8 of a tile
+  Plan p{small_env >= 0 ? small_env != 0 : (BYTE && row128 ? tiles128 <= 512 : tiles256 < 96), 1};
+  if (!row128 || !have_ws || split_env == 1) return p;
+  const int np = a.K * ES / 128;
+  // S in {2, 4, 8} (a slice = 8 / S token fragments of every wave), 2 + S state words per tile in the counter region, and all tiles * S workgroups on the chip at
+  // once (256 CUs x one 256-tile / two 128-tile workgroups): the tail does not need that to be correct, only to be fast
+  auto fits = [&](int64_t tiles, int S, bool small_tile) {
+    return (S == 2 || S == 4 || S == 8) && np % S == 0 && np / S >= 2 && tiles * (2 + S) * 4 <= (int64_t)QUANTO_HIP_WS_COUNTER_BYTES &&
+           tiles * S <= (small_tile ? 512 : 256);
+  };
+  if (split_env > 1) {  // forced: with the tile QUANTO_HIP_NATIVE8_SMALL asks for (default: 256-tiles)
+    p.small = small_env > 0;
+    p.S = fits(p.small ? tiles128 : tiles256, split_env, p.small) ? split_env : 1;
+    return p;
+  }
+  if (!BYTE || !p.small) return p;
+  // AUTO (128-tiles): four ways for a handful of tiles (K >= 4096) or a long K (>= 3072 per range), two ways while a range keeps K >= 4096
+  if (tiles128 <= 64 && np >= 32 && fits(tiles128, 4, true)) return Plan{true, 4};
+  if (np >= 96 && fits(tiles128, 4, true)) return Plan{true, 4};
+  if (np >= 64 && tiles128 <= 128 && fits(tiles128, 2, true)) return Plan{true, 2};  // (beyond one split workgroup per CU the partial traffic eats the gain: (512,8192,8192) 44.1 -> 46.0)
+  return p;
+}
+template <int KIND>
+static size_t plan_workspace(const Plan& p, int64_t M, int64_t N) {
+  if (p.S <= 1) return 0;
+  const int T = p.small ? 128 : 256;
+  const int64_t tiles = ((N + T - 1) / T) * ((M + T - 1) / T);
+  return (size_t)QUANTO_HIP_WS_COUNTER_BYTES + (size_t)tiles * p.S * ((size_t)T * T * 4);  // one 4-byte accumulator per tile element and split
+}
+
+template <int ODT, int KIND>
+static int launch(Args a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  constexpr int ES = (KIND == K_BF16 || KIND == K_F16) ? 2 : 1;
+  const bool ws_ok = workspace && reinterpret_cast<uintptr_t>(workspace) % 16 == 0;
+  Plan p = make_plan<KIND>(a, ws_ok);
+  if (p.S > 1 && workspace_bytes < plan_workspace<KIND>(p, a.M, a.N)) p = make_plan<KIND>(a, false);
+  a.S = p.S;
+  a.counters = p.S > 1 ? reinterpret_cast<int*>(workspace) : nullptr;
+  a.partials = p.S > 1 ? reinterpret_cast<uint8_t*>(workspace) + QUANTO_HIP_WS_COUNTER_BYTES : nullptr;
+  a.poll_ticks = env_int("QUANTO_HIP_NATIVE8_POLL_TICKS", 20000);  // tests: 0 = nobody waits, the last arriver reduces every slice it finds abandoned
+  const bool small = p.small;
   // 128-byte rows (full-line vector-L1 fills, one barrier per 128 bytes of K) whenever K allows
   if ((a.K * ES) % 128 == 0 && env_int("QUANTO_HIP_NATIVE8_ROW128", 1) != 0)
     return small ? launch_r128<ODT, KIND, true>(a, stream) : launch_r128<ODT, KIND, false>(a, stream);
@@ -722,6 +930,7 @@ static int launch(const Args& a, hipStream_t stream) {
   // reachable only where the 128-byte-row kernel applies as well, i.e. through QUANTO_HIP_NATIVE8_ROW128=0, and left the product library; the
   // loop stays in the source for probes built with -DQH_N8_EXPERIMENTS)
 #ifdef QH_N8_EXPERIMENTS
+  constexpr bool FP8 = KIND == K_F8E4M3 || KIND == K_F8E5M2;
   if (FP8 && (a.K * ES) % 128 == 0 && env_int("QUANTO_HIP_PAIRED", 1) != 0)
     return small ? launch_cfg<ODT, KIND, true, true>(a, stream) : launch_cfg<ODT, KIND, true, false>(a, stream);
 #endif
@@ -740,9 +949,9 @@ bool dense_mm_large_supported(int64_t M, int64_t N, int64_t K, int dtype) {
 int dense_mm_large(const void* x, const void* w, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int dtype, hipStream_t stream) {
   if (!dense_mm_large_supported(M, N, K, dtype)) return QUANTO_HIP_ENOTSUP;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16) return QUANTO_HIP_EALIGN;
-  n8::Args args{reinterpret_cast<const uint8_t*>(x), reinterpret_cast<const uint8_t*>(w), nullptr, bias, y, (int)M, (int)N, (int)K, n8::raster_group()};
-  if (dtype == QUANTO_HIP_BF16) return n8::launch<QUANTO_HIP_BF16, n8::K_BF16>(args, stream);
-  return n8::launch<QUANTO_HIP_F16, n8::K_F16>(args, stream);
+  n8::Args args{reinterpret_cast<const uint8_t*>(x), reinterpret_cast<const uint8_t*>(w), nullptr, bias, y, (int)M, (int)N, (int)K, n8::raster_group(), 1, nullptr, nullptr, 0};
+  if (dtype == QUANTO_HIP_BF16) return n8::launch<QUANTO_HIP_BF16, n8::K_BF16>(args, nullptr, 0, stream);
+  return n8::launch<QUANTO_HIP_F16, n8::K_F16>(args, nullptr, 0, stream);
 }
 
 bool qbytes_native8_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
@@ -754,15 +963,28 @@ bool qbytes_native8_supported(int64_t M, int64_t N, int64_t K, int a_dtype, int 
          N < (1 << 30);
 }
 
+static int native8_kind(int a_dtype) { return a_dtype == QUANTO_HIP_I8 ? n8::K_I8 : a_dtype == QUANTO_HIP_F8_E4M3FN ? n8::K_F8E4M3 : n8::K_F8E5M2; }
+
+// split-K scratch for this problem: [QUANTO_HIP_WS_COUNTER_BYTES of arrival counters, zero on entry and on exit | partial accumulator tiles]; 0 = the plan does not split
+size_t qbytes_native8_workspace(int64_t M, int64_t N, int64_t K, int a_dtype, int b_dtype, int out_dtype) {
+  if (!qbytes_native8_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return 0;
+  n8::Args args{nullptr, nullptr, nullptr, nullptr, nullptr, (int)M, (int)N, (int)K, 1, 1, nullptr, nullptr, 0};
+  switch (native8_kind(a_dtype)) {
+    case n8::K_I8: return n8::plan_workspace<n8::K_I8>(n8::make_plan<n8::K_I8>(args, true), M, N);
+    case n8::K_F8E4M3: return n8::plan_workspace<n8::K_F8E4M3>(n8::make_plan<n8::K_F8E4M3>(args, true), M, N);
+    default: return n8::plan_workspace<n8::K_F8E5M2>(n8::make_plan<n8::K_F8E5M2>(args, true), M, N);
+  }
+}
+
 int qbytes_mm_native8(const void* a, const void* b, const void* s, const void* bias, void* y, int64_t M, int64_t N, int64_t K, int a_dtype,
-                      int b_dtype, int out_dtype, hipStream_t stream) {
+                      int b_dtype, int out_dtype, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!qbytes_native8_supported(M, N, K, a_dtype, b_dtype, out_dtype)) return QUANTO_HIP_ENOTSUP;
   if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16) return QUANTO_HIP_EALIGN;
-  n8::Args args{reinterpret_cast<const uint8_t*>(a), reinterpret_cast<const uint8_t*>(b), s, bias, y, (int)M, (int)N, (int)K, n8::raster_group()};
+  n8::Args args{reinterpret_cast<const uint8_t*>(a), reinterpret_cast<const uint8_t*>(b), s, bias, y, (int)M, (int)N, (int)K, n8::raster_group(), 1, nullptr, nullptr, 0};
 #define QH_KIND(ODT)                                                                  \
-  if (a_dtype == QUANTO_HIP_I8) return n8::launch<ODT, n8::K_I8>(args, stream);       \
-  if (a_dtype == QUANTO_HIP_F8_E4M3FN) return n8::launch<ODT, n8::K_F8E4M3>(args, stream); \
-  return n8::launch<ODT, n8::K_F8E5M2>(args, stream)
+  if (a_dtype == QUANTO_HIP_I8) return n8::launch<ODT, n8::K_I8>(args, workspace, workspace_bytes, stream);       \
+  if (a_dtype == QUANTO_HIP_F8_E4M3FN) return n8::launch<ODT, n8::K_F8E4M3>(args, workspace, workspace_bytes, stream); \
+  return n8::launch<ODT, n8::K_F8E5M2>(args, workspace, workspace_bytes, stream)
   if (out_dtype == QUANTO_HIP_BF16) { QH_KIND(QUANTO_HIP_BF16); }
   if (out_dtype == QUANTO_HIP_F16) { QH_KIND(QUANTO_HIP_F16); }
   QH_KIND(QUANTO_HIP_F32);

@@ -136,6 +136,15 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.quanto_hip_qbytes_mm_workspace_size(1024, 4096, 4096, 2, 3, 2, 0) == 0  # 256 tiles: every CU has one
     assert lib.quanto_hip_qbytes_mm_workspace_size(512, 4096, 14336, 2, 3, 2, 0) == 4096 + 128 * 2 * 128 * 128 * 4  # fixed counter region + fp32 partials
     assert lib.quanto_hip_qbytes_mm_pick(4096, 4096, 4096, 3, 3, 2) == 6                         # int8 activations: native8
+    # native8 (r6): 128-tiles split over K where K is long for the output it feeds - (256,8192,8192) = 128 tiles x 2, (512,4096,14336) = 128 tiles x 4,
+    # (128,4096,4096) = 32 tiles x 4; int32 / fp32 partial tiles of 64 KiB
+    assert lib.quanto_hip_qbytes_mm_workspace_size(256, 8192, 8192, 5, 5, 2, 0) == 4096 + 128 * 2 * 128 * 128 * 4
+    assert lib.quanto_hip_qbytes_mm_workspace_size(512, 8192, 8192, 3, 3, 2, 0) == 0              # 256 tiles: two split workgroups per CU lose to none
+    assert lib.quanto_hip_qbytes_mm_workspace_size(512, 4096, 14336, 3, 3, 2, 0) == 4096 + 128 * 4 * 128 * 128 * 4
+    assert lib.quanto_hip_qbytes_mm_workspace_size(128, 4096, 4096, 5, 5, 2, 0) == 4096 + 32 * 4 * 128 * 128 * 4
+    assert lib.quanto_hip_qbytes_mm_workspace_size(1024, 4096, 4096, 3, 3, 2, 0) == 0             # 256 tiles, K = 4096: not split
+    assert lib.quanto_hip_qbytes_mm_workspace_size(4096, 4096, 4096, 3, 3, 2, 0) == 0             # 256-tiles: not split
+    assert lib.quanto_hip_qbytes_mm_workspace_size(512, 8192, 8128, 3, 3, 2, 0) == 0              # K % 128 != 0: the 64-byte-row kernel has no split
 
 
 def test_conv2d_entries_reject_bad_arguments_without_a_gpu():
