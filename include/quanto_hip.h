@@ -312,6 +312,17 @@ int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, c
                              void* stream);
 
 /*
+ * F.conv2d with groups = in_channels (depthwise; channel multiplier OC / cin >= 1) and an int8 / fp8 weight [OC, 1, KH, KW] (r6) - the layer type for which
+ * QConv2d.forward (nn/qconv2d.py:54-55) otherwise keeps the reference's dequantize + float convolution:
+ *   y[b, oc, oh, ow] = scale[oc] * sum_{i,j} x[b, oc / (OC / cin), oh*sh - ph + i*dh, ow*sw - pw + j*dw] * w[oc, 0, i, j]  (+ bias[oc]).
+ * No GEMM in it (KH*KW products per output): a direct stencil kernel, csrc/qconv_depthwise.hip.  Same tensor layouts, dtypes, argument checks and status
+ * codes as quanto_hip_qbytes_conv2d; `cin` is the number of INPUT channels (= groups), OC a multiple of it; any window.
+ */
+int quanto_hip_qbytes_conv2d_depthwise(const void* x, const void* w, const void* scales, const void* bias, void* y, int64_t B, int64_t cin, int64_t H,
+                                       int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,
+                                       int pad_w, int dil_h, int dil_w, int a_dtype, int b_dtype, int out_dtype, void* stream);
+
+/*
  * Scratch bytes the convolution kernels want for their K split (0: the problem is not split): when the 128 x 128 output tiles alone cannot
  * occupy the chip the K-tiles are dealt over up to 64 workgroups per tile, whose fp32 sums a second kernel adds in split order (deterministic,
  * no atomics, nothing to zero).  K = cin * KH * KW.  Both quanto_hip_q*_conv2d entries take the buffer (16-byte aligned); with NULL / too few

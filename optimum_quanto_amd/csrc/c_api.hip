@@ -34,6 +34,9 @@ bool qbits_conv2d_supported(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t
 int qbits_conv2d_mfma(const void*, const uint8_t*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
                       int64_t, int64_t, int, int, int, int, int, int, const PackedGeom&, int, bool, void*, size_t, hipStream_t);
 size_t conv2d_workspace(int64_t, int64_t, int64_t);
+// depthwise convolution with an 8-bit weight (r6, qconv_depthwise.hip)
+int qbytes_conv2d_depthwise(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
+                            int64_t, int, int, int, int, int, int, int, int, int, hipStream_t);
 bool conv2d_last_was_rows();
 size_t conv2d_dense_weight_bytes(int64_t, int64_t);
 bool conv2d_rows_eligible(int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int64_t);
@@ -724,6 +727,21 @@ int quanto_hip_qbytes_conv2d(const void* x, const void* w, const void* scales, c
   const int r = qbytes_conv2d_mfma(x, w, scales, bias, y, B, cin, H, W, OC, KH, KW, OH, OW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, a_dtype,
                                    b_dtype, out_dtype, workspace, workspace_bytes, reinterpret_cast<hipStream_t>(stream));
   if (r == QUANTO_HIP_OK) set_last_kernel(conv2d_last_was_rows() ? "conv2d_mfma_rows" : "conv2d_mfma");
+  return r;
+}
+
+int quanto_hip_qbytes_conv2d_depthwise(const void* x, const void* w, const void* scales, const void* bias, void* y, int64_t B, int64_t cin, int64_t H,
+                                       int64_t W, int64_t OC, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int stride_h, int stride_w, int pad_h,
+                                       int pad_w, int dil_h, int dil_w, int a_dtype, int b_dtype, int out_dtype, void* stream) {
+  if (B < 0 || cin <= 0 || H <= 0 || W <= 0 || OC <= 0 || KH <= 0 || KW <= 0 || OH < 0 || OW < 0 || OC % cin != 0) return QUANTO_HIP_EINVAL;
+  if (stride_h <= 0 || stride_w <= 0 || pad_h < 0 || pad_w < 0 || dil_h <= 0 || dil_w <= 0) return QUANTO_HIP_EINVAL;
+  if (OH != (H + 2 * pad_h - dil_h * (KH - 1) - 1) / stride_h + 1 || OW != (W + 2 * pad_w - dil_w * (KW - 1) - 1) / stride_w + 1) return QUANTO_HIP_EINVAL;
+  if (!is_float_dtype(out_dtype)) return QUANTO_HIP_ENOTSUP;
+  if (B == 0 || OH == 0 || OW == 0) return QUANTO_HIP_OK;
+  if (!x || !w || !scales || !y) return QUANTO_HIP_EINVAL;
+  const int r = qbytes_conv2d_depthwise(x, w, scales, bias, y, B, cin, H, W, OC, KH, KW, OH, OW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, a_dtype,
+                                        b_dtype, out_dtype, reinterpret_cast<hipStream_t>(stream));
+  if (r == QUANTO_HIP_OK) set_last_kernel("conv2d_depthwise");
   return r;
 }
 

@@ -65,6 +65,7 @@ struct Args {
   int S;                 // K split: blockIdx.z handles groups [z * G / S, (z + 1) * G / S)
   int* counters;         // [tiles] arrival counters, zero on entry and on exit (S > 1)
   float* partials;       // [tiles][S][MI][512 lanes] float4
+  int ablate;            // QUANTO_HIP_A8_ABLATE (timing experiments, WRONG results): 1 no fold, 2 no matrix steps, 4 the DMA re-reads tile 0, 8 no weight unpack
 };
 
 template <int AK>
@@ -117,6 +118,7 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_a8_fused_kernel(const Arg
   }
   const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
   auto issue_tile = [&](int kt_tile, int stage) {
+    if (a.ablate & 4) kt_tile = 0;
     const uint32_t st = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE_BYTES);
 #pragma unroll
     for (int u = 0; u < XP; ++u) glds16(a.a + (size_t)(kt0 + kt_tile) * BK, xsrc[u], st + (wave * XP + u) * 1024);
@@ -230,7 +232,9 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_a8_fused_kernel(const Arg
 #pragma unroll
       for (int d = 0; d < 8; ++d) {
         const uint32_t s = raw[d] >> nib_shift;
-        if constexpr (AK == A_I8) {
+        if (a.ablate & 8) {
+          op[d] = raw[d];
+        } else if constexpr (AK == A_I8) {
           op[d] = s & nibmask;
         } else {
           const uint32_t q7 = s & 0x07070707u;
@@ -249,16 +253,18 @@ __global__ void __launch_bounds__(WAVES * 64, 1) qbits_a8_fused_kernel(const Arg
         const int i = 2 * (s >> 2) + (s & 1), h = (s >> 1) & 1;
         const i32x4 wa = h == 0 ? i32x4{(int)op[0], (int)op[1], (int)op[2], (int)op[3]} : i32x4{(int)op[4], (int)op[5], (int)op[6], (int)op[7]};
         const uint4& xv = h == 0 ? xl[i] : xh[i];
-        cg[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, __builtin_bit_cast(i32x4, xv), h == 0 ? i32x4{0, 0, 0, 0} : cg[i], 0, 0, 0);
+        if (!(a.ablate & 2)) cg[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, __builtin_bit_cast(i32x4, xv), h == 0 ? i32x4{0, 0, 0, 0} : cg[i], 0, 0, 0);
       } else {
         const int i = s;
         const i32x8 wa = i32x8{(int)op[0], (int)op[1], (int)op[2], (int)op[3], (int)op[4], (int)op[5], (int)op[6], (int)op[7]};
         const i32x8 xa = i32x8{(int)xl[i].x, (int)xl[i].y, (int)xl[i].z, (int)xl[i].w, (int)xh[i].x, (int)xh[i].y, (int)xh[i].z, (int)xh[i].w};
-        cg[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);  // e4m3 x e4m3, scales 2^0
+        if (!(a.ablate & 2)) cg[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);  // e4m3 x e4m3, scales 2^0
       }
       if constexpr (have_prev) {
+        if (!(a.ablate & 1)) {
 #pragma unroll
-        for (int q = s * FPS; q < (s + 1) * FPS; ++q) fold_slice(pg, q);
+          for (int q = s * FPS; q < (s + 1) * FPS; ++q) fold_slice(pg, q);
+        }
       }
       // the fragment two ahead, once per token fragment (int8: fragments 2p+2, 2p+3 behind steps 0 and 2 of pair p - their registers are free: the
       // fragments of pair p+1 are not in use yet)
@@ -468,7 +474,8 @@ int qbits_mm_a8(const void* act, const void* act_scale, const uint8_t* packed, c
   }
   const a8::Args a{reinterpret_cast<const uint8_t*>(act), act_scale, packed, scale, shift, bias, y, (int)M, (int)g.N, (int)g.K, (int)g.G, p.S,
                    reinterpret_cast<int*>(workspace),
-                   p.S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + QUANTO_HIP_WS_COUNTER_BYTES) : nullptr};
+                   p.S > 1 ? reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + QUANTO_HIP_WS_COUNTER_BYTES) : nullptr,
+                   env_int("QUANTO_HIP_A8_ABLATE", 0)};
   if (dtype == QUANTO_HIP_BF16)
     return a_dtype == QUANTO_HIP_I8 ? a8::launch_shift<QUANTO_HIP_BF16, a8::A_I8>(a, p.bm, int_shift, stream)
                                     : a8::launch_shift<QUANTO_HIP_BF16, a8::A_F8E4M3>(a, p.bm, int_shift, stream);

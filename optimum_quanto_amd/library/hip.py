@@ -152,6 +152,8 @@ class _Bindings:
         c.quanto_hip_pack.argtypes = [vp, vp, i64, i64, ci, vp]
         c.quanto_hip_qbytes_conv2d.restype = ci
         c.quanto_hip_qbytes_conv2d.argtypes = [vp, vp, vp, vp, vp] + [i64] * 9 + [ci] * 9 + [vp, ctypes.c_size_t, vp]
+        c.quanto_hip_qbytes_conv2d_depthwise.restype = ci
+        c.quanto_hip_qbytes_conv2d_depthwise.argtypes = [vp, vp, vp, vp, vp] + [i64] * 9 + [ci] * 9 + [vp]
         c.quanto_hip_conv2d_workspace_size.restype = i64
         c.quanto_hip_conv2d_workspace_size.argtypes = [i64] * 5
         c.quanto_hip_qbits_conv2d_workspace_size.restype = i64
@@ -331,11 +333,27 @@ class _Bindings:
                 w.dtype in (torch.int8, torch.float8_e4m3fn, torch.float8_e5m2) and
                 self.conv2d_geometry_ok(tuple(x.shape), tuple(w.shape), stride, padding, dilation))
 
+    def qbytes_conv2d_depthwise_supported(self, x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1)) -> bool:
+        """Depthwise layers (r6): weight [OC, 1, KH, KW] on an input of C > 1 channels with OC a multiple of C; NCHW 16-bit activations, 8-bit OCP weight."""
+        if not (x.is_cuda and x.dim() == 4 and w.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16) and
+                w.dtype in (torch.int8, torch.float8_e4m3fn, torch.float8_e5m2)):
+            return False
+        B, C, H, W = x.shape
+        OC, wc, KH, KW = w.shape
+        if wc != 1 or C < 2 or OC % C != 0 or min(stride) <= 0 or min(dilation) <= 0 or min(padding) < 0:
+            return False
+        OH = self.conv2d_out_size(H, KH, stride[0], padding[0], dilation[0])
+        OW = self.conv2d_out_size(W, KW, stride[1], padding[1], dilation[1])
+        return (B >= 1 and OH >= 1 and OW >= 1 and B * C * H * W < (1 << 31) and B * OC * OH * OW < (1 << 31) and KH * KW <= 4096)
+
     def qbytes_conv2d(self, x, w, scales, bias, stride, padding, dilation):
-        """Dense convolution with an 8-bit weight [OC, C, KH, KW] and per-channel scales: im2col happens inside the kernel's staging loads."""
+        """Dense convolution with an 8-bit weight [OC, C, KH, KW] and per-channel scales: im2col happens inside the kernel's staging loads.  A weight
+        [OC, 1, KH, KW] on an input of C > 1 channels is the depthwise layer (groups = C): the stencil kernel of csrc/qconv_depthwise.hip."""
         self._require_cuda(x, w, scales, bias)
         B, C, H, W = x.shape
-        OC, _, KH, KW = w.shape
+        OC, wc, KH, KW = w.shape
+        if wc == 1 and C > 1:
+            return self._qbytes_conv2d_depthwise(x, w, scales, bias, stride, padding, dilation)
         OH = self.conv2d_out_size(H, KH, stride[0], padding[0], dilation[0])
         OW = self.conv2d_out_size(W, KW, stride[1], padding[1], dilation[1])
         x, w = x.contiguous(), w.contiguous()
@@ -351,6 +369,25 @@ class _Bindings:
                                                   padding[0], padding[1], dilation[0], dilation[1], _dt(x), _dt(w), _dt(y), _ptr(ws), ws_bytes,
                                                   self._stream(x))
         self._check(st, "qbytes_conv2d")
+        return y
+
+    def _qbytes_conv2d_depthwise(self, x, w, scales, bias, stride, padding, dilation):
+        B, C, H, W = x.shape
+        OC, _, KH, KW = w.shape
+        OH = self.conv2d_out_size(H, KH, stride[0], padding[0], dilation[0])
+        OW = self.conv2d_out_size(W, KW, stride[1], padding[1], dilation[1])
+        x, w = x.contiguous(), w.contiguous()
+        s = scales.reshape(-1).to(x.dtype).contiguous()
+        if s.numel() == 1:
+            s = s.expand(OC).contiguous()
+        if bias is not None:
+            bias = bias.to(x.dtype).contiguous()
+        y = torch.empty((B, OC, max(OH, 0), max(OW, 0)), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            st = self._c.quanto_hip_qbytes_conv2d_depthwise(_ptr(x), _ptr(w), _ptr(s), _ptr(bias), _ptr(y), B, C, H, W, OC, KH, KW, OH, OW, stride[0],
+                                                            stride[1], padding[0], padding[1], dilation[0], dilation[1], _dt(x), _dt(w), _dt(y),
+                                                            self._stream(x))
+        self._check(st, "qbytes_conv2d_depthwise")
         return y
 
     # -- quanto::qbits_conv2d (implicit GEMM, int4 dequantized while staged) -----------------------------------
@@ -661,7 +698,7 @@ class QuantoHipExtension(NativeLibrary):
             "quanto_hip",
             root_dir=csrc,
             lib_path=os.path.join(_PKG_DIR, "lib", "libquanto_hip.so"),
-            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qconv_mfma.hip", "qmm_mfma_large.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbits_a8_fused.hip", "qbits_mfma_large.hip", "qbytes_skinny.hip", "qmm_native8.hip", "qmm_f32.hip", "quantize.hip",
+            sources=["c_api.hip", "unpack.hip", "naive_mm.hip", "qbits_gemv.hip", "qbytes_gemv.hip", "qmm_mfma.hip", "qconv_mfma.hip", "qconv_depthwise.hip", "qmm_mfma_large.hip", "qmm_large_common.h", "qbits_skinny.hip", "qbits_mmv.hip", "qbits_mfma_fused.hip", "qbits_a8_fused.hip", "qbits_mfma_large.hip", "qbytes_skinny.hip", "qmm_native8.hip", "qmm_f32.hip", "quantize.hip",
                      "qh_common.h", os.path.join("..", "..", "include", "quanto_hip.h")],
         )
         self._bindings = None

@@ -24,6 +24,8 @@ When ``optimum.quanto`` itself is already imported in the process the ops exist;
 """
 from typing import Optional, Union
 
+import os
+
 import torch
 
 from ..tensor.dtypes import dtype_info
@@ -155,7 +157,8 @@ if _define("qbytes_mm_bias", "(Tensor A, Tensor B, Tensor scales, Tensor? bias) 
 def qbytes_conv2d_default(input, weight, scales, bias, stride, padding, dilation):
     """What the reference computes for F.conv2d on a WeightQBytesTensor (nn/qconv2d.py:54-55 -> qfallback): dequantize, float convolution."""
     w = scales.reshape(-1, 1, 1, 1).to(input.dtype) * weight.to(input.dtype)
-    return torch.nn.functional.conv2d(input, w, bias, tuple(stride), tuple(padding), tuple(dilation), 1)
+    groups = input.shape[1] // weight.shape[1]  # 1, or the channel count of a depthwise layer (weight [OC, 1, KH, KW])
+    return torch.nn.functional.conv2d(input, w, bias, tuple(stride), tuple(padding), tuple(dilation), groups)
 
 
 def qbytes_conv2d_hip(input, weight, scales, bias, stride, padding, dilation):
@@ -304,12 +307,19 @@ def qbits_mm_a8_default(input, input_scale, packed, scale, shift, bias, bits: in
     return torch.ops.quanto.qbits_mm(x, packed, scale, shift, bias, bits, group_size, out_features, in_features)
 
 
+_A8_MAX_TILES = int(os.environ.get("QUANTO_HIP_A8_MAX_TILES", "512")) if os.environ.get("QUANTO_HIP_EXPERIMENT", "0") not in ("", "0") else 512
+
+
 def qbits_mm_a8_hip(input, input_scale, packed, scale, shift, bias, bits: int, group_size: Optional[int], out_features: int, in_features: int):
     lib = quanto_hip.lib
     m = input.numel() // in_features if in_features else 0
     # batched-decode sizes keep the weight-streaming kernels (the activation is dequantized: M x K elements, nothing next to the weight stream);
     # from 64 rows on the stored integers / fp8 values go to the 8-bit matrix instructions
-    if (m > 64 and input.dtype in lib.A8_DTYPES and input_scale.numel() == 1
+    # ... while the output's 128 x 128 tiles are all resident at once (two workgroups per CU): the kernel moves 24 KiB through a CU's vector L1 per tile
+    # and group and is bound by that, not by the matrix pipe; beyond one residency round the dequantize-first sequence on the dense bf16 GEMM is faster
+    # (r6 sweep, profiles/r06_w4a8_crossover.jsonl: (2048,4096,4096) 93 vs 109 us, (4096,4096,4096) 184 vs 146, (768,14336,4096) 137 vs 114)
+    tiles = -(-m // 128) * -(-out_features // 128)
+    if (64 < m and tiles <= _A8_MAX_TILES and input.dtype in lib.A8_DTYPES and input_scale.numel() == 1
             and lib.qbits_mm_a8_workspace(m, out_features, in_features, bits, group_size, input.dtype, scale.dtype) >= 0):
         return lib.qbits_mm_a8(input, input_scale, packed, scale, shift, bias, bits, group_size, out_features, in_features)
     return qbits_mm_a8_default(input, input_scale, packed, scale, shift, bias, bits, group_size, out_features, in_features)

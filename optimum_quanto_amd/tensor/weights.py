@@ -83,14 +83,20 @@ def _implicit_conv2d(input, weight, scale, bias, stride, padding, dilation, grou
     C*kh*kw), no gradient wanted.  None otherwise: the caller then lowers to a materialised im2col + GEMM (conv2d_as_gemm) or keeps the reference behaviour."""
     from ..library.hip import quanto_hip
 
-    if groups != 1 or isinstance(padding, str) or type(input) is not torch.Tensor or input.dim() != 4 or input.device.type != "cuda":
+    if isinstance(padding, str) or type(input) is not torch.Tensor or input.dim() != 4 or input.device.type != "cuda":
         return None
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (input, weight, bias)):
         return None
     stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+    pair = _pair
+    if groups != 1:
+        # r6: depthwise layers (groups = in_channels, weight [OC, 1, KH, KW]) have their own stencil kernel; other groupings keep the reference behaviour
+        if (weight.dim() == 4 and groups == input.shape[1] and weight.shape[1] == 1
+                and quanto_hip.lib.qbytes_conv2d_depthwise_supported(input, weight._data, stride, padding, dilation)):
+            return torch.ops.quanto.qbytes_conv2d(input, weight._data, scale, bias, pair(stride), pair(padding), pair(dilation))
+        return None
     if weight.dim() != 4 or input.shape[1] != weight.shape[1] or not quanto_hip.lib.qbytes_conv2d_supported(input, weight._data, stride, padding, dilation):
         return None
-    pair = _pair
     # (until r5 pointwise convolutions with ONE K-tile - fewer than 128 input channels - went to a permuted view + the tuned GEMM kernels: 21.5 vs 25.0 us at
     # (8,64,56,56) -> 256; with the r5 gather and epilogue the convolution kernel takes that shape in 12.0 us: profiles/r05_qconv2d_paths_grid.jsonl)
     return torch.ops.quanto.qbytes_conv2d(input, weight._data, scale, bias, pair(stride), pair(padding), pair(dilation))

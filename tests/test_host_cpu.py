@@ -161,6 +161,14 @@ def test_conv2d_entries_reject_bad_arguments_without_a_gpu():
     assert f(None, None, None, None, None, *geom, 1, 1, 1, 1, 1, 0, 2, 3, 2, None, 0, None) == -1           # dilation 0
     assert f(None, None, None, None, None, *geom, 1, 1, 1, 1, 1, 1, 2, 3, 3, None, 0, None) == -2           # int8 output
     assert f(None, None, None, None, None, 0, 8, 8, 8, 8, 3, 3, 8, 8, 1, 1, 1, 1, 1, 1, 2, 3, 2, None, 0, None) == 0   # empty batch
+    # depthwise entry (r6): the same checks; OC must be a multiple of the input channels
+    h = lib.quanto_hip_qbytes_conv2d_depthwise
+    h.restype, h.argtypes = ci, [vp] * 5 + [i64] * 9 + [ci] * 9 + [vp]
+    assert h(None, None, None, None, None, *geom, 1, 1, 1, 1, 1, 1, 2, 3, 2, None) == -1                     # null tensors
+    assert h(None, None, None, None, None, 1, 8, 8, 8, 12, 3, 3, 8, 8, 1, 1, 1, 1, 1, 1, 2, 3, 2, None) == -1  # OC = 12 on 8 input channels
+    assert h(None, None, None, None, None, 1, 8, 8, 8, 8, 3, 3, 7, 8, 1, 1, 1, 1, 1, 1, 2, 3, 2, None) == -1   # OH does not follow from the geometry
+    assert h(None, None, None, None, None, *geom, 1, 1, 1, 1, 1, 1, 2, 3, 3, None) == -2                     # int8 output
+    assert h(None, None, None, None, None, 0, 8, 8, 8, 8, 3, 3, 8, 8, 1, 1, 1, 1, 1, 1, 2, 3, 2, None) == 0    # empty batch
     g = lib.quanto_hip_qbits_conv2d
     g.restype, g.argtypes = ci, [vp] * 6 + [i64] * 9 + [ci] * 10 + [vp, sz, vp]
     assert g(None, None, None, None, None, None, *geom, 1, 1, 1, 1, 1, 1, 4, 0, 2, 2, None, 0, None) == -1  # null tensors

@@ -230,6 +230,59 @@ def test_qconv2d_implicit_gemm_gpu(dt, wq, cin, cout, k, s, p, d):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("wq", ["qint8", "qfloat8_e4m3fn", "qfloat8_e5m2"])
+@pytest.mark.parametrize("c,mult,k,s,p,d,hw", [(32, 1, 3, 1, 1, 1, (14, 14)), (48, 1, 3, 2, 1, 1, (15, 13)), (24, 2, 5, 1, 2, 1, (12, 17)), (16, 1, 7, 2, 3, 1, (20, 9)),
+                                                (40, 1, (3, 5), (2, 1), (1, 2), (1, 2), (13, 11)), (8, 3, 3, 1, 0, 2, (11, 10)), (64, 1, 1, 1, 0, 1, (7, 7)),
+                                                (20, 1, (2, 4), 1, (1, 0), 1, (9, 6)), (96, 1, 3, 1, 1, 1, (56, 56))])
+def test_qconv2d_depthwise_gpu(dt, wq, c, mult, k, s, p, d, hw):
+    """r6: depthwise layers (groups = in_channels; channel multipliers 1, 2, 3) with an int8 / fp8 weight on the stencil kernel of csrc/qconv_depthwise.hip -
+    the register windows (3, 5, 7), rectangular and even windows (the generic tap loop), strides, paddings, dilations, widths that are not a multiple of the four
+    columns a thread owns, a 56 x 56 MobileNet plane.  Gate: float64 grouped convolution on the stored integers / fp8 values, per-channel scale on the sum, the
+    reference's bias order (nn/qconv2d.py:54-55 dequantizes the weight and calls the float convolution)."""
+    torch.manual_seed(c + mult)
+    conv = torch.nn.Conv2d(c, c * mult, k, stride=s, padding=p, dilation=d, groups=c).to(TORCH_DT[dt])
+    q = Q.QConv2d.from_module(conv, weights=getattr(Q, wq))
+    Q.freeze(q)
+    q = q.cuda()
+    x = torch.randn(3, c, *hw).to(TORCH_DT[dt])
+    with torch.no_grad():
+        y = q(x.cuda())
+        assert quanto_hip.lib.last_kernel() == "conv2d_depthwise"
+        w64 = q.weight._data.cpu().double() if wq == "qint8" else q.weight._data.cpu().float().double()
+        prod = torch.nn.functional.conv2d(x.double(), w64, None, conv.stride, conv.padding, conv.dilation, groups=c)
+        prod = prod * q.weight._scale.cpu().double().reshape(1, -1, 1, 1)
+    assert y.shape == prod.shape and y.dtype == TORCH_DT[dt]
+    bias = to_numpy(q.bias).astype(np.float64).reshape(1, -1, 1, 1)
+    assert_close_with_bias(to_numpy(y), prod.numpy(), np.broadcast_to(bias, prod.shape), dt, f"depthwise conv {c}x{mult} k{k}")
+    q.bias = None
+    with torch.no_grad():
+        y0 = q(x.cuda())
+    assert_close_to_exact(to_numpy(y0), prod.numpy(), dt, f"depthwise conv {c}x{mult} k{k}, no bias")
+    # the reference's own tolerance against its dequantize-first result (tests/nn/test_qconv2d.py: assert_similar)
+    with torch.no_grad():
+        ref = torch.nn.functional.conv2d(x.cuda(), q.weight.dequantize(), None, conv.stride, conv.padding, conv.dilation, groups=c)
+    assert_similar(ref.float().cpu(), y0.float().cpu(), atol=1e-2 if dt == "bf16" else 1e-3)
+
+
+@pytest.mark.gpu
+def test_qconv2d_other_groupings_keep_the_reference_behaviour_gpu():
+    """groups = 2 on 8 channels is not a depthwise layer: the dispatch keeps dequantize + float convolution (no library kernel runs)."""
+    torch.manual_seed(1)
+    conv = torch.nn.Conv2d(8, 16, 3, padding=1, groups=2).to(torch.bfloat16)
+    q = Q.QConv2d.from_module(conv, weights=Q.qint8)
+    Q.freeze(q)
+    q = q.cuda()
+    x = torch.randn(2, 8, 9, 9, dtype=torch.bfloat16, device="cuda")
+    before = quanto_hip.lib.last_kernel()
+    with torch.no_grad():
+        y = q(x)
+        ref = torch.nn.functional.conv2d(x, q.weight.dequantize(), q.bias, 1, 1, 1, 2)
+    assert quanto_hip.lib.last_kernel() == before
+    torch.testing.assert_close(y, ref, rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("zp", [False, True])
 @pytest.mark.parametrize("cin,cout,k,s,p,d,gs", [(128, 96, 3, 1, 1, 1, 128), (64, 40, 3, 2, 0, 1, 64), (128, 64, (3, 5), (2, 1), (1, 2), (1, 2), 128),
                                                  (192, 130, 3, 1, 2, 2, 32), (64, 256, 3, 1, 1, 1, None), (32, 34, (2, 3), 1, 0, 1, 96),
