@@ -93,6 +93,8 @@ WORKLOADS = {
     "fp8a8": ("qbytes_f8f8", 4096, 4096, 4096, "fp8-e4m3fn x fp8-e4m3fn qbytes_mm (quantized activations), (M,K,N)=(4096,4096,4096)"),
     "cfg4_fp8a8": ("qbytes_f8f8", 512, 8192, 8192, "fp8-e4m3fn x fp8-e4m3fn qbytes_mm on the native fp8 MFMA (BASELINE configs[3] with quantized activations), (M,K,N)=(512,8192,8192)"),
     "cfg4_w8a8": ("qbytes_i8i8", 512, 8192, 8192, "int8 x int8 qbytes_mm (quantized activations), (M,K,N)=(512,8192,8192)"),
+    # r6: a Llama-3 down-projection at 512 tokens with quantized activations - 128 output tiles for K = 14336: the K split of qmm_native8.hip
+    "w8a8_down512": ("qbytes_i8i8", 512, 14336, 4096, "int8 x int8 qbytes_mm (quantized activations), Llama-3-8B down_proj at 512 tokens, (M,K,N)=(512,14336,4096)"),
     # r6: int4 weights x quantized activations on the 8-bit matrix instructions (quanto::qbits_mm_a8, csrc/qbits_a8_fused.hip)
     "w4a8": ("qbits_i4_a8i", 4096, 4096, 4096, "int8 activations x int4 qbits_mm_a8, group_size=128 scale+shift, (M,K,N)=(4096,4096,4096)"),
     "w4a8_512": ("qbits_i4_a8i", 512, 4096, 4096, "int8 activations x int4 qbits_mm_a8, group_size=128 scale+shift, (M,K,N)=(512,4096,4096)"),
@@ -123,7 +125,7 @@ WORKLOADS = {
     "int4_decode1_down": ("qbits_i4", 1, 14336, 4096, "bf16 x int4 qbits_mm, group_size=128 scale+shift, decode (M,K,N)=(1,14336,4096) (Llama-3-8B down_proj)"),
     "int4_decode32_up": ("qbits_i4", 32, 4096, 14336, "bf16 x int4 qbits_mm, group_size=128 scale+shift, batched decode (M,K,N)=(32,4096,14336)"),
 }
-DEFAULT_SUB = ["northstar", "cfg3", "cfg4", "cfg4_fp8a8", "w8a8", "fp8a8", "w4a8", "w4a8_512", "int4_prefill", "int4_prefill512", "gateup_fused", "int4_decode32",
+DEFAULT_SUB = ["northstar", "cfg3", "cfg4", "cfg4_fp8a8", "w8a8", "fp8a8", "w8a8_down512", "w4a8", "w4a8_512", "int4_prefill", "int4_prefill512", "gateup_fused", "int4_decode32",
                "qkv_fused32", "layer_decode_b1", "layer_decode_b32"]  # (q/k/v at M = 1 and the int8 gate/up launch of r2-r4 are inside layer_decode_b1 / --sub)
 # printed ONCE per JSON line (r2's line repeated this prose in every sub-result, grew past the driver's 8 KB stdout tail and lost
 # its first two sub-results): what cpu_baseline.kind == "reference" and each cpu_baseline.path code stand for
@@ -265,7 +267,7 @@ def make_step(kind, x, sets, K, N):
     return step
 
 
-REF_ROCM_FOR = ("cfg2", "cfg3", "northstar", "cfg4", "int4_prefill", "int4_prefill512", "w8a8", "fp8a8", "cfg4_fp8a8", "cfg4_w8a8", "w4a8", "w4a8_512", "w4afp8", "w4afp8_512")
+REF_ROCM_FOR = ("cfg2", "cfg3", "northstar", "cfg4", "int4_prefill", "int4_prefill512", "w8a8", "fp8a8", "cfg4_fp8a8", "cfg4_w8a8", "w8a8_down512", "w4a8", "w4a8_512", "w4afp8", "w4afp8_512")
 
 
 def make_ref_rocm_step(kind, x, wset, K, N):
@@ -612,10 +614,10 @@ def run_layer_decode(name, args, device, rank, world, dist, steps):
     if rank != 0:
         return None
     us, mall_us = elapsed * 1e6 / steps, m_elapsed * 1e6 / steps
-    out = {"name": name, "B": B, "launches": [n for n, _, _, _ in LAYER_LAUNCHES], "us_per_layer": round(us, 3), "event_us": round(dev_ms * 1e3 / steps, 3),
+    # (launches of a layer: q/k/v in one, o, gate/up in one, down - LAYER_LAUNCHES; r6: the list, the event time and the rotation count left the line)
+    out = {"name": name, "B": B, "us_per_layer": round(us, 3),
            "alg_bytes": int(nbytes), "GBs": round(nbytes * world / us / 1e3, 1), "bound": "hbm", "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
-           "rot": len(sets), "steps": steps, "kernel_us": None, "kernel_us_min": None, "traffic": None,
-           "cache_resident_us_per_layer": round(mall_us, 3), "cache_resident_GBs": round(nbytes / mall_us / 1e3, 1)}
+           "kernel_us": None, "traffic": None, "cache_resident_us_per_layer": round(mall_us, 3)}
     del sets
     torch.cuda.empty_cache()
     return out
@@ -653,7 +655,7 @@ def run_qconv2d(args, device, steps=50):
     flops = 2 * M * K * N
     io_bytes = c["B"] * c["C"] * c["H"] * c["W"] * 2 + M * N * 2
     out = {"name": CONV_NAME, "shape": f"({c['B']},{c['C']},{c['H']},{c['W']})->{c['OC']} 3x3 pad 1", "M": M, "K": K, "N": N, "alg_flops": flops,
-           "steps": steps, "kernel_us": None, "kernel_us_min": None, "traffic": None}
+           "kernel_us": None, "traffic": None}
     with torch.no_grad():
         for wq in ("qint8", "qint4"):
             q, x = build_qconv(wq, device)
@@ -668,8 +670,25 @@ def run_qconv2d(args, device, steps=50):
             out[f"{wq[1:]}_frac_hbm"] = round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)
             el, _ = timed_replay(lambda: torch.nn.functional.conv2d(x, w.dequantize(), bias, c["stride"], c["pad"]), steps, args, None, device, warmup=3)
             out[f"ref_rocm_{wq[1:]}_us"] = round(el * 1e6 / steps, 2)
-    out["bound"] = "the serial phases of a K-tile inside a workgroup - gather / staging / MFMA (DESIGN 4.8): both roofline fractions given"
-    out["ref_rocm"] = "dequantize + MIOpen conv; kernel_us / traffic: the int8 launch"
+    # r6: a depthwise layer of the same network family - (8,144,56,56) 3x3 pad 1, groups = 144, int8 weight - on the stencil kernel of csrc/qconv_depthwise.hip
+    # against the reference's sequence (dequantize the weight, grouped float convolution); HBM-bound: input + output once
+    with torch.no_grad():
+        import optimum_quanto_amd as Q
+        torch.manual_seed(1)
+        dconv = torch.nn.Conv2d(144, 144, 3, padding=1, groups=144).to(torch.bfloat16)
+        dq = Q.QConv2d.from_module(dconv, weights=Q.qint8)
+        Q.freeze(dq)
+        dq = dq.to(device)
+        dx = torch.randn(8, 144, 56, 56, device=device).to(torch.bfloat16)
+        el, _ = timed_replay(lambda: dq(dx), steps, args, None, device, warmup=3)
+        dw_us = el * 1e6 / steps
+        out["dw_kernel"] = quanto_hip.lib.last_kernel()
+        dw_w, dw_b = dq.weight, dq.bias
+        el, _ = timed_replay(lambda: torch.nn.functional.conv2d(dx, dw_w.dequantize(), dw_b, 1, 1, 1, 144), steps, args, None, device, warmup=3)
+        out["dw_us"], out["ref_rocm_dw_us"] = round(dw_us, 2), round(el * 1e6 / steps, 2)
+        out["dw_frac_hbm"] = round(2 * dx.numel() * 2 / dw_us / 1e3 / HBM_PEAK_GBS, 4)
+    # bound: the serial phases of a K-tile inside a workgroup - both roofline fractions are given; ref_rocm_* = dequantize + MIOpen convolution;
+    # kernel_us / traffic belong to the int8 launch
     return out
 
 
@@ -696,8 +715,9 @@ def run_cfg5(args, device, batches=(1, 32), prompt=512, new=512):
     Q.QuantizedModelForCausalLM.quantize(model, weights="qint4", exclude="lm_head")
     linked = Q.fuse_decode_projections(model)
     torch.cuda.synchronize()
-    out = {"name": "cfg5", "model": "Llama-3-8B random-init bf16, qint4 g128, lm_head excluded", "prompt": prompt, "new_tokens": new,
-           "method": "generate() per latency.py:24-105; graph_* = static-cache decode step replayed from a hipGraph", "fused_groups": linked,
+    # model: Llama-3-8B random-init bf16, qint4 g128, lm_head excluded; *_tok_s = generate() per latency.py:24-105, graph_* = static-cache decode step replayed
+    # from a hipGraph
+    out = {"name": "cfg5", "prompt": prompt, "new_tokens": new, "fused_groups": linked,
            "build_s": round(time.perf_counter() - t0, 1), "int4_bytes_per_token": 32 * sum((sum(N) if isinstance(N, tuple) else N) * (K // 2 + K // 128 * 4) for _, _, K, N in LAYER_LAUNCHES)}
     if getattr(model, "generation_config", None) is not None:
         model.generation_config.eos_token_id = None
@@ -949,7 +969,7 @@ def apply_profile(rec, prof, compacted):
     if not prof:
         return
     roof = rec if compacted else rec["roofline"]
-    for k in ("kernel_us", "kernel_us_min"):
+    for k in (("kernel_us",) if compacted else ("kernel_us", "kernel_us_min")):  # compact records carry the mean only (line budget)
         if k in prof:
             roof[k] = prof[k]
     if "traffic" in prof:
@@ -961,17 +981,16 @@ def compact(r):
     peak; alg_flops = 2 M sum(N) K), nothing repeated.  ``kernel_us`` (steady-state graph replay under rocprofv3) <= ``event_us`` (device
     events around the timed replay) <= ``us_per_step`` (host clock around barrier + synchronize: the time ``value`` uses)."""
     roof, cfg = r["roofline"], r["config"]
+    # r6 diet (the default line had reached 8,019 bytes against the driver's 8 KiB stdout tail): device-event time, the minimum of the traced durations,
+    # the rotation count and the CPU record's unit / path strings are in --verbose (stderr) only; "cpu_s" = seconds per call of the reference's CPU path
     out = {"name": cfg["name"], "M": cfg["M"], "K": cfg["K"], "N": cfg["N"], "value": r["value"], "unit": r["unit"],
-           "us_per_step": round(r["ms_per_step"] * 1e3, 3), "event_us": roof["event_us"], "kernel_us": None, "kernel_us_min": None,
+           "us_per_step": round(r["ms_per_step"] * 1e3, 3), "kernel_us": None,
            "kernel": roof["kernel"], "bound": roof["bound"], "frac": roof["frac"], "alg_bytes": int(roof["algorithmic_bytes"]),
-           "traffic": roof["traffic"], "rot": cfg["weight_buffers_rotated"]}
+           "traffic": roof["traffic"]}
     if "ref_rocm_us" in r:
         out["ref_rocm_us"] = r["ref_rocm_us"]
     if "cpu_baseline" in r:
-        c = r["cpu_baseline"]
-        out["cpu"] = {"v": c["value"], "unit": c["unit"], "s": c["seconds_per_call"], "path": c["path"]}
-        if "tinygemm" in c:
-            out["cpu"]["tinygemm_GBs"] = c["tinygemm"]["value"]
+        out["cpu_s"] = r["cpu_baseline"]["seconds_per_call"]
     return out
 
 

@@ -251,6 +251,14 @@ int quanto_hip_quantize_symmetric(const void* base, const void* scale, void* out
                                   int scale_mode, int in_dtype, int out_dtype, void* stream);
 
 /*
+ * QBytesTensor.dequantize() for a per-tensor scale (r6) - tensor/qbytes.py:23-36 `scale * data.to(dtype)`, the step the reference takes whenever a quantized
+ * activation meets an op without a quantized kernel (tensor/weights/awq/qbits.py:57-58 before every int4 product) - as one pass instead of a cast kernel and
+ * a multiply kernel: out[i] = T(float(q[i]) * float(scale[0])), bit-identical to the two-kernel sequence (every int8 / fp8 value is exact in T).
+ *   q: int8 / OCP fp8 [numel] (16-byte aligned); scale: T[1]; out: T[numel] (16-byte aligned); T in {F32, F16, BF16}.  QUANTO_HIP_EALIGN for other views.
+ */
+int quanto_hip_dequantize_symmetric(const void* q, const void* scale, void* out, int64_t numel, int q_dtype, int out_dtype, void* stream);
+
+/*
  * quanto::quantize_affine(Tensor base, int bits, int axis, int? group_size, Tensor scale, Tensor shift) -> Tensor, axis 0
  *   replaces library/quantize.py:66-78 (add/div, round, clamp, cast passes) at freeze / dynamic-quantization time.
  * base: dtype[N*K] (row-major [N, K]); scale: dtype[N*K/C]; shift: dtype[N*K/C] (float shift) or U8/I8 (zero-point), with

@@ -27,6 +27,7 @@ bool qbytes_mfma_large_supported(int64_t, int64_t, int64_t, int, int, int);
 int qbytes_mm_mfma_large(const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int, int, int, void*, size_t, hipStream_t);
 size_t qbytes_mfma_large_workspace(int64_t, int64_t, int64_t);
 int quantize_symmetric(const void*, const void*, void*, int64_t, int64_t, int, int, int, hipStream_t);
+int dequantize_symmetric(const void*, const void*, void*, int64_t, int, int, hipStream_t);
 int quantize_affine(const void*, const void*, const void*, void*, int64_t, int64_t, int, int, bool, hipStream_t);
 int quantize_affine_packed(const void*, const void*, const void*, void*, int64_t, int64_t, int, int, bool, hipStream_t);
 int pack_weights(const uint8_t*, uint8_t*, int64_t, int64_t, int, hipStream_t);
@@ -654,6 +655,15 @@ int quanto_hip_quantize_symmetric(const void* base, const void* scale, void* out
   if (numel == 0) return QUANTO_HIP_OK;
   if (!base || !scale || !out) return QUANTO_HIP_EINVAL;
   return quantize_symmetric(base, scale, out, numel, inner, scale_mode, in_dtype, out_dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+int quanto_hip_dequantize_symmetric(const void* q, const void* scale, void* out, int64_t numel, int q_dtype, int out_dtype, void* stream) {
+  if (numel < 0) return QUANTO_HIP_EINVAL;
+  if (!is_float_dtype(out_dtype)) return QUANTO_HIP_ENOTSUP;
+  if (q_dtype != QUANTO_HIP_I8 && q_dtype != QUANTO_HIP_F8_E4M3FN && q_dtype != QUANTO_HIP_F8_E5M2) return QUANTO_HIP_ENOTSUP;
+  if (numel == 0) return QUANTO_HIP_OK;
+  if (!q || !scale || !out) return QUANTO_HIP_EINVAL;
+  return dequantize_symmetric(q, scale, out, numel, q_dtype, out_dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
 int quanto_hip_quantize_affine(const void* base, const void* scale, const void* shift, uint8_t* out, int64_t N, int64_t K, int bits,

@@ -130,6 +130,42 @@ int launch_mode(const void* x, const void* s, void* out, int64_t numel, int64_t 
   return launch_status();
 }
 
+// ---- QBytesTensor.dequantize() for a per-tensor scale (activations): out = T(scale * T(q)) in ONE pass -------------------------------------------------
+// (tensor/qbytes.py:23-36: `scale * data.to(dtype)` = a cast kernel and a multiply kernel, 7 bytes of traffic per element in bf16 - here 3).  Every int8 / fp8
+// value is exact in bf16 / fp16 / fp32, so T(q) is exact and the product has one rounding: fp32 multiply, rounded to T - what aten's mul does through its
+// opmath type.  16 elements per thread and iteration: one 16-byte load, two 16-byte (16-bit T) or four (fp32) stores.
+template <int QDT, int ODT>
+__global__ void __launch_bounds__(256) dequantize_symmetric_kernel(const uint8_t* __restrict__ q, const typename Elem<ODT>::T* __restrict__ scale,
+                                                                   typename Elem<ODT>::T* __restrict__ out, int64_t numel) {
+  using E = Elem<ODT>;
+  using T = typename E::T;
+  const float s = E::to_f32(scale[0]);
+  const int64_t nvec = numel >> 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvec; v += stride) {
+    uint8_t b[16];
+    *reinterpret_cast<u32x4*>(b) = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q) + v);
+    T o[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) o[k] = E::from_f32(decode8<QDT>(b[k]) * s);
+#pragma unroll
+    for (int k = 0; k < (int)(16 * sizeof(T) / 16); ++k)
+      __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(o)[k], reinterpret_cast<u32x4*>(out + (v << 4)) + k);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = nvec << 4; i < numel; ++i) out[i] = E::from_f32(decode8<QDT>(q[i]) * s);
+}
+
+template <int QDT, int ODT>
+int launch_dequantize(const void* q, const void* scale, void* out, int64_t numel, hipStream_t stream) {
+  using T = typename Elem<ODT>::T;
+  const int64_t nvec = numel >> 4;
+  const int blocks = (int)(nvec < 256 ? 1 : (nvec + 255) / 256 > 4096 ? 4096 : (nvec + 255) / 256);
+  hipLaunchKernelGGL((dequantize_symmetric_kernel<QDT, ODT>), dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint8_t*>(q),
+                     reinterpret_cast<const T*>(scale), reinterpret_cast<T*>(out), numel);
+  return launch_status();
+}
+
 template <int IDT>
 int launch_out(const void* x, const void* s, void* out, int64_t numel, int64_t inner, int mode, int out_dtype, hipStream_t stream) {
   switch (out_dtype) {
@@ -235,6 +271,20 @@ int quantize_symmetric(const void* x, const void* s, void* out, int64_t numel, i
     case QUANTO_HIP_F16: return launch_out<QUANTO_HIP_F16>(x, s, out, numel, inner, mode, out_dtype, stream);
     case QUANTO_HIP_BF16: return launch_out<QUANTO_HIP_BF16>(x, s, out, numel, inner, mode, out_dtype, stream);
   }
+  return QUANTO_HIP_ENOTSUP;
+}
+
+int dequantize_symmetric(const void* q, const void* scale, void* out, int64_t numel, int q_dtype, int out_dtype, hipStream_t stream) {
+  if ((reinterpret_cast<uintptr_t>(q) % 16) || (reinterpret_cast<uintptr_t>(out) % 16)) return QUANTO_HIP_EALIGN;
+#define QH_DEQ(ODT)                                                                                                  \
+  if (q_dtype == QUANTO_HIP_I8) return launch_dequantize<QUANTO_HIP_I8, ODT>(q, scale, out, numel, stream);              \
+  if (q_dtype == QUANTO_HIP_F8_E4M3FN) return launch_dequantize<QUANTO_HIP_F8_E4M3FN, ODT>(q, scale, out, numel, stream); \
+  if (q_dtype == QUANTO_HIP_F8_E5M2) return launch_dequantize<QUANTO_HIP_F8_E5M2, ODT>(q, scale, out, numel, stream);     \
+  return QUANTO_HIP_ENOTSUP
+  if (out_dtype == QUANTO_HIP_BF16) { QH_DEQ(QUANTO_HIP_BF16); }
+  if (out_dtype == QUANTO_HIP_F16) { QH_DEQ(QUANTO_HIP_F16); }
+  if (out_dtype == QUANTO_HIP_F32) { QH_DEQ(QUANTO_HIP_F32); }
+#undef QH_DEQ
   return QUANTO_HIP_ENOTSUP;
 }
 

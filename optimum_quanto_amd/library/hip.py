@@ -152,6 +152,8 @@ class _Bindings:
         c.quanto_hip_pack.argtypes = [vp, vp, i64, i64, ci, vp]
         c.quanto_hip_qbytes_conv2d.restype = ci
         c.quanto_hip_qbytes_conv2d.argtypes = [vp, vp, vp, vp, vp] + [i64] * 9 + [ci] * 9 + [vp, ctypes.c_size_t, vp]
+        c.quanto_hip_dequantize_symmetric.restype = ci
+        c.quanto_hip_dequantize_symmetric.argtypes = [vp, vp, vp, i64, ci, ci, vp]
         c.quanto_hip_qbytes_conv2d_depthwise.restype = ci
         c.quanto_hip_qbytes_conv2d_depthwise.argtypes = [vp, vp, vp, vp, vp] + [i64] * 9 + [ci] * 9 + [vp]
         c.quanto_hip_conv2d_workspace_size.restype = i64
@@ -247,6 +249,22 @@ class _Bindings:
             st = self._c.quanto_hip_quantize_symmetric(_ptr(base), _ptr(scale), _ptr(out), base.numel(), inner, mode, _dt(base),
                                                        _dt(out), self._stream(base))
         self._check(st, "quantize_symmetric")
+        return out
+
+    def dequantize_symmetric(self, data: torch.Tensor, scale: torch.Tensor):
+        """``scale * data.to(scale.dtype)`` for a per-tensor scale in one pass (tensor/qbytes.py:23-36); None when the view is not one the kernel takes (the
+        caller keeps the two-kernel expression)."""
+        if not (data.is_cuda and scale.is_cuda and scale.numel() == 1 and data.is_contiguous() and data.dtype in (torch.int8, torch.float8_e4m3fn, torch.float8_e5m2)
+                and scale.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+            return None
+        out = torch.empty(data.shape, dtype=scale.dtype, device=data.device)
+        if data.numel() == 0:
+            return out
+        if (data.data_ptr() | out.data_ptr()) % 16:
+            return None
+        with torch.cuda.device(data.device):
+            st = self._c.quanto_hip_dequantize_symmetric(_ptr(data), _ptr(scale), _ptr(out), data.numel(), _dt(data), _dt(out), self._stream(data))
+        self._check(st, "dequantize_symmetric")
         return out
 
     def quantize_affine(self, base: torch.Tensor, bits: int, group_size, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:

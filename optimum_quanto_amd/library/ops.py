@@ -303,7 +303,11 @@ if _define("qbits_mm",
 # ------------------------------------------------------------------------------------------------
 def qbits_mm_a8_default(input, input_scale, packed, scale, shift, bias, bits: int, group_size: Optional[int], out_features: int, in_features: int):
     """What the reference computes (tensor/weights/awq/qbits.py:57-58, tensor/function.py:41-47): dequantize the activation, then the float product."""
-    x = input.to(scale.dtype) * input_scale.to(scale.dtype)
+    x = None
+    if input.is_cuda:  # r6: cast + multiply in one pass (bit-identical: csrc/quantize.hip dequantize_symmetric)
+        x = quanto_hip.lib.dequantize_symmetric(input, input_scale.to(scale.dtype))
+    if x is None:
+        x = input.to(scale.dtype) * input_scale.to(scale.dtype)
     return torch.ops.quanto.qbits_mm(x, packed, scale, shift, bias, bits, group_size, out_features, in_features)
 
 

@@ -98,6 +98,13 @@ class _DequantizeBytes(Function):
 
     @staticmethod
     def forward(ctx, t):
+        if t._data.is_cuda and t._scale.numel() == 1 and t._data.dim() >= max(t._scale.dim(), 1):
+            # r6: a per-tensor scale on the device (a quantized activation): cast + multiply in one pass, bit-identical (csrc/quantize.hip)
+            from ..library.hip import quanto_hip
+
+            out = quanto_hip.lib.dequantize_symmetric(t._data, t._scale)
+            if out is not None:
+                return out
         data = t._data.to(t._scale.dtype) if t.qtype.is_floating_point else t._data
         return t._scale * data
 

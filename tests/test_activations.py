@@ -312,3 +312,32 @@ def test_device_side_freeze_matches_cpu_freeze(wname, dt):
     dev = Q.quantize_weight(w.to(DEV), qtype=qt, axis=0, scale=scale.to(DEV), shift=shift.to(DEV), group_size=128)
     assert torch.equal(dev._data._data.cpu(), cpu._data._data)
     assert torch.equal(dev.dequantize().cpu(), cpu.dequantize())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("kind", ["int8", "e4m3fn", "e5m2"])
+@pytest.mark.parametrize("shape", [(4, 37), (1, 4096), (33, 1000), (5,), (0, 16)])
+def test_dequantize_symmetric_one_pass_is_bit_identical_gpu(dt, kind, shape):
+    """r6: QBytesTensor.dequantize() with a per-tensor scale on the device = one kernel (csrc/quantize.hip: dequantize_symmetric) - bit-identical to the
+    reference's `scale * data.to(dtype)` (tensor/qbytes.py:23-36) computed on the CPU, for every 8-bit format, every float dtype, ragged sizes and an empty tensor;
+    all 256 byte values appear."""
+    from optimum_quanto_amd.library.hip import quanto_hip
+
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dt]
+    n = int(np.prod(shape))
+    codes = (np.arange(n, dtype=np.int64) * 7 % 256).astype(np.uint8).reshape(shape)
+    if kind != "int8":  # NaN patterns compare unequal: keep the finite codes
+        nan = (codes & 0x7F) == 0x7F if kind == "e4m3fn" else (codes & 0x7F) > 0x7C
+        codes = np.where(nan, 0x38, codes).astype(np.uint8)
+    qdt = {"int8": torch.int8, "e4m3fn": torch.float8_e4m3fn, "e5m2": torch.float8_e5m2}[kind]
+    data = torch.from_numpy(codes).view(qdt)
+    scale = torch.tensor([0.0371], dtype=tdt)
+    want = scale * data.to(tdt)
+    got = quanto_hip.lib.dequantize_symmetric(data.cuda(), scale.cuda())
+    assert got is not None and got.dtype == tdt and got.shape == want.shape
+    assert torch.equal(got.cpu(), want)
+    # through the tensor class: a quantized activation on the device
+    if n:
+        qt = Q.ActivationQBytesTensor(Q.qint8 if kind == "int8" else getattr(Q, "qfloat8_" + kind), data.shape, data.stride(), data.cuda(), scale.cuda())
+        assert torch.equal(qt.dequantize().cpu(), want)

@@ -111,6 +111,11 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.quanto_hip_quantize_symmetric(None, None, None, 16, 5, 1, 2, 3, None) == -1   # numel not a multiple of inner
     assert lib.quanto_hip_quantize_symmetric(None, None, None, 16, 1, 0, 2, 7, None) == -2   # e4m3fnuz target: not supported
     assert lib.quanto_hip_quantize_symmetric(None, None, None, 0, 1, 0, 2, 3, None) == 0     # empty tensor
+    lib.quanto_hip_dequantize_symmetric.argtypes = [vp, vp, vp, i64, ci, ci, vp]
+    assert lib.quanto_hip_dequantize_symmetric(None, None, None, 16, 3, 2, None) == -1     # null pointers
+    assert lib.quanto_hip_dequantize_symmetric(None, None, None, 16, 2, 2, None) == -2     # bf16 "quantized" data
+    assert lib.quanto_hip_dequantize_symmetric(None, None, None, 16, 3, 3, None) == -2     # int8 output
+    assert lib.quanto_hip_dequantize_symmetric(None, None, None, 0, 5, 1, None) == 0       # empty tensor
     lib.quanto_hip_quantize_affine.argtypes = [vp, vp, vp, vp, i64, i64, ci, ci, ci, ci, vp]
     assert lib.quanto_hip_quantize_affine(None, None, None, None, 8, 128, 4, 128, 2, 2, None) == -1
     assert lib.quanto_hip_quantize_affine(None, None, None, None, 8, 100, 4, 128, 2, 2, None) == -1  # K % group_size
