@@ -143,6 +143,28 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // r6: per-feature scale / bias of the tile wait in LDS behind the ring.  The epilogue used to fetch them from global memory AFTER the
+  // K loop: a full round trip in front of the first output byte, on the critical path of every tile (all tiles end together).  One 2-byte
+  // load per thread, issued in front of the prologue's DMA (oldest entry of the in-order vector-memory queue: complete at the prologue's
+  // counted wait), parked behind the ring before the first barrier.  As asm: a load hipcc can see makes it wait vmcnt(0) at the store.
+  constexpr int RING_BYTES = (WD != 0 ? WD : STAGES) * STAGE_BYTES;
+  static_assert(NWAVES * 64 >= 2 * BN, "one table entry per thread");
+  uint32_t tab_val = 0;
+  const bool tab_scale = tid < BN ? a.scale != nullptr : a.bias != nullptr;
+  if (tid < 2 * BN && tab_scale) {
+    int n = n0 + (tid < BN ? tid : tid - BN);
+    n = n < N ? n : N - 1;
+    const T* src = reinterpret_cast<const T*>(tid < BN ? a.scale : a.bias) + n;
+    asm volatile("global_load_ushort %0, %1, off" : "=v"(tab_val) : "v"(src) : "memory");
+  }
+  auto park_table = [&]() {  // after the prologue's vmcnt wait, before its barrier
+    asm volatile("" : "+v"(tab_val));
+    if (tid < 2 * BN) {
+      const uint16_t one = DT == QUANTO_HIP_BF16 ? 0x3F80 : 0x3C00;
+      reinterpret_cast<uint16_t*>(smem + RING_BYTES)[tid] = tab_scale ? (uint16_t)tab_val : (tid < BN ? one : (uint16_t)0);
+    }
+  };
+
   uint32_t w0[NJ][4], w1[NJ][4];
   V8 xf[4];              // activation fragments, two steps ahead (ring of 4: STEPS is a multiple of 4, the ring stays aligned)
   auto as_v8 = [&](const uint32_t(&w)[4]) { return __builtin_bit_cast(V8, make_uint4(w[0], w[1], w[2], w[3])); };
@@ -194,7 +216,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int b = 0; b < WB; ++b) asm volatile("" : "+v"(rg[t][j][b]));
+    park_table();
     QH_LT_STAMP(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     QH_LT_STAMP(2);
@@ -284,7 +308,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
       for (int p = 0; p < NPIECES; ++p) issue_piece(1, 1, p);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile 1 too: its weight bytes are fetched during tile 0
+    park_table();
     QH_LT_STAMP(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     QH_LT_STAMP(2);
@@ -398,7 +424,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
 
   // ---- epilogue: scale (+bias) on the fp32 accumulator; each wave parks MI*16 tokens x 64 features per pass -------------
   T* yg = reinterpret_cast<T*>(a.y);
-  const bool has_bias = a.bias != nullptr, has_scale = a.scale != nullptr;
+  const bool has_bias = a.bias != nullptr;
   const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (N % 8 == 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -445,18 +471,21 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   constexpr int JP = NJ < 4 ? NJ : 4;  // feature fragments per pass: parked rows of JP*32 bytes
   constexpr int ROWB = JP * 32, LPR = ROWB / 16;  // lanes per parked row on the read side
   uint8_t* park = smem + wave * (MI * 16 * ROWB);
+  const T* tab = reinterpret_cast<const T*>(smem + RING_BYTES);  // [scale x BN | bias x BN], parked by the prologue
 #pragma unroll
   for (int p = 0; p < NJ / JP; ++p) {
 #pragma unroll
     for (int jj = 0; jj < JP; ++jj) {
       const int j = p * JP + jj;
-      const int nb = n0 + wn * (NJ * 16) + j * 16 + (lane >> 4) * 4;
+      const int nl = wn * (NJ * 16) + j * 16 + (lane >> 4) * 4;  // the lane's four consecutive features inside the tile
+      T sct[4], bvt[4];
+      *reinterpret_cast<uint2*>(sct) = *reinterpret_cast<const uint2*>(tab + nl);
+      *reinterpret_cast<uint2*>(bvt) = *reinterpret_cast<const uint2*>(tab + BN + nl);
       float sc[4], bv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = nb + r < N ? nb + r : N - 1;
-        sc[r] = has_scale ? E::to_f32(reinterpret_cast<const T*>(a.scale)[n]) : 1.f;
-        bv[r] = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
+        sc[r] = E::to_f32(sct[r]);   // 1.0 without a scale (the dense variant)
+        bv[r] = E::to_f32(bvt[r]);   // 0.0 without a bias (not added below)
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
@@ -506,7 +535,7 @@ template <int DT, int FMT, int BM, int BN, int WM, int WN, int WD = 0>
 static int launch_cfg(const Args& a, hipStream_t stream) {
   constexpr int lds0 = WD != 0 ? WD * (BM * BK * 2) : STAGES * (BM * BK * 2 + BN * BK);
   const int pad = env_int("QUANTO_HIP_LARGE_LDS_PAD", 0);  // experiments
-  const int lds = lds0 + pad;
+  const int lds = lds0 + 2 * BN * 2 + pad;  // ring + the tile's scale / bias table
   static_assert(lds0 >= BM * BN * 2, "the epilogue parks the output tile in the stage memory");
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN, tiles = tiles_m * tiles_n;
   Args b = a;
