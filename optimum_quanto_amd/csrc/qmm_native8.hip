@@ -93,12 +93,51 @@ __device__ __forceinline__ void tile_of(int bid, int tiles_m, int tiles_n, int g
   tm = first + (in - tn * rows);
 }
 
+// ---- r6: per-feature scale / bias of the tile, parked in LDS behind the operand ring by the prologue ------------------------------------
+// The epilogue used to fetch them from global memory after the K loop: a round trip in front of the first output byte of every tile, and all
+// tiles of these grids end together.  One load per thread (threads = 2 * BN), issued in FRONT of the prologue's DMA - the oldest entry of the
+// in-order vector-memory queue, so the prologue's counted wait covers it - and stored behind the ring before the prologue's barrier.  As asm:
+// a load hipcc can see makes it drain the DMA queue (vmcnt(0)) at the store.  (Same change as qmm_mfma_large.hip: cfg2 -1.4 us, cfg4 -1.1 us.)
+template <int ODT, int BN>
+struct FeatureTable {
+  using T = typename Elem<ODT>::T;
+  static constexpr int BYTES = 2 * BN * (int)sizeof(T);  // [scale x BN | bias x BN]
+  uint32_t v;
+  bool have;
+  __device__ __forceinline__ void fetch(const Args& a, int n0, int tid) {
+    v = 0;
+    have = tid < BN ? a.scale != nullptr : a.bias != nullptr;
+    if (tid < 2 * BN && have) {
+      int n = n0 + (tid < BN ? tid : tid - BN);
+      n = n < a.N ? n : a.N - 1;
+      const T* src = reinterpret_cast<const T*>(tid < BN ? a.scale : a.bias) + n;
+      if constexpr (sizeof(T) == 2)
+        asm volatile("global_load_ushort %0, %1, off" : "=v"(v) : "v"(src) : "memory");
+      else
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(src) : "memory");
+    }
+  }
+  // after the prologue's vmcnt wait, before its barrier
+  __device__ __forceinline__ void park(uint8_t* tab, int tid) {
+    asm volatile("" : "+v"(v));
+    if (tid < 2 * BN) {
+      if constexpr (sizeof(T) == 2) {
+        const uint16_t one = ODT == QUANTO_HIP_BF16 ? 0x3F80 : 0x3C00;
+        reinterpret_cast<uint16_t*>(tab)[tid] = have ? (uint16_t)v : (tid < BN ? one : (uint16_t)0);
+      } else {
+        reinterpret_cast<uint32_t*>(tab)[tid] = have ? v : (tid < BN ? 0x3F800000u : 0u);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+};
+
 // ---- epilogue: (int32 | fp32) accumulator * scale[n] (+ bias), parked per wave in LDS, stored as full 128-byte lines ----
 // (shared by the 64-byte-row and the 128-byte-row kernels; every wave must be done with the operand stages: the barrier below)
 // NI / i0: the token fragments acc[.][0 .. NI-1] are fragments i0 .. i0 + NI - 1 of the wave's 128 rows (the K split hands every workgroup 8 / S of them)
 template <int ODT, int KIND, int NJ, int BM, int BN, int NI = 8>
-__device__ __forceinline__ void epilogue(const Args& a, typename Acc<KIND>::V (&acc)[NJ][NI], uint8_t* smem, int m0, int n0, int wm, int wn, int wave,
-                                         int lane, int i0 = 0) {
+__device__ __forceinline__ void epilogue(const Args& a, typename Acc<KIND>::V (&acc)[NJ][NI], uint8_t* smem, const uint8_t* tabp, int m0, int n0, int wm,
+                                         int wn, int wave, int lane, int i0 = 0) {
   using E = Elem<ODT>;
   using T = typename E::T;
   const int M = a.M, N = a.N;
@@ -117,13 +156,13 @@ __device__ __forceinline__ void epilogue(const Args& a, typename Acc<KIND>::V (&
 #pragma unroll
     for (int jj = 0; jj < JP; ++jj) {
       const int j = p * JP + jj;
-      const int nb = n0 + wn * (NJ * 16) + j * 16 + (lane >> 4) * 4;
+      const int nl = wn * (NJ * 16) + j * 16 + (lane >> 4) * 4;  // the lane's four consecutive features inside the tile
+      const T* tab = reinterpret_cast<const T*>(tabp);
       float sc[4], bv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = nb + r < N ? nb + r : N - 1;
-        sc[r] = a.scale ? E::to_f32(reinterpret_cast<const T*>(a.scale)[n]) : 1.f;
-        bv[r] = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
+        sc[r] = E::to_f32(tab[nl + r]);       // 1.0 without a scale
+        bv[r] = E::to_f32(tab[BN + nl + r]);  // 0.0 without a bias (not added below)
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -209,7 +248,8 @@ __device__ __forceinline__ void splitk_store(const Args& a, typename Acc<KIND>::
 }
 
 template <int ODT, int KIND, int NJ, int BM, int BN, int NWAVES, int SS>
-__device__ __forceinline__ void splitk_reduce(const Args& a, uint8_t* smem, int tile_lin, int sp, int m0, int n0, int wm, int wn, int wave, int lane, int tid) {
+__device__ __forceinline__ void splitk_reduce(const Args& a, uint8_t* smem, const uint8_t* tabp, int tile_lin, int sp, int m0, int n0, int wm, int wn, int wave,
+                                              int lane, int tid) {
   using AV = typename Acc<KIND>::V;
   constexpr int NI = 8 / SS, NT = NWAVES * 64, NF = NJ * 8, CW = 2 + SS;
   const unsigned long long POLL_LIMIT = (unsigned long long)a.poll_ticks;  // s_memrealtime ticks (100 MHz); 20000 = 200 us
@@ -273,7 +313,7 @@ __device__ __forceinline__ void splitk_reduce(const Args& a, uint8_t* smem, int 
     // loop below; hipcc otherwise computes them once ahead of all of them and carries ~150 registers through the reduction (measured: 130 - 470 spills)
     int zero;
     asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-    epilogue<ODT, KIND, NJ, BM, BN, NI>(a, L[0], smem, m0, n0 + zero, wm, wn, wave, lane, s * NI);
+    epilogue<ODT, KIND, NJ, BM, BN, NI>(a, L[0], smem, tabp, m0, n0 + zero, wm, wn, wave, lane, s * NI);
   };
   // completion: S slices + the last arriver's sweep; whoever counts the last one leaves the state words as found
   auto complete = [&]() {
@@ -334,6 +374,10 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
   int tm, tn;
   tile_of(bid, tiles_m, tiles_n, a.gm, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
+  constexpr int RING_BYTES = STAGES * STAGE_BYTES;
+  FeatureTable<ODT, BN> ftab;  // scale / bias of the tile: fetched ahead of the DMA, parked behind the ring before the prologue's barrier
+  static_assert(NWAVES * 64 == 2 * BN, "one table entry per thread");
+  ftab.fetch(a, n0, tid);
 
   // ---- DMA: 2 + 2 pieces of 1 KiB per wave and K-tile; piece j of an operand covers tile rows (j*8+wave)*16 .. +15 -------
   uint32_t asrc[2], wsrc[2];
@@ -456,6 +500,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ftab.park(smem + RING_BYTES, tid);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -510,6 +555,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    ftab.park(smem + RING_BYTES, tid);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -572,7 +618,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_kernel(co
 
   }
 
-  epilogue<ODT, KIND, NJ, BM, BN>(a, acc, smem, m0, n0, wm, wn, wave, lane);
+  epilogue<ODT, KIND, NJ, BM, BN>(a, acc, smem, smem + RING_BYTES, m0, n0, wm, wn, wave, lane);
 }
 
 // =============================================================================================================================
@@ -633,6 +679,10 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
   int tm, tn;
   tile_of(tile_lin, tiles_m, tiles_n, a.gm, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
+  constexpr int RING_BYTES = 4 * OP_BYTES;
+  FeatureTable<ODT, BN> ftab;  // scale / bias of the tile: fetched ahead of the DMA, parked behind the ring before the prologue's barrier
+  static_assert(NWAVES * 64 == 2 * BN, "one table entry per thread");
+  ftab.fetch(a, n0, tid);
 
   // ---- DMA: 4 + 4 pieces of 1 KiB per wave and pair; piece j of an operand covers tile rows (j * NWAVES + wave) * 8 .. + 7 ----
   uint32_t asrc[PPW], wsrc[PPW];
@@ -682,6 +732,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  ftab.park(smem + RING_BYTES, tid);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
@@ -819,14 +870,14 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
   if (S > 1) {
     splitk_store<KIND, NJ, NWAVES>(a, acc, S, tile_lin, sp, tid);
     if (S == 2)
-      splitk_reduce<ODT, KIND, NJ, BM, BN, NWAVES, 2>(a, smem, tile_lin, sp, m0, n0, wm, wn, wave, lane, tid);
+      splitk_reduce<ODT, KIND, NJ, BM, BN, NWAVES, 2>(a, smem, smem + RING_BYTES, tile_lin, sp, m0, n0, wm, wn, wave, lane, tid);
     else if (S == 4)
-      splitk_reduce<ODT, KIND, NJ, BM, BN, NWAVES, 4>(a, smem, tile_lin, sp, m0, n0, wm, wn, wave, lane, tid);
+      splitk_reduce<ODT, KIND, NJ, BM, BN, NWAVES, 4>(a, smem, smem + RING_BYTES, tile_lin, sp, m0, n0, wm, wn, wave, lane, tid);
     else
-      splitk_reduce<ODT, KIND, NJ, BM, BN, NWAVES, 8>(a, smem, tile_lin, sp, m0, n0, wm, wn, wave, lane, tid);
+      splitk_reduce<ODT, KIND, NJ, BM, BN, NWAVES, 8>(a, smem, smem + RING_BYTES, tile_lin, sp, m0, n0, wm, wn, wave, lane, tid);
     return;
   }
-  epilogue<ODT, KIND, NJ, BM, BN>(a, acc, smem, m0, n0, wm, wn, wave, lane);
+  epilogue<ODT, KIND, NJ, BM, BN>(a, acc, smem, smem + RING_BYTES, m0, n0, wm, wn, wave, lane);
 #ifdef QH_N8_STAMPS
   QH_N8_STAMP(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -837,7 +888,7 @@ __global__ void __launch_bounds__(SMALL ? 256 : 512, 1) qbytes_native8_r128_kern
 template <int ODT, int KIND, bool SMALL>
 static int launch_r128(const Args& a, hipStream_t stream) {
   constexpr int T = SMALL ? 128 : 256;
-  constexpr int need = 2 * 2 * T * 128;  // two buffers of 128-byte rows: 128 KiB (64 KiB for the 128-tile); the epilogue parks in it
+  constexpr int need = 2 * 2 * T * 128 + FeatureTable<ODT, T>::BYTES;  // two buffers of 128-byte rows: 128 KiB (64 KiB for the 128-tile; the epilogue parks in it) + scale / bias table
   const int tiles = ((a.N + T - 1) / T) * ((a.M + T - 1) / T);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_r128_kernel<ODT, KIND, SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, need);
   hipLaunchKernelGGL((qbytes_native8_r128_kernel<ODT, KIND, SMALL>), dim3(tiles * a.S), dim3(SMALL ? 256 : 512), need, stream, a);
@@ -852,7 +903,7 @@ static int raster_group() {
 template <int ODT, int KIND, bool PAIRED, bool SMALL>
 static int launch_cfg(const Args& a, hipStream_t stream) {
   constexpr int T = SMALL ? 128 : 256;
-  constexpr int need = STAGES * 2 * T * BK;  // 128 KiB (64 KiB for the 128-tile: two workgroups per CU); the epilogue parks in it
+  constexpr int need = STAGES * 2 * T * BK + FeatureTable<ODT, T>::BYTES;  // 128 KiB (64 KiB for the 128-tile: two workgroups per CU; the epilogue parks in it) + scale / bias table
   const int tiles = ((a.N + T - 1) / T) * ((a.M + T - 1) / T);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qbytes_native8_kernel<ODT, KIND, PAIRED, SMALL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, need);
