@@ -470,59 +470,68 @@ __global__ void __launch_bounds__(WM * WN * 64, 1) qbytes_mfma_large_kernel(cons
   }
   constexpr int JP = NJ < 4 ? NJ : 4;  // feature fragments per pass: parked rows of JP*32 bytes
   constexpr int ROWB = JP * 32, LPR = ROWB / 16;  // lanes per parked row on the read side
+  // r6: the wave's rows leave in RH halves - the stores of the first 64 rows drain while the second 64 are scaled, converted and parked (one
+  // pass over all 128 rows ran the phases of all eight waves in step: first every wave on the VALU / LDS, then every wave on the store path)
+  constexpr int RH = MI >= 8 ? 2 : 1, MIH = MI / RH;
   uint8_t* park = smem + wave * (MI * 16 * ROWB);
   const T* tab = reinterpret_cast<const T*>(smem + RING_BYTES);  // [scale x BN | bias x BN], parked by the prologue
 #pragma unroll
   for (int p = 0; p < NJ / JP; ++p) {
+    float sc[JP][4], bv[JP][4];
 #pragma unroll
     for (int jj = 0; jj < JP; ++jj) {
-      const int j = p * JP + jj;
-      const int nl = wn * (NJ * 16) + j * 16 + (lane >> 4) * 4;  // the lane's four consecutive features inside the tile
+      const int nl = wn * (NJ * 16) + (p * JP + jj) * 16 + (lane >> 4) * 4;  // the lane's four consecutive features inside the tile
       T sct[4], bvt[4];
       *reinterpret_cast<uint2*>(sct) = *reinterpret_cast<const uint2*>(tab + nl);
       *reinterpret_cast<uint2*>(bvt) = *reinterpret_cast<const uint2*>(tab + BN + nl);
-      float sc[4], bv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        sc[r] = E::to_f32(sct[r]);   // 1.0 without a scale (the dense variant)
-        bv[r] = E::to_f32(bvt[r]);   // 0.0 without a bias (not added below)
+        sc[jj][r] = E::to_f32(sct[r]);   // 1.0 without a scale (the dense variant)
+        bv[jj][r] = E::to_f32(bvt[r]);   // 0.0 without a bias (not added below)
       }
+    }
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        T out[4];
+    for (int h = 0; h < RH; ++h) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[j][i][r] * sc[r];
-          asm volatile("" : "+v"(v));  // product rounded to fp32 first, with and without bias (no single-rounding v_fma_mixlo_f16)
-          if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[r];
-          out[r] = E::from_f32(v);
+      for (int jj = 0; jj < JP; ++jj) {
+        const int j = p * JP + jj;
+#pragma unroll
+        for (int i = h * MIH; i < (h + 1) * MIH; ++i) {
+          T out[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[j][i][r] * sc[jj][r];
+            asm volatile("" : "+v"(v));  // product rounded to fp32 first, with and without bias (no single-rounding v_fma_mixlo_f16)
+            if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[jj][r];
+            out[r] = E::from_f32(v);
+          }
+          const int row = i * 16 + (lane & 15);
+          const int chunk = (jj * 4 + (lane >> 4)) ^ ((row & (LPR - 1)) << 1);
+          *reinterpret_cast<uint2*>(park + row * ROWB + chunk * 8) = *reinterpret_cast<const uint2*>(out);
         }
-        const int row = i * 16 + (lane & 15);
-        const int chunk = (jj * 4 + (lane >> 4)) ^ ((row & (LPR - 1)) << 1);
-        *reinterpret_cast<uint2*>(park + row * ROWB + chunk * 8) = *reinterpret_cast<const uint2*>(out);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier needed
+#pragma unroll
+      for (int t = h * (MIH * 16 * LPR / 64); t < (h + 1) * (MIH * 16 * LPR / 64); ++t) {
+        const int row = t * (64 / LPR) + lane / LPR;
+        const int c16 = lane % LPR;
+        const uint4 v = *reinterpret_cast<const uint4*>(park + row * ROWB + (((c16 * 2) ^ ((row & (LPR - 1)) << 1)) * 8));
+        const int m = m0 + wm * (MI * 16) + row;
+        const int n = n0 + wn * (NJ * 16) + p * (JP * 16) + c16 * 8;
+        if (full) {
+          // non-temporal: the 2*M*N output bytes are not re-read by this kernel; streaming them past the L2 shortens the
+          // end-of-kernel write-back (measured: 19.4 -> 13.3 us at K = 128, -3 us at K = 4096)
+          typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+          __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + (size_t)m * N + n));
+        } else if (m < M) {
+          const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (n + r < N) yg[(size_t)m * N + n + r] = e[r];
+        }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier needed
-#pragma unroll
-    for (int t = 0; t < MI * 16 * LPR / 64; ++t) {
-      const int row = t * (64 / LPR) + lane / LPR;
-      const int c16 = lane % LPR;
-      const uint4 v = *reinterpret_cast<const uint4*>(park + row * ROWB + (((c16 * 2) ^ ((row & (LPR - 1)) << 1)) * 8));
-      const int m = m0 + wm * (MI * 16) + row;
-      const int n = n0 + wn * (NJ * 16) + p * (JP * 16) + c16 * 8;
-      if (full) {
-        // non-temporal: the 2*M*N output bytes are not re-read by this kernel; streaming them past the L2 shortens the
-        // end-of-kernel write-back (measured: 19.4 -> 13.3 us at K = 128, -3 us at K = 4096)
-        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + (size_t)m * N + n));
-      } else if (m < M) {
-        const T* e = reinterpret_cast<const T*>(&v);
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-          if (n + r < N) yg[(size_t)m * N + n + r] = e[r];
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next pass parks into the rows this one has just read
   }
   QH_LT_STAMP(5);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
