@@ -151,62 +151,72 @@ __device__ __forceinline__ void epilogue(const Args& a, typename Acc<KIND>::V (&
   constexpr int JP = FP / 16, PASSES = NJ / JP;  // feature fragments per pass
   constexpr int ROWB = FP * (int)sizeof(T), LPR = ROWB / 16;  // bytes per parked row, lanes per row on the read side
   uint8_t* park = smem + wave * (128 * ROWB);     // <= 16 KiB per wave
+  const T* tab = reinterpret_cast<const T*>(tabp);
+  // r6: the wave's rows leave in RH halves - the stores of the first half drain while the second half is scaled, converted and parked (as
+  // qmm_mfma_large.hip: one pass over all rows ran the phases of all waves in step, first all on the VALU / LDS, then all on the store path)
+  constexpr int RH = NI >= 8 ? 2 : 1, NIH = NI / RH;
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
+    float sc[JP][4], bv[JP][4];
 #pragma unroll
     for (int jj = 0; jj < JP; ++jj) {
-      const int j = p * JP + jj;
-      const int nl = wn * (NJ * 16) + j * 16 + (lane >> 4) * 4;  // the lane's four consecutive features inside the tile
-      const T* tab = reinterpret_cast<const T*>(tabp);
-      float sc[4], bv[4];
+      const int nl = wn * (NJ * 16) + (p * JP + jj) * 16 + (lane >> 4) * 4;  // the lane's four consecutive features inside the tile
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        sc[r] = E::to_f32(tab[nl + r]);       // 1.0 without a scale
-        bv[r] = E::to_f32(tab[BN + nl + r]);  // 0.0 without a bias (not added below)
+        sc[jj][r] = E::to_f32(tab[nl + r]);       // 1.0 without a scale
+        bv[jj][r] = E::to_f32(tab[BN + nl + r]);  // 0.0 without a bias (not added below)
       }
+    }
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        T out[4];
+    for (int h = 0; h < RH; ++h) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = (float)acc[j][i][r] * sc[r];  // library/qbytes_mm.py:47-49: fp32(int32) * fp32(scale), rounded to fp32 ...
-          asm volatile("" : "+v"(v));             // ... and only then to the output dtype (no single-rounding v_fma_mixlo_f16)
-          if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[r];
-          out[r] = E::from_f32(v);
+      for (int jj = 0; jj < JP; ++jj) {
+        const int j = p * JP + jj;
+#pragma unroll
+        for (int i = h * NIH; i < (h + 1) * NIH; ++i) {
+          T out[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = (float)acc[j][i][r] * sc[jj][r];  // library/qbytes_mm.py:47-49: fp32(int32) * fp32(scale), rounded to fp32 ...
+            asm volatile("" : "+v"(v));                 // ... and only then to the output dtype (no single-rounding v_fma_mixlo_f16)
+            if (has_bias) v = E::to_f32(E::from_f32(v)) + bv[jj][r];
+            out[r] = E::from_f32(v);
+          }
+          const int row = i * 16 + (lane & 15);
+          if constexpr (sizeof(T) == 2) {
+            const int chunk = (jj * 4 + (lane >> 4)) ^ ((row & (LPR - 1)) << 1);  // 8-byte chunks
+            *reinterpret_cast<uint2*>(park + row * ROWB + chunk * 8) = *reinterpret_cast<const uint2*>(out);
+          } else {
+            const int chunk = (jj * 4 + (lane >> 4)) ^ (row & (LPR - 1));  // 16-byte chunks
+            *reinterpret_cast<uint4*>(park + row * ROWB + chunk * 16) = *reinterpret_cast<const uint4*>(out);
+          }
         }
-        const int row = i * 16 + (lane & 15);
-        if constexpr (sizeof(T) == 2) {
-          const int chunk = (jj * 4 + (lane >> 4)) ^ ((row & (LPR - 1)) << 1);  // 8-byte chunks
-          *reinterpret_cast<uint2*>(park + row * ROWB + chunk * 8) = *reinterpret_cast<const uint2*>(out);
-        } else {
-          const int chunk = (jj * 4 + (lane >> 4)) ^ (row & (LPR - 1));  // 16-byte chunks
-          *reinterpret_cast<uint4*>(park + row * ROWB + chunk * 16) = *reinterpret_cast<const uint4*>(out);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      constexpr int TH = 2 * LPR * NIH / 8;  // read / store iterations per half: 64 / LPR rows each
+#pragma unroll
+      for (int t = h * TH; t < (h + 1) * TH; ++t) {
+        const int row = t * (64 / LPR) + lane / LPR;
+        const int c16 = lane % LPR;
+        uint4 v;
+        if constexpr (sizeof(T) == 2)
+          v = *reinterpret_cast<const uint4*>(park + row * ROWB + (((c16 * 2) ^ ((row & (LPR - 1)) << 1)) * 8));
+        else
+          v = *reinterpret_cast<const uint4*>(park + row * ROWB + ((c16 ^ (row & (LPR - 1))) * 16));
+        const int m = m0 + wm * 128 + i0 * 16 + row;
+        const int n = n0 + wn * (NJ * 16) + p * FP + c16 * (16 / (int)sizeof(T));
+        if (full) {
+          typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // non-temporal: see qmm_mfma_large.hip
+          __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + (size_t)m * N + n));
+        } else if (m < M) {
+          const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+          for (int r = 0; r < 16 / (int)sizeof(T); ++r)
+            if (n + r < N) yg[(size_t)m * N + n + r] = e[r];
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int t = 0; t < 2 * LPR * NI / 8; ++t) {
-      const int row = t * (64 / LPR) + lane / LPR;
-      const int c16 = lane % LPR;
-      uint4 v;
-      if constexpr (sizeof(T) == 2)
-        v = *reinterpret_cast<const uint4*>(park + row * ROWB + (((c16 * 2) ^ ((row & (LPR - 1)) << 1)) * 8));
-      else
-        v = *reinterpret_cast<const uint4*>(park + row * ROWB + ((c16 ^ (row & (LPR - 1))) * 16));
-      const int m = m0 + wm * 128 + i0 * 16 + row;
-      const int n = n0 + wn * (NJ * 16) + p * FP + c16 * (16 / (int)sizeof(T));
-      if (full) {
-        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // non-temporal: see qmm_mfma_large.hip
-        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + (size_t)m * N + n));
-      } else if (m < M) {
-        const T* e = reinterpret_cast<const T*>(&v);
-#pragma unroll
-        for (int r = 0; r < 16 / (int)sizeof(T); ++r)
-          if (n + r < N) yg[(size_t)m * N + n + r] = e[r];
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next pass parks into the rows this one has just read
   }
 }
 

@@ -1,5 +1,5 @@
 set -x
-O=gpurun_out/s3e; mkdir -p $O
+O=gpurun_out/s3g; mkdir -p $O
 timeout 1200 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "native8 or w8a8 or fp8a8 or a8 or activations or prefill or dense or dequant or quantized_act" > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 cp optimum_quanto_amd/lib/libquanto_hip.so /tmp/cur.so
 for rep in 1 2; do
