@@ -391,17 +391,41 @@ def qbits_mm_a8_chain(a_i8, a_scale, packed, bits, scale, shift, group_size, out
     ``dtype`` (+ bias: rounded product plus bias, rounded again - tensor/function.py:45-46).  Bit-exact gate of the int8 path."""
     N, K = out_features, in_features
     G = K // group_size
-    q = unpacked_rows(packed, bits, N * G).reshape(N, G, group_size).astype(np.float64)     # grouped rows n * G + g
+    qT = np.ascontiguousarray(unpacked_rows(packed, bits, N * G).reshape(N, G, group_size).astype(np.float64).transpose(1, 2, 0))  # [g][k][n]
     a = np.asarray(a_i8).astype(np.float64).reshape(-1, G, group_size)
     s = np.asarray(scale, np.float32).reshape(N, G)
     sh = np.asarray(shift).reshape(N, G)
     z = sh.astype(np.float32) if np.issubdtype(sh.dtype, np.floating) else (s * sh.astype(np.float32)).astype(np.float32)
+    s64, nz64 = s.astype(np.float64), -z.astype(np.float64)
     acc = np.zeros((a.shape[0], N), np.float32)
-    for g in range(G):
-        P = np.matmul(a[:, g, :], q[:, g, :].T).astype(np.float32)          # exact integers below 2^24
-        A = a[:, g, :].sum(axis=1).astype(np.float32)
-        acc = _fma32(np.broadcast_to(s[:, g][None, :], acc.shape), P, acc)
-        acc = _fma32(np.broadcast_to(-z[:, g][None, :], acc.shape), np.broadcast_to(A[:, None], acc.shape), acc)
+
+    def rows(r0, r1):
+        # the same two fused operations per group as _fma32 states them (product and sum exact in float64, ONE rounding to fp32 each), on a
+        # block of rows with the fp32-valued accumulator carried in float64 between roundings: no broadcast temporaries, cache-sized blocks
+        acc64 = np.zeros((r1 - r0, N), np.float64)
+        t = np.empty_like(acc64)
+        for g in range(G):
+            ag = a[r0:r1, g, :]
+            np.matmul(ag, qT[g], out=t)                 # P_g: exact integers below 2^24
+            t *= s64[:, g][None, :]
+            t += acc64
+            acc64[...] = t.astype(np.float32)           # acc = fma(s, P, acc)
+            A = ag.sum(axis=1)                          # exact integer
+            np.multiply(A[:, None], nz64[:, g][None, :], out=t)
+            t += acc64
+            acc64[...] = t.astype(np.float32)           # acc = fma(-z, A, acc)
+        acc[r0:r1] = acc64
+
+    step = 256
+    blocks = [(r0, min(r0 + step, a.shape[0])) for r0 in range(0, a.shape[0], step)]
+    if len(blocks) > 1:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=min(len(blocks), max(1, (os.cpu_count() or 1)))) as pool:
+            list(pool.map(lambda b: rows(*b), blocks))
+    else:
+        rows(*blocks[0])
     sx = np.float32(np.asarray(a_scale, np.float32).reshape(-1)[0])
     y = round_to((acc * sx).astype(np.float32), dtype)
     if bias is not None:

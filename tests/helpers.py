@@ -25,31 +25,60 @@ def fp8_tensor(codes: np.ndarray, kind: str, device="cpu") -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(codes, dtype=np.uint8)).view(FP8_TORCH[kind]).to(device)
 
 
-def make_qbits_problem(M, N, K, dt, bits=4, group_size=128, zeropoint=False, seed=0, wscale=0.02):
-    """Seeded activations + a weight quantized by the (reference-pinned) oracle, generic PackedTensor layout."""
-    rng = np.random.default_rng(seed)
-    w = O.round_to((rng.standard_normal((N, K)) * wscale).astype(np.float32), dt)
-    x = O.round_to(rng.standard_normal((M, K)).astype(np.float32), dt)
-    scale, shift = O.max_scale_shift(w, bits, 0, group_size, dt)
-    if zeropoint:
-        shift = np.clip(np.rint(O.round_to(shift / scale, dt)), 0, 2**bits - 1).astype(np.uint8)
-    q = O.quantize_affine(w, bits, 0, group_size, scale, shift, dt)
-    packed = O.pack_weights(q, bits)
-    return dict(x=x, packed=packed, scale=scale, shift=shift, bits=bits, group_size=group_size, N=N, K=K, dt=dt)
+_WEIGHT_CACHE = {}  # weight_seed given: the quantized weight of a (shape, format, seed) is built once per session and shared by every M
 
 
-def make_qbytes_problem(M, N, K, dt, kind=None, seed=0, wscale=0.02):
-    """int8 (kind None) or fp8 weight with per-row absmax scale, built by the oracle."""
+def _activations(M, K, dt, rng):
+    return O.round_to(rng.standard_normal((M, K)).astype(np.float32), dt)
+
+
+def make_qbits_problem(M, N, K, dt, bits=4, group_size=128, zeropoint=False, seed=0, wscale=0.02, weight_seed=None):
+    """Seeded activations + a weight quantized by the (reference-pinned) oracle, generic PackedTensor layout.
+    ``weight_seed``: draw the weight from its own stream and cache the quantized result (suites that sweep M over one weight)."""
+
+    def weight(rng):
+        w = O.round_to((rng.standard_normal((N, K)) * wscale).astype(np.float32), dt)
+        scale, shift = O.max_scale_shift(w, bits, 0, group_size, dt)
+        if zeropoint:
+            shift = np.clip(np.rint(O.round_to(shift / scale, dt)), 0, 2**bits - 1).astype(np.uint8)
+        q = O.quantize_affine(w, bits, 0, group_size, scale, shift, dt)
+        return dict(packed=O.pack_weights(q, bits), scale=scale, shift=shift)
+
     rng = np.random.default_rng(seed)
-    w = O.round_to((rng.standard_normal((N, K)) * wscale).astype(np.float32), dt)
-    x = O.round_to(rng.standard_normal((M, K)).astype(np.float32), dt)
-    if kind is None:
-        scale = O.absmax_scale(w, 127.0, 0, dt)
-        data = O.quantize_symmetric_int8(w, scale, dt)
+    if weight_seed is None:
+        wq = weight(rng)  # historical stream order: weight first, then activations
     else:
-        scale = O.absmax_scale(w, O.FP8_MAX[kind], 0, dt)
-        data = O.quantize_symmetric_fp8(w, scale, kind, dt)
-    return dict(x=x, data=data, scale=scale, kind=kind, N=N, K=K, dt=dt)
+        key = ("qbits", N, K, dt, bits, group_size, zeropoint, weight_seed, wscale)
+        if key not in _WEIGHT_CACHE:
+            _WEIGHT_CACHE[key] = weight(np.random.default_rng(weight_seed))
+        wq = _WEIGHT_CACHE[key]
+    x = _activations(M, K, dt, rng)
+    return dict(x=x, packed=wq["packed"], scale=wq["scale"], shift=wq["shift"], bits=bits, group_size=group_size, N=N, K=K, dt=dt)
+
+
+def make_qbytes_problem(M, N, K, dt, kind=None, seed=0, wscale=0.02, weight_seed=None):
+    """int8 (kind None) or fp8 weight with per-row absmax scale, built by the oracle (``weight_seed``: as make_qbits_problem)."""
+
+    def weight(rng):
+        w = O.round_to((rng.standard_normal((N, K)) * wscale).astype(np.float32), dt)
+        if kind is None:
+            scale = O.absmax_scale(w, 127.0, 0, dt)
+            data = O.quantize_symmetric_int8(w, scale, dt)
+        else:
+            scale = O.absmax_scale(w, O.FP8_MAX[kind], 0, dt)
+            data = O.quantize_symmetric_fp8(w, scale, kind, dt)
+        return dict(data=data, scale=scale)
+
+    rng = np.random.default_rng(seed)
+    if weight_seed is None:
+        wq = weight(rng)
+    else:
+        key = ("qbytes", N, K, dt, kind, weight_seed, wscale)
+        if key not in _WEIGHT_CACHE:
+            _WEIGHT_CACHE[key] = weight(np.random.default_rng(weight_seed))
+        wq = _WEIGHT_CACHE[key]
+    x = _activations(M, K, dt, rng)
+    return dict(x=x, data=wq["data"], scale=wq["scale"], kind=kind, N=N, K=K, dt=dt)
 
 
 def assert_close_to_exact(y: np.ndarray, y_exact: np.ndarray, dt: str, what=""):

@@ -14,7 +14,7 @@ from helpers import assert_close_to_exact, make_qbits_problem, to_numpy, to_torc
 
 
 def _problems(M, K, Ns, dt, dev, seed=0, bias=False, zeropoint=False):
-    ps = [make_qbits_problem(M, n, K, dt, seed=seed + 17 * i, zeropoint=zeropoint) for i, n in enumerate(Ns)]
+    ps = [make_qbits_problem(M, n, K, dt, seed=seed + 17 * i, zeropoint=zeropoint, weight_seed=1000 + 17 * i) for i, n in enumerate(Ns)]  # one weight per member, shared by every M
     x = to_torch(ps[0]["x"], dt, dev)  # one shared activation
     packed = [torch.from_numpy(p["packed"]).to(dev) for p in ps]
     scale = [to_torch(p["scale"], dt, dev) for p in ps]
@@ -292,7 +292,7 @@ def test_fused_decode_projections_on_device():
 def _qbytes_problems(M, K, Ns, dt, dev, kind=None, seed=0):
     from helpers import fp8_tensor, make_qbytes_problem
 
-    ps = [make_qbytes_problem(M, n, K, dt, kind=kind, seed=seed + 13 * i) for i, n in enumerate(Ns)]
+    ps = [make_qbytes_problem(M, n, K, dt, kind=kind, seed=seed + 13 * i, weight_seed=2000 + 13 * i) for i, n in enumerate(Ns)]  # one weight per member, shared by every M
     x = to_torch(ps[0]["x"], dt, dev)
     ws = [fp8_tensor(p["data"], kind, dev) if kind else torch.from_numpy(p["data"]).to(dev) for p in ps]
     scales = [to_torch(p["scale"], dt, dev) for p in ps]
