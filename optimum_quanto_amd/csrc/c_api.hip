@@ -751,7 +751,7 @@ int quanto_hip_qbytes_conv2d_depthwise(const void* x, const void* w, const void*
   if (!x || !w || !scales || !y) return QUANTO_HIP_EINVAL;
   const int r = qbytes_conv2d_depthwise(x, w, scales, bias, y, B, cin, H, W, OC, KH, KW, OH, OW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, a_dtype,
                                         b_dtype, out_dtype, reinterpret_cast<hipStream_t>(stream));
-  if (r == QUANTO_HIP_OK) set_last_kernel("conv2d_depthwise");
+  // (the form that ran names itself: "conv2d_depthwise" = quads, "conv2d_depthwise_strip" = 16-byte row chunks)
   return r;
 }
 

@@ -235,6 +235,24 @@ def test_qconv2d_implicit_gemm_gpu(dt, wq, cin, cout, k, s, p, d):
                                                 (40, 1, (3, 5), (2, 1), (1, 2), (1, 2), (13, 11)), (8, 3, 3, 1, 0, 2, (11, 10)), (64, 1, 1, 1, 0, 1, (7, 7)),
                                                 (20, 1, (2, 4), 1, (1, 0), 1, (9, 6)), (96, 1, 3, 1, 1, 1, (56, 56))])
 def test_qconv2d_depthwise_gpu(dt, wq, c, mult, k, s, p, d, hw):
+    _depthwise_case(dt, wq, c, mult, k, s, p, d, hw, ("conv2d_depthwise", "conv2d_depthwise_strip"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("wq", ["qint8", "qfloat8_e4m3fn", "qfloat8_e5m2"])
+@pytest.mark.parametrize("c,mult,k,s,p,hw", [(16, 1, 3, 1, 1, (9, 16)), (8, 2, 3, 2, 1, (13, 24)), (12, 1, 5, 1, 2, (10, 32)), (8, 1, 5, 2, 2, (11, 40)),
+                                              (8, 1, 3, 1, 0, (7, 16)), (8, 3, 3, 2, 0, (9, 24)), (4, 1, 3, 1, 1, (5, 8)), (6, 1, 3, 2, 1, (56, 56)),
+                                              (5, 1, 5, 1, 2, (3, 8)), (3, 1, 3, 1, 1, (1, 64)),
+                                              (10, 1, 3, 1, 1, (28, 28)), (6, 1, 5, 1, 2, (9, 12)), (6, 2, 3, 2, 1, (11, 20)), (4, 1, 5, 2, 2, (8, 4)), (4, 1, 3, 1, 0, (6, 12))])
+def test_qconv2d_depthwise_strip_gpu(dt, wq, c, mult, k, s, p, hw):
+    """r6: the strip form of the depthwise kernel (rows of whole 16-byte chunks: W % 8 == 0; 3 x 3 / 5 x 5 windows, stride 1 or 2, "same" padding or none) - a
+    single chunk per row (both neighbours out of range), ragged groups of output rows, output widths that are not a multiple of the eight columns a thread owns
+    (stride 2), channel multipliers, planes shorter than the window."""
+    _depthwise_case(dt, wq, c, mult, k, s, p, 1, hw, ("conv2d_depthwise_strip",))
+
+
+def _depthwise_case(dt, wq, c, mult, k, s, p, d, hw, kernels):
     """r6: depthwise layers (groups = in_channels; channel multipliers 1, 2, 3) with an int8 / fp8 weight on the stencil kernel of csrc/qconv_depthwise.hip -
     the register windows (3, 5, 7), rectangular and even windows (the generic tap loop), strides, paddings, dilations, widths that are not a multiple of the four
     columns a thread owns, a 56 x 56 MobileNet plane.  Gate: float64 grouped convolution on the stored integers / fp8 values, per-channel scale on the sum, the
@@ -247,7 +265,7 @@ def test_qconv2d_depthwise_gpu(dt, wq, c, mult, k, s, p, d, hw):
     x = torch.randn(3, c, *hw).to(TORCH_DT[dt])
     with torch.no_grad():
         y = q(x.cuda())
-        assert quanto_hip.lib.last_kernel() == "conv2d_depthwise"
+        assert quanto_hip.lib.last_kernel() in kernels
         w64 = q.weight._data.cpu().double() if wq == "qint8" else q.weight._data.cpu().float().double()
         prod = torch.nn.functional.conv2d(x.double(), w64, None, conv.stride, conv.padding, conv.dilation, groups=c)
         prod = prod * q.weight._scale.cpu().double().reshape(1, -1, 1, 1)
