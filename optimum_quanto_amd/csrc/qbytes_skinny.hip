@@ -203,6 +203,18 @@ __global__ void __launch_bounds__(256) qbytes_skinny_kernel(Args a, const Segs s
       if (piece < XPIECES) glds16(xsrc[u] + (size_t)kt * (BK * 2), st + W_BYTES + piece * 1024);
     }
   };
+  // r6: the lane's four scale / bias values are requested HERE, in front of the first DMA (the oldest entries of the in-order vector-memory queue), not
+  // after the K loop: the epilogue used to open with a global round trip (~1 us of a 7-10 us call).  As asm: hipcc would drain the DMA queue at a load it sees.
+  uint32_t sc_raw[4], bv_raw[4] = {0u, 0u, 0u, 0u};
+  {
+    const int nq = n_blk + wave * 16 + 4 * (lane >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nq + r < N ? nq + r : N - 1;
+      asm volatile("global_load_ushort %0, %1, off" : "=v"(sc_raw[r]) : "v"(reinterpret_cast<const T*>(a.scale) + n) : "memory");
+      if (a.bias != nullptr) asm volatile("global_load_ushort %0, %1, off" : "=v"(bv_raw[r]) : "v"(reinterpret_cast<const T*>(a.bias) + n) : "memory");
+    }
+  }
 #pragma unroll
   for (int t = 0; t < STAGES - 2; ++t)
     if (t < nk) issue(t, t);
@@ -306,11 +318,12 @@ __global__ void __launch_bounds__(256) qbytes_skinny_kernel(Args a, const Segs s
   const int n0 = n_blk + wave * 16 + 4 * fg;
   float sc[4], bv[4];
   const bool has_bias = a.bias != nullptr;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // long since complete (requested ahead of the first tile)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int n = n0 + r < N ? n0 + r : N - 1;
-    sc[r] = E::to_f32(reinterpret_cast<const T*>(a.scale)[n]);
-    bv[r] = has_bias ? E::to_f32(reinterpret_cast<const T*>(a.bias)[n]) : 0.f;
+    asm volatile("" : "+v"(sc_raw[r]), "+v"(bv_raw[r]));
+    sc[r] = E::to_f32(__builtin_bit_cast(T, (uint16_t)sc_raw[r]));
+    bv[r] = has_bias ? E::to_f32(__builtin_bit_cast(T, (uint16_t)bv_raw[r])) : 0.f;
   }
 #pragma unroll
   for (int tf = 0; tf < TF; ++tf) {
