@@ -14,11 +14,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // M0 is written and not restored: on gfx9+ the compiler only needs M0 for constructs this kernel does not contain
 // (movrel, GWS, sendmsg, its own LDS-DMA builtins), and two SALU instructions per piece matter in a one-wave-per-SIMD
 // instruction stream where every issue slot next to an MFMA is accounted for.
+#ifndef QH_GLDS_POLICY
+#define QH_GLDS_POLICY ""  // cache policy bits of the operand DMA (probes: " sc1", " nt", " sc0 sc1": profiles/r06_glds_cache_policy_ab.jsonl)
+#endif
 __device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
   asm volatile(
       "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %1"
+      "global_load_lds_dwordx4 %0, %1" QH_GLDS_POLICY
       :
       : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");

@@ -37,11 +37,14 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 // M0 is written and not restored (see qmm_mfma_large.hip: nothing else in these kernels reads it, and every scalar
 // instruction in the K loop takes an MFMA issue gap).
+#ifndef QH_GLDS_POLICY
+#define QH_GLDS_POLICY ""  // cache policy bits of the operand DMA (probes: " sc1", " nt", " sc0 sc1": profiles/r06_glds_cache_policy_ab.jsonl)
+#endif
 __device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_dst) {
   asm volatile(
       "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %1"
+      "global_load_lds_dwordx4 %0, %1" QH_GLDS_POLICY
       :
       : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");
