@@ -46,3 +46,32 @@ def test_no_mfma_kernel_takes_the_high_half_of_src1_into_a_low_result():
         assert "v_mfma" in text, unit
         bad = [ln.strip() for ln in text.splitlines() if re.search(r"\bv_pk_(add|mul|fma)_f32\b", ln) and re.search(r"op_sel:\[[01],1", ln)]
         assert not bad, f"{unit}: {len(bad)} packed fp32 instructions whose low result reads the high half of src1, e.g. {bad[:3]}"
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="needs llvm-objdump")
+def test_the_built_library_itself_carries_no_high_half_src1_packed_fp32():
+    """The two tests above rebuild the listings with the Makefile's flags; this one disassembles the code objects of the library that SHIPS
+    (optimum_quanto_amd/lib/libquanto_hip.so).  r6: a probe build with CXXFLAGS given on the make command line dropped the per-file
+    -fno-slp-vectorize, left six objects of that build behind and produced a library whose int4 large-tile kernel returned wrong lanes on the
+    GPU while both listing tests stayed green."""
+    import importlib.util
+    import tempfile
+
+    lib = os.path.join(ROOT, "optimum_quanto_amd", "lib", "libquanto_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    spec = importlib.util.spec_from_file_location("so_kernel_report", os.path.join(ROOT, "scripts", "so_kernel_report.py"))
+    rep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rep)
+    bad, mfma_objects = [], 0
+    for blob in rep.code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(blob)
+            f.flush()
+            text = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, timeout=900).stdout
+        if "v_mfma" not in text:
+            continue
+        mfma_objects += 1
+        bad += [ln.strip() for ln in text.splitlines() if re.search(r"\bv_pk_(add|mul|fma)_f32\b", ln) and re.search(r"op_sel:\[[01],1", ln)]
+    assert mfma_objects >= 8, mfma_objects
+    assert not bad, f"{len(bad)} packed fp32 instructions whose low result reads the high half of src1 in the shipped library, e.g. {bad[:3]}: rebuild with `make clean && make`"
