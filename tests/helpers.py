@@ -53,7 +53,26 @@ def make_qbits_problem(M, N, K, dt, bits=4, group_size=128, zeropoint=False, see
             _WEIGHT_CACHE[key] = weight(np.random.default_rng(weight_seed))
         wq = _WEIGHT_CACHE[key]
     x = _activations(M, K, dt, rng)
-    return dict(x=x, packed=wq["packed"], scale=wq["scale"], shift=wq["shift"], bits=bits, group_size=group_size, N=N, K=K, dt=dt)
+    return dict(x=x, packed=wq["packed"], scale=wq["scale"], shift=wq["shift"], bits=bits, group_size=group_size, N=N, K=K, dt=dt,
+                wkey=None if weight_seed is None else key)
+
+
+_EXACT_W = {}  # float64 dequantized weights of cached problems, the last six: an M sweep alternates dtype x zero-point (x members of a multi launch)
+
+
+def qbits_exact(p, x=None, bias=None):
+    """O.qbits_mm_exact on a problem of make_qbits_problem (``x``: another activation, e.g. the shared input of a multi launch); the float64
+    weight of a cached problem (``weight_seed``) is kept between the Ms of a sweep instead of being dequantized again for every M."""
+    x = p["x"] if x is None else x
+    key = p.get("wkey")
+    if key is None:
+        return O.qbits_mm_exact(x, p["packed"], p["bits"], p["scale"], p["shift"], p["group_size"], p["N"], p["K"], bias)
+    if key not in _EXACT_W:
+        while len(_EXACT_W) >= 6:
+            _EXACT_W.pop(next(iter(_EXACT_W)))
+        _EXACT_W[key] = O.dequantize_qbits_exact(p["packed"], p["bits"], p["scale"], p["shift"], 0, p["group_size"], (p["N"], p["K"]))
+    y = np.matmul(np.asarray(x, np.float64), _EXACT_W[key].T)
+    return y if bias is None else y + np.asarray(bias, np.float64)
 
 
 def make_qbytes_problem(M, N, K, dt, kind=None, seed=0, wscale=0.02, weight_seed=None):

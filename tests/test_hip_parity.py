@@ -13,7 +13,7 @@ import optimum_quanto_amd as Q
 from optimum_quanto_amd.library.hip import quanto_hip
 from oracle import quanto_oracle as O
 
-from helpers import (TORCH_DT, assert_close_to_exact, assert_close_with_bias, assert_similar, fp8_tensor, make_qbits_problem, make_qbytes_problem,
+from helpers import (TORCH_DT, assert_close_to_exact, assert_close_with_bias, assert_similar, fp8_tensor, make_qbits_problem, make_qbytes_problem, qbits_exact,
                      to_numpy, to_torch)
 
 pytestmark = pytest.mark.gpu
@@ -104,7 +104,7 @@ def _run_qbits(p, kernel, bias=None):
 
 
 def _exact_qbits(p, bias=None):
-    return O.qbits_mm_exact(p["x"], p["packed"], p["bits"], p["scale"], p["shift"], p["group_size"], p["N"], p["K"], bias)
+    return qbits_exact(p, bias=bias)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
@@ -305,7 +305,7 @@ def test_qbits_skinny_small_groups_and_per_channel(dt, zp, M, N, K, gs):
     scales (one table entry per feature, repeated): 1 / 2 / 4 token fragments, passes of 64 rows, K split over workgroups (N = 512,
     K = 4096), long K (448 table rows of 64 features), integer zero-points; exact-math gate and the bias-add sequence.
     r4: group size 96 (in_features = 96 (2j + 1): tiles of 96 k with idle DMA lanes; 2 / 3 tiles, an odd tile count, K split 2 ways)."""
-    p = make_qbits_problem(M, N, K, dt, group_size=gs, zeropoint=zp, seed=M + N + K)
+    p = make_qbits_problem(M, N, K, dt, group_size=gs, zeropoint=zp, seed=M + N + K, weight_seed=N + K + 3)  # one weight per (shape, format): the Ms share it
     y = _run_qbits(p, "skinny")
     assert quanto_hip.lib.last_kernel() == "skinny"
     assert_close_to_exact(y, _exact_qbits(p), dt, f"skinny group_size={gs} {M}x{K}x{N}")

@@ -10,7 +10,7 @@ import torch
 import optimum_quanto_amd as Q
 from oracle import quanto_oracle as O
 
-from helpers import assert_close_to_exact, make_qbits_problem, to_numpy, to_torch
+from helpers import assert_close_to_exact, make_qbits_problem, qbits_exact, to_numpy, to_torch
 
 
 def _problems(M, K, Ns, dt, dev, seed=0, bias=False, zeropoint=False):
@@ -32,7 +32,7 @@ def test_multi_default_equals_separate_ops_cpu():
     for i, n in enumerate(Ns):
         want = torch.ops.quanto.qbits_mm(x, packed[i], scale[i], shift[i], biases[i], 4, 128, n, K)
         assert torch.equal(ys[i], want)
-        exact = O.qbits_mm_exact(ps[0]["x"], ps[i]["packed"], 4, ps[i]["scale"], ps[i]["shift"], 128, n, K) + to_numpy(biases[i])
+        exact = qbits_exact(ps[i], x=ps[0]["x"]) + to_numpy(biases[i])
         assert O.rel_fro(to_numpy(ys[i]), exact) < 1e-5
 
 
@@ -79,7 +79,7 @@ def test_multi_is_bit_identical_to_separate_calls_gpu(dt, M, Ns, K):
     if M == 1 and dt == "bf16":  # and the oracle on the fused launch itself
         for i, n in enumerate(Ns):
             if biases[i] is None:
-                exact = O.qbits_mm_exact(ps[0]["x"], ps[i]["packed"], 4, ps[i]["scale"], ps[i]["shift"], 128, n, K)
+                exact = qbits_exact(ps[i], x=ps[0]["x"])
                 assert_close_to_exact(to_numpy(ys[i]), exact, dt, f"multi segment {i}")
 
 
@@ -133,7 +133,7 @@ def test_multi_batched_decode_one_streaming_launch_gpu(dt, M, Ns, K):
     ys = torch.ops.quanto.qbits_mm_multi(x, packed, scale, shift, biases, 4, 128, list(Ns), K)
     assert lib.last_kernel() == "skinny_multi"
     for i, n in enumerate(Ns):
-        exact = O.qbits_mm_exact(ps[0]["x"], ps[i]["packed"], 4, ps[i]["scale"], ps[i]["shift"], 128, n, K)
+        exact = qbits_exact(ps[i], x=ps[0]["x"])
         y0 = to_numpy(plain[i])
         assert_close_to_exact(y0, exact, dt, f"batched multi M={M} segment {i} (N={n})")
         if bias_np[i] is None:
