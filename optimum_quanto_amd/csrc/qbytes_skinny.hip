@@ -205,14 +205,17 @@ __global__ void __launch_bounds__(256) qbytes_skinny_kernel(Args a, const Segs s
   };
   // r6: the lane's four scale / bias values are requested HERE, in front of the first DMA (the oldest entries of the in-order vector-memory queue), not
   // after the K loop: the epilogue used to open with a global round trip (~1 us of a 7-10 us call).  As asm: hipcc would drain the DMA queue at a load it sees.
-  uint32_t sc_raw[4], bv_raw[4] = {0u, 0u, 0u, 0u};
+  uint32_t sc_raw[4], bv_raw[4];
   {
     const int nq = n_blk + wave * 16 + 4 * (lane >> 4);
+    // no bias: the same loads from the scale vector (unused) - a branch-free sequence, so that nothing but these asm statements ever writes the
+    // destination registers before the counted wait (tests/test_build_invariants.py reads the listing for exactly that)
+    const T* bsrc = reinterpret_cast<const T*>(a.bias != nullptr ? a.bias : a.scale);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = nq + r < N ? nq + r : N - 1;
       asm volatile("global_load_ushort %0, %1, off" : "=v"(sc_raw[r]) : "v"(reinterpret_cast<const T*>(a.scale) + n) : "memory");
-      if (a.bias != nullptr) asm volatile("global_load_ushort %0, %1, off" : "=v"(bv_raw[r]) : "v"(reinterpret_cast<const T*>(a.bias) + n) : "memory");
+      asm volatile("global_load_ushort %0, %1, off" : "=v"(bv_raw[r]) : "v"(bsrc + n) : "memory");
     }
   }
 #pragma unroll

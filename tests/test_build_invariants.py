@@ -75,3 +75,41 @@ def test_the_built_library_itself_carries_no_high_half_src1_packed_fp32():
         bad += [ln.strip() for ln in text.splitlines() if re.search(r"\bv_pk_(add|mul|fma)_f32\b", ln) and re.search(r"op_sel:\[[01],1", ln)]
     assert mfma_objects >= 8, mfma_objects
     assert not bad, f"{len(bad)} packed fp32 instructions whose low result reads the high half of src1 in the shipped library, e.g. {bad[:3]}: rebuild with `make clean && make`"
+
+
+def _regs_in(line):
+    """VGPR numbers a line of gfx950 assembly mentions (single registers and v[a:b] ranges)."""
+    regs = set(int(m) for m in re.findall(r"\bv(\d+)\b", line))
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", line):
+        regs.update(range(int(a), int(b) + 1))
+    return regs
+
+
+@pytest.mark.skipif(not HAVE_HIPCC, reason="needs hipcc")
+@pytest.mark.parametrize("unit", ["qmm_mfma_large", "qmm_native8", "qbytes_skinny"])
+def test_asm_prefetch_registers_are_untouched_until_the_counted_wait(unit):
+    """r6: the tile's scale / bias values are requested by inline-asm ``global_load_ushort`` / ``global_load_dword`` ahead of the operand DMA (hipcc would
+    drain the DMA queue at a load it can see) and used after a hand-counted ``s_waitcnt vmcnt``.  To hipcc the destination is defined the moment the asm
+    statement ends: a register copy or a spill between the load and the wait would read it before the data has landed.  This test reads the listing and
+    fails if any instruction between such a load and the next vmcnt wait mentions its destination register."""
+    listing = os.path.join(CSRC, "build", unit + ".s")
+    proc = subprocess.run(["make", "-C", CSRC, f"build/{unit}.s"], capture_output=True, text=True, timeout=1800)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = open(listing).read().splitlines()
+    loads = 0
+    for i, ln in enumerate(lines):
+        m = re.match(r"\s+global_load_(?:ushort|dword) v(\d+), v\[\d+:\d+\], off\s*$", ln)
+        if not m:
+            continue
+        loads += 1
+        dst = int(m.group(1))
+        for j in range(i + 1, min(i + 4000, len(lines))):
+            nxt = lines[j]
+            if "s_waitcnt" in nxt and "vmcnt(" in nxt:
+                break
+            if re.match(r"\s+global_load_(?:ushort|dword) v\d+, v\[\d+:\d+\], off\s*$", nxt):
+                continue  # the neighbouring prefetch loads (their own destinations are checked in turn; addresses are register pairs)
+            assert dst not in _regs_in(nxt.split(";")[0]), f"{unit}.s:{j + 1}: v{dst} (asm prefetch at line {i + 1}) is touched before the wait: {nxt.strip()}"
+        else:
+            raise AssertionError(f"{unit}.s:{i + 1}: no vmcnt wait after the asm prefetch")
+    assert loads >= 2, f"{unit}: the prefetch loads were not found ({loads})"
