@@ -668,8 +668,11 @@ __device__ __forceinline__ float byte_to_f32(uint32_t d, int b) {  // b: a liter
 // the downsampling 3 x 3 layers and 7 x 7 / 13 x 13 feature maps the pair form cannot take.  An 8-byte window still brings the pixel's three taps
 // of a row (twice the load instructions of the pair form per element, a third fewer than the tap gather), the transposition is 8 rows x 3 elements
 // into three 16-byte pieces.
-template <int DT, int FMT, bool BUF, bool SINGLE>
-__global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
+// DB (r6): TWO LDS buffers (112 KiB: one workgroup per CU) and ONE barrier per K-tile - tile t+1 is staged into the other buffer while slower waves are still
+// multiplying tile t, so the phases of a tile overlap across the waves of the workgroup instead of running one after the other ("the phases of a
+// tile run one after the other inside a workgroup ... a second workgroup on the CU does [help]").  For grids that leave every workgroup a CU of its own anyway.
+template <int DT, int FMT, bool BUF, bool SINGLE, bool DB = false>
+__global__ void __launch_bounds__(NT, DB ? 1 : 2) qconv2d_rows_kernel(const Args a) {
   using namespace rows;
   constexpr int NR = SINGLE ? 8 : 4;  // window rows per thread and K-tile
   using V8 = typename Mma<DT>::V8;
@@ -802,7 +805,8 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
     }
     cw[j] = make_uint4(o[0], o[1], o[2], o[3]);
   };
-  auto write = [&]() {
+  auto write = [&](auto bo_tag) {
+    constexpr int BO = decltype(bo_tag)::value;  // byte offset of the LDS buffer the tile is staged into
     if (QH_CONV_ABLATE & 16) {  // keep the loaded registers alive
       uint32_t t = 0;
 #pragma unroll
@@ -820,7 +824,7 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
     }
     constexpr uint32_t LO = 0x05040100u, HI = 0x07060302u;  // the low / high halves of two registers
     if constexpr (SINGLE) {  // tap j of rows 0 .. 7: 16 bytes of tap block j
-      uint8_t* sa = smem + awr;
+      uint8_t* sa = smem + BO + awr;
       uint32_t t0[4], t1[4], t2[4];
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
@@ -831,7 +835,7 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
       *reinterpret_cast<uint4*>(sa) = make_uint4(t0[0], t0[1], t0[2], t0[3]);
       *reinterpret_cast<uint4*>(sa + 64) = make_uint4(t1[0], t1[1], t1[2], t1[3]);
       *reinterpret_cast<uint4*>(sa + 128) = make_uint4(t2[0], t2[1], t2[2], t2[3]);
-      uint8_t* sb = smem + bwr;
+      uint8_t* sb = smem + BO + bwr;
 #pragma unroll
       for (int j = 0; j < 3; ++j) *reinterpret_cast<uint4*>(sb + 64 * j) = cw[j];
       return;
@@ -840,14 +844,14 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
     const uint2 p1 = make_uint2(__builtin_amdgcn_perm(n0[1], n0[0], HI), __builtin_amdgcn_perm(n0[3], n0[2], HI));
     const uint2 p2 = make_uint2(__builtin_amdgcn_perm(n1[1], n1[0], LO), __builtin_amdgcn_perm(n1[3], n1[2], LO));
     const uint2 p3 = make_uint2(__builtin_amdgcn_perm(n1[1], n1[0], HI), __builtin_amdgcn_perm(n1[3], n1[2], HI));
-    uint8_t* sa = smem + awr;
+    uint8_t* sa = smem + BO + awr;
     *reinterpret_cast<uint2*>(sa) = p0;
     *reinterpret_cast<uint2*>(sa + 64) = p1;
     *reinterpret_cast<uint2*>(sa + 128) = p2;
     *reinterpret_cast<uint2*>(sa + RS) = p1;
     *reinterpret_cast<uint2*>(sa + RS + 64) = p2;
     *reinterpret_cast<uint2*>(sa + RS + 128) = p3;
-    uint8_t* sb = smem + bwr;
+    uint8_t* sb = smem + BO + bwr;
 #pragma unroll
     for (int j = 0; j < 3; ++j) *reinterpret_cast<uint4*>(sb + 64 * j) = cw[j];
   };
@@ -860,19 +864,20 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
   // the MFMA phase, ordered by hand (with a fence behind the loads hipcc otherwise serialises fragment read -> wait -> two MFMAs; without one it
   // sinks the next tile's loads behind the MFMAs): the fragments of k-step kk + 1 are read while the MFMAs of k-step kk run, fences between the steps
   V8 fa[2][4], fb[2][2];
-  auto read_frags = [&](int kk) {
+  auto read_frags = [&](int kk, auto bo_tag) {
+    constexpr int BO = decltype(bo_tag)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[kk & 1][i] = *reinterpret_cast<const V8*>(smem + ard + i * 16 * RS + kk * 64);
+    for (int i = 0; i < 4; ++i) fa[kk & 1][i] = *reinterpret_cast<const V8*>(smem + BO + ard + i * 16 * RS + kk * 64);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fb[kk & 1][j] = *reinterpret_cast<const V8*>(smem + brd + j * 16 * RS + kk * 64);
+    for (int j = 0; j < 2; ++j) fb[kk & 1][j] = *reinterpret_cast<const V8*>(smem + BO + brd + j * 16 * RS + kk * 64);
   };
-  auto mma_phase = [&]() {
+  auto mma_phase = [&](auto bo_tag) {
     if (QH_CONV_ABLATE & 2) return;
-    read_frags(0);
+    read_frags(0, bo_tag);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < 3; ++kk) {
-      if (kk < 2) read_frags(kk + 1);
+      if (kk < 2) read_frags(kk + 1, bo_tag);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -881,26 +886,54 @@ __global__ void __launch_bounds__(NT, 2) qconv2d_rows_kernel(const Args a) {
     }
   };
 
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, rows::LDS_BYTES>;
   issue(0);
 #pragma unroll
   for (int j = 0; j < 3; ++j) convert(j);
-  write();
+  write(B0{});
   __syncthreads();
+  if constexpr (DB) {
+    // tile t is multiplied out of buffer `cur` while tile t + 1 is staged into `nxt`; the one barrier of the tile orders both hand-overs: nxt complete before
+    // anybody reads it, every wave done with cur before the tile after next is staged into it
+    auto step = [&](int t, auto cur, auto nxt) {
+      issue(t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_phase(cur);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) convert(j);
+      __builtin_amdgcn_sched_barrier(0);
+      write(nxt);
+      __syncthreads();
+    };
+    int t = 0;
+    for (; t + 2 < nk; t += 2) {
+      step(t, B0{}, B1{});
+      step(t + 1, B1{}, B0{});
+    }
+    if (t + 1 < nk) {
+      step(t, B0{}, B1{});
+      mma_phase(B1{});
+    } else {
+      mma_phase(B0{});
+    }
+  } else {
   for (int t = 0; t + 1 < nk; ++t) {
     // the next tile's loads first; its weights are converted AFTER the MFMAs, so that no vmcnt wait on loads issued a moment ago stands in front
     // of them.  (Measured against hipcc's own order, which interleaved the conversion: the same time within 1-3 % either way,
     // profiles/r05_qconv2d_rows_ablations*.jsonl - the hand-placed order is kept because it does not move with the compiler.)
     issue(t + 1);
     __builtin_amdgcn_sched_barrier(0);
-    mma_phase();
+    mma_phase(B0{});
 #pragma unroll
     for (int j = 0; j < 3; ++j) convert(j);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // every wave has read tile t
-    write();
+    write(B0{});
     __syncthreads();
   }
-  mma_phase();
+  mma_phase(B0{});
+  }
 
   if (S > 1) {
     f32x4* mine = reinterpret_cast<f32x4*>(a.partials) + ((size_t)(sp * gridDim.y + blockIdx.y) * gridDim.x + nt) * (8 * 8 * 64) + (wave * 8) * 64 + lane;
@@ -987,16 +1020,23 @@ static int launch_rows(Args a, int ntiles, int mtiles, hipStream_t stream) {  //
   g_last_rows = true;
   const int nk_rows = (a.cin * a.KH + rows::RT - 1) / rows::RT;
   a.S = a.S < nk_rows ? a.S : nk_rows;
+  // two LDS buffers where every workgroup has a CU to itself anyway (QUANTO_HIP_CONV_ROWS_DB: 0 never, 2 always - experiments)
+  const int dbk = env_int("QUANTO_HIP_CONV_ROWS_DB", 1);
+  const bool db = dbk == 2 || (dbk == 1 && (int64_t)ntiles * mtiles * a.S <= 256 && nk_rows / a.S >= 2);
+#define QH_ROWS(BUF, SINGLE, DB)                                                                                                                       \
+  do {                                                                                                                                                 \
+    constexpr int lds = (DB ? 2 : 1) * rows::LDS_BYTES;                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, BUF, SINGLE, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, BUF, SINGLE, DB>), dim3(ntiles, mtiles, a.S), dim3(NT), lds, stream, a);                          \
+  } while (0)
   if (!rows_pairs(a.OW, a.sw)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
-    hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, true, true>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
+    if (db) QH_ROWS(true, true, true); else QH_ROWS(true, true, false);
   } else if (env_int("QUANTO_HIP_CONV_ROWS", 1) == 2) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
-    hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, false, false>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
+    QH_ROWS(false, false, false);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qconv2d_rows_kernel<DT, FMT, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, rows::LDS_BYTES);
-    hipLaunchKernelGGL((qconv2d_rows_kernel<DT, FMT, true, false>), dim3(ntiles, mtiles, a.S), dim3(NT), rows::LDS_BYTES, stream, a);
+    if (db) QH_ROWS(true, false, true); else QH_ROWS(true, false, false);
   }
+#undef QH_ROWS
   if (a.S > 1) hipLaunchKernelGGL((qconv2d_reduce_kernel<DT, 1>), dim3(ntiles, mtiles, 8), dim3(64), 0, stream, a);
   return launch_status();
 }

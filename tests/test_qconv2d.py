@@ -683,6 +683,32 @@ def test_qconv2d_subbyte_row_form_gpu(monkeypatch, dt, bits, zp, gs, cin, cout, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wq", ["qint8", "qfloat8_e4m3fn", "qint4"])
+@pytest.mark.parametrize("cin,cout,k,s,p,hw,split", [(128, 128, 3, 1, 1, (28, 28), 1), (128, 200, 3, 1, 1, (17, 10), 5), (24, 136, 3, 1, 1, (9, 10), 1),
+                                                      (128, 128, 3, 2, 1, (28, 28), 1), (64, 40, 3, 1, 1, (9, 7), 2), (8, 40, (1, 3), 1, (0, 1), (5, 4), 1)])
+def test_qconv2d_row_form_two_lds_buffers_bit_equal_gpu(monkeypatch, wq, cin, cout, k, s, p, hw, split):
+    """r6: the row form with TWO LDS buffers and one barrier per K-tile (grids that leave every workgroup a CU of its own) stages and multiplies the same
+    operands in the same order as the one-buffer form: forced on (2) and off (0) the outputs are bit-identical - pair and one-pixel mappings, K split, a
+    single K-tile (no second buffer ever filled), ragged last tiles, sub-byte weights through the dense route."""
+    monkeypatch.setenv("QUANTO_HIP_CONV_SPLIT", str(split))
+    monkeypatch.setenv("QUANTO_HIP_CONV_DENSE_MIN_TILES", "1")
+    torch.manual_seed(cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=s, padding=p).to(torch.bfloat16)
+    q = Q.QConv2d.from_module(conv, weights=getattr(Q, wq))
+    Q.freeze(q)
+    q = q.cuda()
+    x = torch.randn(3, cin, *hw).to(torch.bfloat16).cuda()
+    ys = {}
+    with torch.no_grad():
+        for db in ("0", "2"):
+            monkeypatch.setenv("QUANTO_HIP_CONV_ROWS_DB", db)
+            ys[db] = q(x)
+            assert quanto_hip.lib.last_kernel() in ("conv2d_mfma_rows", "qbits_conv2d_rows", "conv2d_dense_rows") or "rows" in quanto_hip.lib.last_kernel()
+    assert torch.isfinite(ys["0"].float()).all()
+    assert torch.equal(ys["0"], ys["2"]), f"{(ys['0'] != ys['2']).sum().item()} of {ys['0'].numel()} elements differ"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("split", [1, 2, 5, 64])
 def test_qconv2d_row_form_k_split_gpu(monkeypatch, split):
     """The row form under the K split (12 K-tiles of 32 window rows: 5 is ragged, 64 is clamped to 12) and against the tap gather on the same call."""
