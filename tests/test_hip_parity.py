@@ -818,8 +818,8 @@ def test_large_tile_int4_gemm_operands_are_the_dequantized_weight():
 def test_auto_takes_the_large_tile_int4_gemm_where_it_wins():
     """8192^3.  r5: with a workspace AUTO = dequantize + dense GEMM again (the 128-byte-row dense kernel: 791 vs 959 us); WITHOUT one (the C entry
     called with a null workspace) AUTO = the large-tile int4 GEMM, which needs none.  Both multiply the same rounded weight, so their outputs may
-    only differ by the fp32 accumulation order: compared element by element in bf16 ulps (a float64 product of this size is left to the smaller
-    shapes above); 24 sampled rows against the float64 oracle."""
+    only differ by the fp32 accumulation order: compared element by element in bf16 ulps, and the large-tile kernel's whole output against the float64
+    product with the reference's rounded weight."""
     M, N, K = 8192, 8192, 8192
     g = torch.Generator(device=DEV).manual_seed(5)
     x = torch.randn((M, K), generator=g, device=DEV).to(torch.bfloat16)
@@ -836,10 +836,12 @@ def test_auto_takes_the_large_tile_int4_gemm_where_it_wins():
     ulps = O.ulp_distance(to_numpy(y), to_numpy(y2), "bf16")
     big = np.abs(to_numpy(y2)) > 1e-2 * np.abs(to_numpy(y2)).max()
     assert (ulps <= 1).mean() >= 0.995 and ulps[big].max() <= 2
-    rows = np.random.default_rng(0).choice(M, 24, replace=False)
-    w = O.dequantize_qbits_ref(p["packed"], 4, p["scale"], p["shift"], 0, 128, (N, K), "bf16").astype(np.float64)
-    want = np.matmul(to_numpy(x[torch.from_numpy(rows).to(DEV)]).astype(np.float64), w.T)
-    assert_close_to_exact(to_numpy(y)[rows], want, "bf16", "large int4 8192^3, sampled rows")
+    # r6: the WHOLE output against the float64 product with the reference's rounded weight (r5 sampled 24 rows), in blocks of 1024 rows
+    w = np.ascontiguousarray(O.dequantize_qbits_ref(p["packed"], 4, p["scale"], p["shift"], 0, 128, (N, K), "bf16").astype(np.float64).T)
+    yn = to_numpy(y)
+    for r0 in range(0, M, 1024):
+        want = np.matmul(to_numpy(x[r0:r0 + 1024]).astype(np.float64), w)
+        assert_close_to_exact(yn[r0:r0 + 1024], want, "bf16", f"large int4 8192^3, rows {r0}..{r0 + 1023}")
 
 
 def test_int4_prefill_4096_cubed():
