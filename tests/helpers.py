@@ -97,7 +97,21 @@ def make_qbytes_problem(M, N, K, dt, kind=None, seed=0, wscale=0.02, weight_seed
             _WEIGHT_CACHE[key] = weight(np.random.default_rng(weight_seed))
         wq = _WEIGHT_CACHE[key]
     x = _activations(M, K, dt, rng)
-    return dict(x=x, data=wq["data"], scale=wq["scale"], kind=kind, N=N, K=K, dt=dt)
+    return dict(x=x, data=wq["data"], scale=wq["scale"], kind=kind, N=N, K=K, dt=dt, wkey=None if weight_seed is None else key)
+
+
+def qbytes_exact(p, x=None):
+    """O.qbytes_mm_exact on a problem of make_qbytes_problem; the float64 image of a cached weight is kept between the Ms of a sweep."""
+    x = p["x"] if x is None else x
+    key = p.get("wkey")
+    if key is None:
+        return O.qbytes_mm_exact(x, p["data"], p["scale"], p["kind"])
+    if key not in _EXACT_W:
+        while len(_EXACT_W) >= 6:
+            _EXACT_W.pop(next(iter(_EXACT_W)))
+        w = O.fp8_decode(p["data"], p["kind"]).astype(np.float64) if p["kind"] else np.asarray(p["data"]).astype(np.float64)
+        _EXACT_W[key] = np.ascontiguousarray(w.T)
+    return np.matmul(np.asarray(x, np.float64), _EXACT_W[key]) * np.asarray(p["scale"], np.float64).reshape(1, -1)
 
 
 def assert_close_to_exact(y: np.ndarray, y_exact: np.ndarray, dt: str, what=""):

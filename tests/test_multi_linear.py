@@ -10,7 +10,7 @@ import torch
 import optimum_quanto_amd as Q
 from oracle import quanto_oracle as O
 
-from helpers import assert_close_to_exact, make_qbits_problem, qbits_exact, to_numpy, to_torch
+from helpers import assert_close_to_exact, make_qbits_problem, qbits_exact, qbytes_exact, to_numpy, to_torch
 
 
 def _problems(M, K, Ns, dt, dev, seed=0, bias=False, zeropoint=False):
@@ -346,7 +346,7 @@ def test_qbytes_multi_one_launch_gpu(dt, kind, M, Ns, K):
     assert lib.last_kernel() == ("gemv_multi" if M <= 2 else "skinny_multi")
     ys = torch.ops.quanto.qbytes_mm_multi(x, ws, scales, biases)
     for i, n in enumerate(Ns):
-        exact = O.qbytes_mm_exact(ps[0]["x"], ps[i]["data"], ps[i]["scale"], ps[i]["kind"])
+        exact = qbytes_exact(ps[i], x=ps[0]["x"])
         y0 = to_numpy(plain[i])
         assert_close_to_exact(y0, exact, dt, f"qbytes multi M={M} member {i} (N={n})")
         if M <= 2:
